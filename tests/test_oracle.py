@@ -1,0 +1,115 @@
+"""CPU oracle (oracle/ahv_oracle.c, oracle/torch_ref.py) pinned against the golden vectors that
+tools/gen_golden.py produced by running the reference's own code.  No GPU."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden
+
+RTOL = 1e-5  # oracle vs reference: same fp32 maths, different summation order only
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def test_rotate_volume_matches_reference(oracle, g128):
+    out = oracle.rotate_volume(g128["vol_src"], g128["R"][:2])
+    assert out.shape == (2, 16, 8, 8, 8)
+    assert relerr(out, g128["rot_first2"]) < RTOL
+
+
+def test_forward_3d2d_matches_reference(oracle, g128):
+    f_tgt = oracle.forward_3d2d(g128["vol_tgt"], g128["W1"], g128["W2"], g128["b2"])
+    assert relerr(f_tgt, g128["f_tgt"]) < RTOL
+    f_src = oracle.forward_3d2d(g128["rot_first2"], g128["W1"], g128["W2"], g128["b2"])
+    assert relerr(f_src, g128["f_src_first2"]) < RTOL
+    # unit norm along channels (modules/modules.py:122)
+    assert np.allclose(np.linalg.norm(f_src, axis=1), 1.0, atol=1e-5)
+
+
+def test_score_and_argmax_n128(oracle, g128):
+    scores, best, idx = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], g128["R"], g128["W1"],
+                                                g128["W2"], g128["b2"])
+    assert relerr(scores, g128["scores"]) < RTOL
+    assert idx[0] == g128["best_idx"][0]
+    assert abs(best[0] - g128["best"][0]) <= 1e-6
+
+
+def test_score_n4096(oracle, g128):
+    g = load_golden("score_n4096")
+    scores, best, idx = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], g["R"], g128["W1"], g128["W2"],
+                                                g128["b2"])
+    assert np.max(np.abs(scores - g["scores"]) / np.abs(g["scores"]).clip(1e-3)) < 1e-4
+    assert idx[0] == g["best_idx"][0]
+    assert float(g["top2_margin"]) > 1e-4  # arg-max is well separated from fp32 noise
+
+
+def test_score_n50k_digest(oracle, ahv, g128):
+    g = load_golden("score_n50k_digest")
+    R = ahv.rotations.haar_rotations_np(int(g["n"]), int(g["seed"]))
+    assert hashlib.sha256(R.tobytes()).hexdigest() == str(g["R_sha256"])
+    scores, best, idx = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], R, g128["W1"], g128["W2"],
+                                                g128["b2"])
+    assert idx[0] == g["best_idx"][0]
+    assert relerr(scores[0, ::97], g["every97_score"]) < RTOL
+    assert relerr(scores[0, g["top16_idx"]], g["top16_score"]) < RTOL
+    order = np.argsort(-scores[0], kind="stable")[:16]
+    assert list(order) == list(g["top16_idx"])
+
+
+def test_edge_rotations(oracle, g128):
+    g = load_golden("edge_rotations")
+    rot = oracle.rotate_volume(g128["vol_src"], g["R"])
+    names = list(g["names"])
+    # identity reproduces the volume bit for bit; 90-degree rotations permute voxels exactly
+    assert np.array_equal(rot[names.index("identity")], g128["vol_src"][0])
+    for i in range(1, 25):
+        assert np.array_equal(np.sort(rot[i].ravel()), np.sort(g128["vol_src"][0].ravel()))
+    assert relerr(rot[g["rot_keep_idx"]], g["rot_keep"]) < RTOL
+    zero_frac = (rot == 0).reshape(rot.shape[0], -1).mean(axis=1)
+    assert np.allclose(zero_frac, g["rot_zero_frac"], atol=2e-3)
+    assert zero_frac[names.index("double")] == pytest.approx(0.875)
+    scores, best, idx = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], g["R"], g128["W1"], g128["W2"],
+                                                g128["b2"])
+    assert np.max(np.abs(scores - g["scores"])) < 2e-6
+    assert idx[0] == g["best_idx"][0]
+
+
+def test_batched_shared_and_per_sample(oracle, g128):
+    g = load_golden("batched")
+    s, best, idx = oracle.score_hypotheses(g["vol_src"], g["vol_tgt"], g["R_shared"], g128["W1"], g128["W2"],
+                                           g128["b2"])
+    assert relerr(s, g["scores_shared"]) < RTOL
+    assert list(idx) == list(g["best_idx_shared"])
+    s2, _, _ = oracle.score_hypotheses(g["vol_src"], g["vol_tgt"], g["R_per"], g128["W1"], g128["W2"], g128["b2"])
+    assert relerr(s2, g["scores_per"]) < RTOL
+
+
+def test_metric(oracle):
+    g = load_golden("metric")
+    err = oracle.geodesic_deg(g["R_pred"], g["R_gt"])
+    assert np.allclose(err, g["err_deg"], atol=2e-2, equal_nan=True)
+    assert err[0] == 0.0 and abs(err[1] - 180.0) < 1e-3 and abs(err[2] - 15.0) < 1e-3
+
+
+def test_argmax_first_index_and_nan(oracle):
+    s = np.array([[0.1, 0.7, 0.7, 0.2], [np.nan, 1.0, np.nan, 0.0]], dtype=np.float32)
+    best, idx = oracle.argmax(s)
+    tb, ti = torch.max(torch.from_numpy(s), dim=1)
+    assert list(idx) == list(ti.numpy())
+    assert best[0] == tb[0].item() and np.isnan(best[1])
+
+
+def test_torch_ref_matches_reference(g128):
+    """The torch op-sequence restatement timed as cpu_baseline equals the reference outputs."""
+    from oracle import torch_ref
+    t = lambda k: torch.from_numpy(g128[k])
+    scores, best, idx = torch_ref.score_hypotheses(t("vol_src"), t("vol_tgt"), t("R"), t("W1"), t("W2"), t("b2"))
+    assert np.array_equal(scores.numpy(), g128["scores"])  # same ATen ops, same order: bit-exact
+    assert idx.item() == int(g128["best_idx"][0])
+    scores_c, _, idx_c = torch_ref.score_hypotheses(t("vol_src"), t("vol_tgt"), t("R"), t("W1"), t("W2"), t("b2"),
+                                                    chunk=50)
+    assert relerr(scores_c.numpy(), g128["scores"]) < 1e-6 and idx_c.item() == idx.item()
