@@ -1,0 +1,75 @@
+"""ctypes binding of libahv_hip.so (the C ABI in include/ahv.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.  ``build()`` compiles it with hipcc for gfx950 (works
+without a GPU: hipcc cross-compiles).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libahv_hip.so")
+
+AHV_SCORE_RESET_BEST = 1
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_u32 = ctypes.c_uint
+
+# name -> (restype, argtypes); mirrors include/ahv.h declaration by declaration
+SIGNATURES = {
+    "ahv_abi_version": (_int, []),
+    "ahv_last_error": (ctypes.c_char_p, []),
+    "ahv_device_cu_count": (_int, []),
+    "ahv_score_hypotheses_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32, _vp]),
+    "ahv_unpack_best": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ahv_rotate_volume_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
+    "ahv_forward_3d2d_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "ahv_score_features_f32": (_int, [_vp, _vp, _int, _i64, _vp, _vp]),
+    "ahv_argmax_f32": (_int, [_vp, _int, _i64, _i64, _vp, _u32, _vp]),
+}
+
+_lib = None
+
+
+class AhvError(RuntimeError):
+    """A libahv_hip call returned a negative status."""
+
+
+def build(force: bool = False) -> str:
+    """Compile libahv_hip.so in-tree with hipcc --offload-arch=gfx950."""
+    args = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    proc = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("building libahv_hip.so failed:\n" + proc.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and type its entry points; raises if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C 3dahv_amd/csrc`."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status < 0:
+        msg = load().ahv_last_error().decode("utf-8", "replace")
+        raise AhvError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,169 @@
+// ahv_abi.hip -- the C ABI declared in include/ahv.h: argument validation, error
+// strings, launches.  No allocation, no host synchronisation, no exceptions.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/ahv.h"
+
+namespace ahv {
+hipError_t launch_score_hypotheses(const float*, const float*, const float*, int64_t, int64_t, const float*,
+                                   const float*, const float*, int, int64_t, float*, uint64_t*, int, hipStream_t);
+hipError_t launch_unpack_best(const uint64_t*, int, float*, int64_t*, hipStream_t);
+hipError_t launch_rotate_volume(const float*, int64_t, const float*, int64_t, int, int, int, int, float*, int,
+                                hipStream_t);
+hipError_t launch_forward_3d2d(const float*, const float*, const float*, const float*, int64_t, float*, int,
+                               hipStream_t);
+hipError_t launch_score_features(const float*, const float*, int, int64_t, float*, int, hipStream_t);
+hipError_t launch_argmax(const float*, int, int64_t, int64_t, uint64_t*, int, hipStream_t);
+}  // namespace ahv
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(const char* what, hipError_t e)
+{
+    return fail(AHV_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+// CU count of the current device, cached per device id.
+int cu_count()
+{
+    static thread_local int cached_dev = -1, cached_cu = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev != cached_dev) {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+            return -1;
+        cached_dev = dev;
+        cached_cu = cu;
+    }
+    return cached_cu;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ahv_abi_version(void) { return (1 << 16) | 0; }
+
+const char* ahv_last_error(void) { return g_err; }
+
+int ahv_device_cu_count(void)
+{
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    return cu;
+}
+
+int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                             int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2,
+                             const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
+                             unsigned flags, void* stream)
+{
+    if (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2) return fail(AHV_EINVAL, "score: null input pointer");
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "score: negative size (B=%d, N=%lld)", B, (long long)N);
+    if (r_batch_stride != 0 && r_batch_stride < N * 9)
+        return fail(AHV_EINVAL, "score: r_batch_stride %lld must be 0 or >= N*9", (long long)r_batch_stride);
+    if (n_offset < 0 || n_offset + N > 4294967296ll)
+        return fail(AHV_EINVAL, "score: n_offset + N must fit in 32 bits");
+    if (flags & ~AHV_SCORE_RESET_BEST) return fail(AHV_EINVAL, "score: unknown flags 0x%x", flags);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (best_key && (flags & AHV_SCORE_RESET_BEST) && B > 0) {
+        hipError_t e = hipMemsetAsync(best_key, 0, sizeof(uint64_t) * (size_t)B, s);
+        if (e != hipSuccess) return hip_fail("score: hipMemsetAsync(best_key)", e);
+    }
+    if (B == 0 || N == 0) return AHV_OK;
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    hipError_t e = ahv::launch_score_hypotheses(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N,
+                                                scores, best_key, cu, s);
+    if (e != hipSuccess) return hip_fail("score: launch", e);
+    return AHV_OK;
+}
+
+int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
+{
+    if (!best_key) return fail(AHV_EINVAL, "unpack: null best_key");
+    if (B < 0) return fail(AHV_EINVAL, "unpack: negative B");
+    if (B == 0) return AHV_OK;
+    hipError_t e = ahv::launch_unpack_best(best_key, B, best_score, best_idx, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("unpack: launch", e);
+    return AHV_OK;
+}
+
+int ahv_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C, int D,
+                          int H, int W, float* out, void* stream)
+{
+    if (!vol || !R || !out) return fail(AHV_EINVAL, "rotate_volume: null pointer");
+    if (N < 0 || C < 1 || D < 1 || H < 1 || W < 1)
+        return fail(AHV_EINVAL, "rotate_volume: bad shape N=%lld C=%d D=%d H=%d W=%d", (long long)N, C, D, H, W);
+    if (vol_batch_stride < 0) return fail(AHV_EINVAL, "rotate_volume: negative batch stride");
+    if (N == 0) return AHV_OK;
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    hipError_t e = ahv::launch_rotate_volume(vol, vol_batch_stride, R, N, C, D, H, W, out, cu,
+                                             static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("rotate_volume: launch", e);
+    return AHV_OK;
+}
+
+int ahv_forward_3d2d_f32(const float* vol, const float* W1, const float* W2, const float* b2, int64_t M,
+                         float* out, void* stream)
+{
+    if (!vol || !W1 || !W2 || !b2 || !out) return fail(AHV_EINVAL, "forward_3d2d: null pointer");
+    if (M < 0) return fail(AHV_EINVAL, "forward_3d2d: negative M");
+    if (M == 0) return AHV_OK;
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    hipError_t e = ahv::launch_forward_3d2d(vol, W1, W2, b2, M, out, cu, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("forward_3d2d: launch", e);
+    return AHV_OK;
+}
+
+int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_t N, float* scores, void* stream)
+{
+    if (!f_src || !f_tgt || !scores) return fail(AHV_EINVAL, "score_features: null pointer");
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "score_features: negative size");
+    if (B == 0 || N == 0) return AHV_OK;
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    hipError_t e = ahv::launch_score_features(f_src, f_tgt, B, N, scores, cu, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("score_features: launch", e);
+    return AHV_OK;
+}
+
+int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key, unsigned flags,
+                   void* stream)
+{
+    if (!scores || !best_key) return fail(AHV_EINVAL, "argmax: null pointer");
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "argmax: negative size");
+    if (B > 65535) return fail(AHV_EINVAL, "argmax: B > 65535");
+    if (n_offset < 0 || n_offset + N > 4294967296ll) return fail(AHV_EINVAL, "argmax: n_offset + N must fit in 32 bits");
+    if (flags & ~AHV_SCORE_RESET_BEST) return fail(AHV_EINVAL, "argmax: unknown flags 0x%x", flags);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((flags & AHV_SCORE_RESET_BEST) && B > 0) {
+        hipError_t e = hipMemsetAsync(best_key, 0, sizeof(uint64_t) * (size_t)B, s);
+        if (e != hipSuccess) return hip_fail("argmax: hipMemsetAsync(best_key)", e);
+    }
+    if (B == 0 || N == 0) return AHV_OK;
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    hipError_t e = ahv::launch_argmax(scores, B, N, n_offset, best_key, cu, s);
+    if (e != hipSuccess) return hip_fail("argmax: launch", e);
+    return AHV_OK;
+}
+
+}  // extern "C"

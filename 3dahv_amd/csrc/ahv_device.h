@@ -1,0 +1,282 @@
+// ahv_device.h -- device-side building blocks shared by the fused scorer and the
+// op-level kernels (gfx950 / CDNA4 only: wave64, fp32 MFMA 16x16x4, 160 KiB LDS).
+//
+// Geometry (fixed by the reference): volume V[c][d][h][w], c<16, d,h,w<8
+// (modules/modules.py:64,97); head GEMM K = 3*16*8 = 384 -> 32 channels at 64
+// positions (modules/modules.py:66-70,112-124).
+//
+// Work decomposition: ONE WAVE OWNS ONE HYPOTHESIS.  The wave keeps the whole
+// 32x384 W1 matrix as MFMA A-fragments in its own registers (192 VGPRs; the
+// kernel runs one wave per SIMD with the 512-register budget), produces the
+// rotated volume a QUARTER at a time (d in {2q,2q+1}: 128 voxels x 16 ch = 8 KiB)
+// into a private LDS buffer, and contracts that quarter against W1 with
+// v_mfma_f32_16x16x4_f32.  Waves never synchronise with each other inside the
+// hypothesis loop: no s_barrier on the hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ahv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- LDS images -------------------------------------------------------------
+// Source volume, channel-last, one 80-byte row per voxel (16 ch + 4 pad floats):
+// a trilinear corner is four ds_read_b128; the 80-B stride maps voxel v, chunk k
+// to 16-B slot (5v + k) mod 16, which spreads neighbouring voxels over all slots.
+constexpr int kSrcStride = 20;
+constexpr int kSrcFloats = 512 * kSrcStride;  // 40 KiB
+// Rotated quarter: [16 c][128] floats, the 128 voxels (a0, b, e) of a plane XOR-
+// swizzled so that all three slab read patterns AND the producer's writes are
+// ds_*_b32 bank-conflict free (bank = addr mod 32 per 32-lane half):
+//   bank bits = [e0, e1^b1, e2^b2, a0, b0], bits 5,6 = b1,b2
+constexpr int kQuarterFloats = 16 * 128;  // 8 KiB
+
+__device__ __forceinline__ int qoff(int a0, int b, int e)
+{
+    return (e ^ (b & 6)) | (a0 << 3) | ((b & 1) << 4) | ((b >> 1) << 5);
+}
+
+// Orders a wave's own LDS writes before its later LDS reads/writes at compiler
+// level.  Hardware executes one wave's DS instructions in order, so no
+// instruction is needed; without this the compiler may legally hoist a lane's
+// read above another lane's write (per-thread alias analysis).
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- head weights as MFMA fragments ------------------------------------------
+// v_mfma_f32_16x16x4_f32: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15],
+// D[row = 4*(lane>>4)+reg][col = lane&15].  Rows = output channels (2 m-tiles of 16),
+// columns = positions (4 n-tiles of 16: tile t holds positions i in {2t,2t+1}, j<8).
+struct HeadFrags {
+    float ax[16][2][2];  // x slab  [c][eh][m]  : W1[16m+row][      c*8 + 4*eh + kq]   (k = w)
+    float ay[16][2][2];  // y slab  [c][bh][m]  : W1[16m+row][128 + c*8 + 4*bh + kq]   (k = h)
+    float az[4][8][2];   // z slab  [q][cp][m]  : W1[16m+row][256 + (2cp+(kq>>1))*8 + 2q+(kq&1)]  (k = d)
+    float a2[2][4][2];   // GEMM2   [m][r][m2]  : W2[16m2+row][16m + 4kq + r]
+    f32x4 bias[2];       // [m2]                : b2[16m2 + 4kq + r]
+};
+
+__device__ __forceinline__ void load_head_frags(HeadFrags& f, const float* __restrict__ W1,
+                                                const float* __restrict__ W2,
+                                                const float* __restrict__ b2, int lane)
+{
+    const int row = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float* w = W1 + (16 * m + row) * 384;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f.ax[c][hh][m] = w[c * 8 + 4 * hh + kq];
+                f.ay[c][hh][m] = w[128 + c * 8 + 4 * hh + kq];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cp = 0; cp < 8; ++cp)
+                f.az[q][cp][m] = w[256 + (2 * cp + (kq >> 1)) * 8 + 2 * q + (kq & 1)];
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f.a2[m][r][m2] = W2[(16 * m2 + row) * 32 + 16 * m + 4 * kq + r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f.bias[m2][r] = b2[16 * m2 + 4 * kq + r];
+    }
+}
+
+// ---- source volume -> LDS (channel-last, padded) ---------------------------------
+__device__ __forceinline__ void stage_src_volume(float* srcT, const float* __restrict__ vol, int tid,
+                                                 int nthreads)
+{
+    for (int i = tid; i < 16 * 512; i += nthreads) {
+        const int c = i >> 9, v = i & 511;
+        srcT[v * kSrcStride + c] = vol[i];
+    }
+}
+
+// ---- trilinear gather of one 64-voxel pass -----------------------------------------
+// Voxel of this lane: (d, h, w).  Semantics = F.affine_grid + F.grid_sample(bilinear,
+// zeros, align_corners=False) as called by utils.rotate_volume (utils.py:123-129):
+//   p = ((2w+1)/8-1, (2h+1)/8-1, (2d+1)/8-1); g = R p; i = ((g+1)*8-1)/2 per axis;
+//   8 neighbours floor(i), floor(i)+1, each dropped when outside [0,7] (zeros padding
+//   per corner).  g[0] indexes W, g[1] H, g[2] D.
+struct TriCoef {
+    float w[8];  // corner weights, order (dz,dy,dx), zero for out-of-range corners
+    int a[8];    // float index of the corner's row in the channel-last source image
+};
+
+__device__ __forceinline__ void axis_coef(float g, float& w0, float& w1, int& o0, int& o1, int scale)
+{
+    float i = ((g + 1.0f) * 8.0f - 1.0f) * 0.5f;
+    // Clamp keeps the int conversion defined for any R (inf/NaN included); every
+    // clamped-away position has all corners out of range anyway (weight 0).
+    i = fminf(fmaxf(i, -2.0f), 9.0f);
+    const float fl = floorf(i);
+    const float t = i - fl;
+    const int i0 = (int)fl;
+    const int i1 = i0 + 1;
+    w0 = ((unsigned)i0 < 8u) ? 1.0f - t : 0.0f;
+    w1 = ((unsigned)i1 < 8u) ? t : 0.0f;
+    o0 = min(max(i0, 0), 7) * scale;
+    o1 = min(max(i1, 0), 7) * scale;
+}
+
+__device__ __forceinline__ void tri_coef(TriCoef& k, const float* Rm, float x, float y, float z)
+{
+    const float gx = Rm[0] * x + Rm[1] * y + Rm[2] * z;
+    const float gy = Rm[3] * x + Rm[4] * y + Rm[5] * z;
+    const float gz = Rm[6] * x + Rm[7] * y + Rm[8] * z;
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+    int ox0, ox1, oy0, oy1, oz0, oz1;
+    axis_coef(gx, wx0, wx1, ox0, ox1, kSrcStride);
+    axis_coef(gy, wy0, wy1, oy0, oy1, 8 * kSrcStride);
+    axis_coef(gz, wz0, wz1, oz0, oz1, 64 * kSrcStride);
+    const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
+    k.w[0] = w00 * wx0; k.w[1] = w00 * wx1; k.w[2] = w01 * wx0; k.w[3] = w01 * wx1;
+    k.w[4] = w10 * wx0; k.w[5] = w10 * wx1; k.w[6] = w11 * wx0; k.w[7] = w11 * wx1;
+    const int a00 = oz0 + oy0, a01 = oz0 + oy1, a10 = oz1 + oy0, a11 = oz1 + oy1;
+    k.a[0] = a00 + ox0; k.a[1] = a00 + ox1; k.a[2] = a01 + ox0; k.a[3] = a01 + ox1;
+    k.a[4] = a10 + ox0; k.a[5] = a10 + ox1; k.a[6] = a11 + ox0; k.a[7] = a11 + ox1;
+}
+
+// Blend the 16 channels of one output voxel from the LDS source image.
+__device__ __forceinline__ void tri_blend(float (&out)[16], const float* srcT, const TriCoef& k)
+{
+#pragma unroll
+    for (int c = 0; c < 16; ++c) out[c] = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(srcT + k.a[n]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = row[j];
+            out[4 * j + 0] += k.w[n] * v[0];
+            out[4 * j + 1] += k.w[n] * v[1];
+            out[4 * j + 2] += k.w[n] * v[2];
+            out[4 * j + 3] += k.w[n] * v[3];
+        }
+    }
+}
+
+// Produce quarter Q (d in {2Q, 2Q+1}) of the rotated volume into `buf` (swizzled planes).
+// Two passes of 64 voxels; lane -> (w = l&7, d0 = (l>>3)&1, h = 4p + 2*((l>>5)&1) + ((l>>4)&1)),
+// a mapping whose ds_write_b32 hits 32 distinct banks per half-wave.
+template <int Q>
+__device__ __forceinline__ void tri_quarter(float* buf, const float* srcT, const float* Rm, int lane)
+{
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+    const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
+    const float z = (2.0f * (2 * Q + a0) + 1.0f) * 0.125f - 1.0f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int b = 4 * p + 2 * b1 + b0;
+        const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
+        TriCoef k;
+        tri_coef(k, Rm, x, y, z);
+        float o[16];
+        tri_blend(o, srcT, k);
+        float* dst = buf + qoff(a0, b, e);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c * 128] = o[c];
+    }
+}
+
+// ---- GEMM1 on one quarter ---------------------------------------------------------
+// u[o][i][j] += sum_{c,k} W1x[o][c,k] V'[c][i][j][k] + W1y[o][c,k] V'[c][i][k][j] + W1z[o][c,k] V'[c][k][i][j]
+// (modules/modules.py:115-120) restricted to the voxels d in {2Q,2Q+1} of V':
+//   x slab: positions (d,h) of this quarter = n-tile Q, all k=(c,w)      -> 64 MFMA
+//   y slab: positions (d,w) of this quarter = n-tile Q, all k=(c,h)      -> 64 MFMA
+//   z slab: all positions (h,w) = 4 n-tiles,  k=(c,d) for the 2 d's      -> 64 MFMA
+template <int Q>
+__device__ __forceinline__ void gemm1_quarter(f32x4 (&acc)[2][4], const HeadFrags& f, const float* buf,
+                                              int lane)
+{
+    const int n = lane & 15, kq = lane >> 4;
+    const int i0 = n >> 3, j = n & 7;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int eh = 0; eh < 2; ++eh) {
+            const float bx = buf[c * 128 + qoff(i0, j, 4 * eh + kq)];
+            acc[0][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ax[c][eh][0], bx, acc[0][Q], 0, 0, 0);
+            acc[1][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ax[c][eh][1], bx, acc[1][Q], 0, 0, 0);
+        }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+            const float by = buf[c * 128 + qoff(i0, 4 * bh + kq, j)];
+            acc[0][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ay[c][bh][0], by, acc[0][Q], 0, 0, 0);
+            acc[1][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ay[c][bh][1], by, acc[1][Q], 0, 0, 0);
+        }
+#pragma unroll
+    for (int cp = 0; cp < 8; ++cp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float bz = buf[(2 * cp + (kq >> 1)) * 128 + qoff(kq & 1, 2 * t + i0, j)];
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.az[Q][cp][0], bz, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.az[Q][cp][1], bz, acc[1][t], 0, 0, 0);
+        }
+}
+
+// ---- ReLU + GEMM2 + bias straight from the accumulators ----------------------------
+// v = W2 relu(u) + b2 (modules/modules.py:68-69).  Register r of accumulator tile (m,t)
+// holds u[16m + 4kq + r][pos]: exactly the B operand of a k-step whose four k values are
+// {16m + 4kq + r}, so no lane movement and no LDS round trip is needed.
+__device__ __forceinline__ void gemm2(f32x4 (&v)[2][4], const f32x4 (&acc)[2][4], const HeadFrags& f)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        v[0][t] = f.bias[0];
+        v[1][t] = f.bias[1];
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float u = fmaxf(acc[m][t][r], 0.0f);
+                v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][0], u, v[0][t], 0, 0, 0);
+                v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][1], u, v[1][t], 0, 0, 0);
+            }
+}
+
+// ---- packed (score, index) keys ---------------------------------------------------
+// key = ordered_u32(score) << 32 | (0xFFFFFFFF - idx): unsigned max = largest score,
+// lowest index among equals (torch.max, test_co3d.py:145).  NaN orders above +inf.
+__device__ __forceinline__ unsigned long long pack_key(float s, unsigned idx)
+{
+    s += 0.0f;  // -0 -> +0 so that equal values compare equal
+    unsigned u = __float_as_uint(s);
+    if (s != s) u = 0x7FC00000u;  // canonical quiet NaN: ranks highest
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__device__ __forceinline__ float key_score(unsigned long long key)
+{
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(k, s, 64);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+}  // namespace ahv

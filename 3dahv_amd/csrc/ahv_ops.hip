@@ -1,0 +1,290 @@
+// ahv_ops.hip -- op-level drop-in kernels: each materialises the tensor the
+// reference's corresponding call returns, so the reference's own call sequence
+// (rotate_volume -> forward_3d2d -> mul/sum/mean -> max) runs unchanged on HIP.
+// These are the HBM-bound siblings of the fused scorer (ahv_score.hip).
+#include "ahv_device.h"
+
+namespace ahv {
+
+// ---------------------------------------------------------------------------------
+// rotate_volume, fast path: volume (16,8,8,8) shared by all N hypotheses (the stride-0
+// expand of test_co3d.py:137).  Source image in LDS (40 KiB -> 4 workgroups per CU);
+// one wave per hypothesis, 8 passes of 64 consecutive voxels, so that each of the 16
+// channel stores of a pass writes one contiguous 256-B segment of out[n][c][:].
+// HBM: 36 B in + 32 KiB out per hypothesis -> write-bandwidth bound.
+// ---------------------------------------------------------------------------------
+constexpr int kRotThreads = 256;
+
+__global__ __launch_bounds__(kRotThreads) void rotate_volume_16x8_kernel(
+    const float* __restrict__ vol, const float* __restrict__ R, long N, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float srcT[kSrcFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_src_volume(srcT, vol, tid, kRotThreads);
+    __syncthreads();
+    const int e = lane & 7, b = lane >> 3;  // w, h of this lane; d = pass
+    const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
+    const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
+    for (long n = (long)blockIdx.x * 4 + wave; n < N; n += (long)gridDim.x * 4) {
+        float Rm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rm[i] = R[n * 9 + i];
+        float* o = out + n * (16 * 512) + lane;
+#pragma unroll 2
+        for (int a = 0; a < 8; ++a) {
+            const float z = (2.0f * a + 1.0f) * 0.125f - 1.0f;
+            TriCoef k;
+            tri_coef(k, Rm, x, y, z);
+            float v[16];
+            tri_blend(v, srcT, k);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(v[c], o + c * 512 + a * 64);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// rotate_volume, generic path: any C, D, H, W and any batch stride (utils.py:113-131
+// accepts every 5-D volume).  One thread per output voxel, channels looped; the source
+// is read through the caches.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void axis_generic(float g, int size, float& w0, float& w1, long& i0, long& i1)
+{
+    float i = ((g + 1.0f) * (float)size - 1.0f) * 0.5f;
+    i = fminf(fmaxf(i, -2.0f), (float)size + 1.0f);
+    const float fl = floorf(i);
+    const float t = i - fl;
+    const int a = (int)fl, b = a + 1;
+    w0 = (a >= 0 && a < size) ? 1.0f - t : 0.0f;
+    w1 = (b >= 0 && b < size) ? t : 0.0f;
+    i0 = min(max(a, 0), size - 1);
+    i1 = min(max(b, 0), size - 1);
+}
+
+__global__ __launch_bounds__(256) void rotate_volume_generic_kernel(
+    const float* __restrict__ vol, long vol_batch_stride, const float* __restrict__ R, long N, int C, int D,
+    int H, int W, float* __restrict__ out)
+{
+    const long plane = (long)D * H * W;
+    const long total = N * plane;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / plane;
+        const long v = i - n * plane;
+        const int w = (int)(v % W), h = (int)((v / W) % H), d = (int)(v / ((long)W * H));
+        const float* r = R + n * 9;
+        const float x = (2.0f * w + 1.0f) / (float)W - 1.0f;
+        const float y = (2.0f * h + 1.0f) / (float)H - 1.0f;
+        const float z = (2.0f * d + 1.0f) / (float)D - 1.0f;
+        const float gx = r[0] * x + r[1] * y + r[2] * z;
+        const float gy = r[3] * x + r[4] * y + r[5] * z;
+        const float gz = r[6] * x + r[7] * y + r[8] * z;
+        float wx[2], wy[2], wz[2];
+        long ox[2], oy[2], oz[2];
+        axis_generic(gx, W, wx[0], wx[1], ox[0], ox[1]);
+        axis_generic(gy, H, wy[0], wy[1], oy[0], oy[1]);
+        axis_generic(gz, D, wz[0], wz[1], oz[0], oz[1]);
+        float wgt[8];
+        long off[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+            wgt[k] = wz[dz] * wy[dy] * wx[dx];
+            off[k] = (oz[dz] * H + oy[dy]) * W + ox[dx];
+        }
+        const float* src = vol + n * vol_batch_stride;
+        float* o = out + n * C * plane + v;
+        for (int c = 0; c < C; ++c) {
+            const float* sc = src + c * plane;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += wgt[k] * sc[off[k]];
+            o[c * plane] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward_3d2d (modules/modules.py:112-124) on materialised volumes [M][16][8][8][8].
+// Same wave-per-item MFMA contraction as the fused scorer; the quarter buffers are
+// filled from HBM instead of by the trilinear gather.  32 KiB in + 8 KiB out per item.
+// ---------------------------------------------------------------------------------
+constexpr int kF32Threads = 256;
+constexpr int kF32LdsFloats = 4 * 2 * kQuarterFloats;
+
+template <int Q>
+__device__ __forceinline__ void stage_quarter(float* buf, const float* __restrict__ vol, int lane)
+{
+    // quarter Q of channel c = 128 contiguous floats at c*512 + Q*128; a lane moves 2 of them
+    const int i = 2 * lane;
+    const int a0 = i >> 6, b = (i >> 3) & 7, e = i & 7;
+    const int o0 = qoff(a0, b, e), o1 = qoff(a0, b, e + 1);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float2 v = *reinterpret_cast<const float2*>(vol + c * 512 + Q * 128 + i);
+        buf[c * 128 + o0] = v.x;
+        buf[c * 128 + o1] = v.y;
+    }
+}
+
+__global__ __launch_bounds__(kF32Threads, 1) void forward_3d2d_kernel(
+    const float* __restrict__ vol, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, long M, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* buf0 = smem + wave * (2 * kQuarterFloats);
+    float* buf1 = buf0 + kQuarterFloats;
+    HeadFrags f;
+    load_head_frags(f, W1, W2, b2, lane);
+    const int n16 = lane & 15, kq = lane >> 4;
+    for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+        const float* V = vol + m * (16 * 512);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_quarter<0>(buf0, V, lane);
+        stage_quarter<1>(buf1, V, lane);
+        wave_lds_fence();
+        gemm1_quarter<0>(acc, f, buf0, lane);
+        gemm1_quarter<1>(acc, f, buf1, lane);
+        wave_lds_fence();
+        stage_quarter<2>(buf0, V, lane);
+        stage_quarter<3>(buf1, V, lane);
+        wave_lds_fence();
+        gemm1_quarter<2>(acc, f, buf0, lane);
+        gemm1_quarter<3>(acc, f, buf1, lane);
+        wave_lds_fence();
+        f32x4 v[2][4];
+        gemm2(v, acc, f);
+        float* o = out + m * (32 * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss += v[m2][t][r] * v[m2][t][r];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize clamp_min(eps)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16] = v[m2][t][r] / nrm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// score (test_co3d.py:143): one wave per (b, n); 8 KiB of f_src streamed per hypothesis.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_features_kernel(const float* __restrict__ f_src,
+                                                             const float* __restrict__ f_tgt, int B, long N,
+                                                             float* __restrict__ scores)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nw = (long)gridDim.x * 4;
+    for (long i = wave; i < (long)B * N; i += nw) {
+        const long b = i / N;
+        const f32x4* s = reinterpret_cast<const f32x4*>(f_src + i * 2048);
+        const f32x4* t = reinterpret_cast<const f32x4*>(f_tgt + b * 2048);
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 a = __builtin_nontemporal_load(s + k * 64 + lane);
+            const f32x4 c = t[k * 64 + lane];
+            acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+        if (lane == 0) scores[i] = acc * (1.0f / 64.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// arg-max over materialised scores (test_co3d.py:145), same packed key as the fused path.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ scores, int B, long N,
+                                                     long n_offset, unsigned long long* __restrict__ best_key)
+{
+    const int b = blockIdx.y;
+    const float* s = scores + (long)b * N;
+    unsigned long long best = 0ull;
+    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+        const unsigned long long k = pack_key(s[n], (unsigned)(n_offset + n));
+        best = k > best ? k : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0 && best != 0ull) atomicMax(best_key + b, best);
+}
+
+// ---- launchers ----------------------------------------------------------------------
+hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C,
+                                int D, int H, int W, float* out, int num_cu, hipStream_t stream)
+{
+    if (C == 16 && D == 8 && H == 8 && W == 8 && vol_batch_stride == 0) {
+        long blocks = (N + 3) / 4;
+        const long cap = (long)num_cu * 4;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(rotate_volume_16x8_kernel, dim3((unsigned)blocks), dim3(kRotThreads), 0, stream, vol,
+                           R, (long)N, out);
+    } else {
+        const long total = (long)N * D * H * W;
+        long blocks = (total + 255) / 256;
+        const long cap = (long)num_cu * 16;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(rotate_volume_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, vol,
+                           (long)vol_batch_stride, R, (long)N, C, D, H, W, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_3d2d(const float* vol, const float* W1, const float* W2, const float* b2, int64_t M,
+                               float* out, int num_cu, hipStream_t stream)
+{
+    const size_t lds = sizeof(float) * kF32LdsFloats;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (attr_dev != dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(forward_3d2d_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_dev = dev;
+    }
+    long blocks = (M + 3) / 4;
+    if (blocks > num_cu) blocks = num_cu;
+    hipLaunchKernelGGL(forward_3d2d_kernel, dim3((unsigned)blocks), dim3(kF32Threads), lds, stream, vol, W1, W2,
+                       b2, (long)M, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_features(const float* f_src, const float* f_tgt, int B, int64_t N, float* scores,
+                                 int num_cu, hipStream_t stream)
+{
+    long blocks = ((long)B * N + 3) / 4;
+    const long cap = (long)num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(score_features_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f_src, f_tgt, B,
+                       (long)N, scores);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmax(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key,
+                         int num_cu, hipStream_t stream)
+{
+    long bx = (N + 255) / 256;
+    const long cap = num_cu * 4 / (B < num_cu ? B : num_cu) + 1;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, scores, B, (long)N,
+                       (long)n_offset, reinterpret_cast<unsigned long long*>(best_key));
+    return hipGetLastError();
+}
+
+}  // namespace ahv

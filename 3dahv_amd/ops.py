@@ -1,0 +1,176 @@
+"""Operator mirrors of the reference's hot-path call surface, backed by libahv_hip.so.
+
+Same names, argument meaning and error behaviour as the reference callables:
+
+* ``rotate_volume(volume, rotation_matrix, padding_mode='zeros')``  -- utils.py:113-131
+* ``forward_3d2d(img_feat, W1, W2, b2)``  -- Feature_Aligner.forward_3d2d, modules/modules.py:112-124
+* ``score_features`` / ``argmax``  -- the inline lines test_co3d.py:143 / :145
+* ``score_hypotheses``  -- all of the above fused into one launch (test_co3d.py:137-145)
+
+Tensors must live on the GPU (``torch.device('cuda')`` is HIP on ROCm); launches go
+to torch's current stream.  Inference only: outputs carry no autograd graph.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_VOL = (16, 8, 8, 8)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors: torch.Tensor) -> torch.device:
+    dev = tensors[0].device
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "3dahv_amd ops run on the GPU only (no CPU fallback); got a tensor on %s" % t.device)
+        if t.device != dev:
+            raise RuntimeError("Expected all tensors to be on the same device, found %s and %s" % (dev, t.device))
+        if t.dtype != torch.float32:
+            raise RuntimeError("expected float32 tensors (the reference path is fp32), got %s" % t.dtype)
+    return dev
+
+
+def _head(W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor):
+    if W1.numel() != 32 * 384 or W2.numel() != 32 * 32 or b2.numel() != 32:
+        raise RuntimeError("head weights must be (32,384[,1,1]), (32,32[,1,1]), (32,)")
+    return W1.detach().reshape(32, 384).contiguous(), W2.detach().reshape(32, 32).contiguous(), b2.detach().contiguous()
+
+
+@torch.no_grad()
+def rotate_volume(volume: torch.Tensor, rotation_matrix: torch.Tensor, padding_mode: str = "zeros") -> torch.Tensor:
+    """Rotate ``volume (N,C,D,H,W)`` by ``rotation_matrix (N,3,3)``; returns a new contiguous tensor.
+
+    The batch dimension of ``volume`` may be a stride-0 expand of one volume (what the
+    reference passes): it is read once, never materialised.
+    """
+    if padding_mode != "zeros":
+        raise NotImplementedError("only padding_mode='zeros' (the only mode the reference uses) is implemented")
+    if volume.dim() != 5:
+        raise RuntimeError("volume must be 5-D (N,C,D,H,W), got %s" % (tuple(volume.shape),))
+    if rotation_matrix.dim() != 3 or tuple(rotation_matrix.shape[1:]) != (3, 3):
+        raise RuntimeError("rotation_matrix must be (N,3,3), got %s" % (tuple(rotation_matrix.shape),))
+    N, C, D, H, W = volume.shape
+    if rotation_matrix.shape[0] != N:
+        raise RuntimeError("Expected volume and rotation_matrix to have the same batch size, got %d and %d"
+                           % (N, rotation_matrix.shape[0]))
+    _need_gpu(volume, rotation_matrix)
+    volume = volume.detach()
+    if N > 1 and volume.stride(0) == 0 and volume[0].is_contiguous():
+        src, stride = volume[0], 0
+    else:
+        src = volume.contiguous()
+        stride = C * D * H * W
+    R = rotation_matrix.detach().contiguous()
+    out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=volume.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_rotate_volume_f32(src.data_ptr(), stride, R.data_ptr(), N, C, D, H, W, out.data_ptr(),
+                                         _stream()), "ahv_rotate_volume_f32")
+    return out
+
+
+@torch.no_grad()
+def forward_3d2d(img_feat: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """``(M,16,8,8,8) -> (M,32,64)``: slabs -> conv1x1 -> ReLU -> conv1x1+bias -> L2-normalise."""
+    if img_feat.dim() != 5 or tuple(img_feat.shape[1:]) != _VOL:
+        raise RuntimeError("img_feat must be (M,16,8,8,8), got %s" % (tuple(img_feat.shape),))
+    _need_gpu(img_feat, W1, W2, b2)
+    W1, W2, b2 = _head(W1, W2, b2)
+    x = img_feat.detach().contiguous()
+    M = x.shape[0]
+    out = torch.empty((M, 32, 64), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_forward_3d2d_f32(x.data_ptr(), W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), M,
+                                        out.data_ptr(), _stream()), "ahv_forward_3d2d_f32")
+    return out
+
+
+@torch.no_grad()
+def score_features(f_src: torch.Tensor, f_tgt: torch.Tensor) -> torch.Tensor:
+    """``(f_src * f_tgt[:, None]).sum(dim=2).mean(dim=-1)``: (B,N,32,64),(B,32,64) -> (B,N)."""
+    if f_src.dim() != 4 or tuple(f_src.shape[2:]) != (32, 64) or tuple(f_tgt.shape) != (f_src.shape[0], 32, 64):
+        raise RuntimeError("expected f_src (B,N,32,64) and f_tgt (B,32,64)")
+    _need_gpu(f_src, f_tgt)
+    B, N = f_src.shape[:2]
+    a, t = f_src.detach().contiguous(), f_tgt.detach().contiguous()
+    out = torch.empty((B, N), dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_score_features_f32(a.data_ptr(), t.data_ptr(), B, N, out.data_ptr(), _stream()),
+               "ahv_score_features_f32")
+    return out
+
+
+@torch.no_grad()
+def unpack_best(best_key: torch.Tensor):
+    """Packed keys (B,) int64 -> (best_score (B,) f32, best_idx (B,) int64)."""
+    B = best_key.numel()
+    score = torch.empty((B,), dtype=torch.float32, device=best_key.device)
+    idx = torch.empty((B,), dtype=torch.int64, device=best_key.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_unpack_best(best_key.data_ptr(), B, score.data_ptr(), idx.data_ptr(), _stream()),
+               "ahv_unpack_best")
+    return score, idx
+
+
+@torch.no_grad()
+def argmax(scores: torch.Tensor, n_offset: int = 0, return_key: bool = False):
+    """``torch.max(scores, dim=1)`` -> (values, first maximal int64 index); (B,N) -> (B,),(B,)."""
+    if scores.dim() != 2:
+        raise RuntimeError("scores must be (B,N)")
+    _need_gpu(scores)
+    B, N = scores.shape
+    if N == 0:
+        raise RuntimeError("max(): Expected reduction dim 1 to have non-zero size.")
+    s = scores.detach().contiguous()
+    key = torch.empty((B,), dtype=torch.int64, device=s.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_argmax_f32(s.data_ptr(), B, N, n_offset, key.data_ptr(), _lib.AHV_SCORE_RESET_BEST,
+                                  _stream()), "ahv_argmax_f32")
+    if return_key:
+        return key
+    return unpack_best(key)
+
+
+@torch.no_grad()
+def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
+                     W2: torch.Tensor, b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True,
+                     best_key: torch.Tensor | None = None):
+    """Fused hot loop (one launch): returns ``(scores (B,N) or None, best_key (B,) int64)``.
+
+    vol_src (B,16,8,8,8); feat_tgt (B,32,64) = forward_3d2d(vol_tgt); R (N,3,3) shared by the
+    batch (modules/model.py:184) or (B,N,3,3) per sample (modules/model.py:51).  ``best_key``
+    given: merge into it (chunked / multi-call N); else a fresh key tensor is reset and returned.
+    Decode with ``unpack_best``; ``n_offset`` is the global index of R[0] when N is sharded.
+    """
+    if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
+        raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
+    B = vol_src.shape[0]
+    if tuple(feat_tgt.shape) != (B, 32, 64):
+        raise RuntimeError("feat_tgt must be (B,32,64), got %s" % (tuple(feat_tgt.shape),))
+    if R.dim() == 3 and tuple(R.shape[1:]) == (3, 3):
+        N, rstride = R.shape[0], 0
+    elif R.dim() == 4 and R.shape[0] == B and tuple(R.shape[2:]) == (3, 3):
+        N, rstride = R.shape[1], R.shape[1] * 9
+    else:
+        raise RuntimeError("R must be (N,3,3) or (B,N,3,3), got %s" % (tuple(R.shape),))
+    dev = _need_gpu(vol_src, feat_tgt, R, W1, W2, b2)
+    W1, W2, b2 = _head(W1, W2, b2)
+    vs, ft, Rc = vol_src.detach().contiguous(), feat_tgt.detach().contiguous(), R.detach().contiguous()
+    scores = torch.empty((B, N), dtype=torch.float32, device=dev) if want_scores else None
+    flags = 0
+    if best_key is None:
+        best_key = torch.empty((B,), dtype=torch.int64, device=dev)
+        flags = _lib.AHV_SCORE_RESET_BEST
+    elif best_key.dtype != torch.int64 or best_key.numel() != B or not best_key.is_cuda:
+        raise RuntimeError("best_key must be a GPU int64 tensor of B elements")
+    lib = _lib.load()
+    _lib.check(lib.ahv_score_hypotheses_f32(vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset,
+                                            W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), B, N,
+                                            scores.data_ptr() if scores is not None else None,
+                                            best_key.data_ptr(), flags, _stream()), "ahv_score_hypotheses_f32")
+    return scores, best_key

@@ -1,0 +1,138 @@
+/*
+ * ahv.h -- C ABI of libahv_hip.so: MI355X (gfx950) kernels for 3DAHV's
+ * rotation-hypothesis verification hot path.
+ *
+ * The reference (sailor-z/3DAHV) has no FFI layer: its boundary for this path is
+ * three Python callables plus three inline tensor expressions.  Each entry point
+ * below names the reference interface it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers (HBM), fp32 unless stated, borrowed
+ *    from the caller (e.g. torch tensors): the caller keeps them alive until the
+ *    stream has executed the call.  Nothing is allocated or freed inside.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    Calls are asynchronous w.r.t. the host and ordered on that stream; they
+ *    contain no host synchronisation, so they can be captured in a hipGraph.
+ *  - Return value: AHV_OK (0) or a negative AHV_E* code; ahv_last_error()
+ *    returns a thread-local description of the last failure on this thread.
+ *    No C++ exception crosses the ABI.  Entry points are re-entrant.
+ *  - Fixed geometry of the reference: volume channels Cv=16, side S=8
+ *    (modules/modules.py:64,97), head width O=32, K=3*Cv*S=384
+ *    (modules/modules.py:66-70), P=S*S=64 output positions.
+ */
+#ifndef AHV_H
+#define AHV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AHV_OK 0
+#define AHV_EINVAL (-1)  /* bad argument (null pointer, negative size, bad stride) */
+#define AHV_ELAUNCH (-2) /* HIP launch / runtime error */
+#define AHV_EDEVICE (-3) /* no usable gfx950 device */
+
+#define AHV_CV 16
+#define AHV_S 8
+#define AHV_K 384
+#define AHV_O 32
+#define AHV_P 64
+#define AHV_VOL_ELEMS (AHV_CV * AHV_S * AHV_S * AHV_S) /* 8192 floats = 32 KiB */
+#define AHV_FEAT_ELEMS (AHV_O * AHV_P)                 /* 2048 floats = 8 KiB  */
+
+/* flags of ahv_score_hypotheses_f32 */
+#define AHV_SCORE_RESET_BEST 1u /* zero best_key[0..B) on the stream before scoring */
+
+/* ABI version (major<<16 | minor). */
+int ahv_abi_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* ahv_last_error(void);
+
+/* Number of compute units of the current device (for sizing / reporting); <0 on error. */
+int ahv_device_cu_count(void);
+
+/*
+ * Fused scorer: rotate + project + verification head + cosine score (+ running
+ * arg-max) for N hypotheses and B volume pairs in ONE launch, O(1) HBM traffic
+ * per hypothesis (36 B of R in, 4 B of score out).
+ *
+ * Replaces, for every b < B and n < N, the reference's inline hot loop
+ *   rotate_volume(vol_src[b].expand(N,...), R)          test_co3d.py:137   (utils.py:113-131)
+ *   feature_aligner.forward_3d2d(...)                   test_co3d.py:140   (modules/modules.py:112-124)
+ *   (f_src * f_tgt[:, None]).sum(dim=2).mean(dim=-1)    test_co3d.py:143
+ *   torch.max(pred_sim, dim=1)                          test_co3d.py:145
+ * (same code at modules/model.py:186-195, :133-146, test_linemod.py:49-62; per-sample
+ *  R form at modules/model.py:51-54).
+ *
+ *  vol_src   [B][16][8][8][8]   source feature volumes (output of forward_2d3d)
+ *  feat_tgt  [B][32][64]        forward_3d2d(vol_tgt): unit-norm target features
+ *  R         hypotheses, row-major 3x3; hypothesis n of sample b is at
+ *            R + b*r_batch_stride + n*9  (r_batch_stride = 0: shared across the
+ *            batch, modules/model.py:184; = N*9: per sample, modules/model.py:51).
+ *            R need not be orthonormal (the reference never assumes it).
+ *  n_offset  global index of local hypothesis 0 (sharding N across GPUs); it is
+ *            added to the index packed into best_key.
+ *  W1 [32][384], W2 [32][32], b2 [32]   feature_embedding_2d.{0.weight, 2.weight, 2.bias}
+ *  scores    [B][N] or NULL     per-hypothesis mean cosine similarity
+ *  best_key  [B] or NULL        packed running maximum, merged with atomic max:
+ *            key = (ordered_u32(score) << 32) | (0xFFFFFFFF - global_idx), so
+ *            that an unsigned max yields the largest score and, among equal
+ *            scores, the LOWEST index (torch.max semantics); NaN scores order
+ *            above +inf (torch.max propagates NaN).  Decode with ahv_unpack_best.
+ *            Requires n_offset + N <= 2^32.
+ *  flags     AHV_SCORE_RESET_BEST or 0 (0 merges into existing keys, e.g. chunked N)
+ */
+int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                             int64_t r_batch_stride, int64_t n_offset, const float* W1,
+                             const float* W2, const float* b2, int B, int64_t N, float* scores,
+                             uint64_t* best_key, unsigned flags, void* stream);
+
+/*
+ * Decode packed keys: best_score[b], best_idx[b] (int64, global hypothesis index).
+ * Replaces the (value, index) pair of torch.max (test_co3d.py:145).  Either output may be NULL.
+ * A key of 0 (nothing scored) decodes to (-inf... see ahv.h) score = NaN-free -inf and idx = -1.
+ */
+int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream);
+
+/*
+ * Op-level drop-in for utils.rotate_volume (utils.py:113-131): F.affine_grid +
+ * F.grid_sample (trilinear, zeros padding, align_corners=False), materialising
+ * out [N][C][D][H][W].  vol_batch_stride (in floats) is 0 for the stride-0
+ * expand the reference passes (test_co3d.py:137) or C*D*H*W.  Any C,D,H,W >= 1;
+ * (16,8,8,8) with stride 0 takes the LDS-staged fast path.
+ */
+int ahv_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N,
+                          int C, int D, int H, int W, float* out, void* stream);
+
+/*
+ * Op-level drop-in for Feature_Aligner.forward_3d2d (modules/modules.py:112-124):
+ * vol [M][16][8][8][8] -> out [M][32][64], unit L2 norm over the 32 channels.
+ */
+int ahv_forward_3d2d_f32(const float* vol, const float* W1, const float* W2, const float* b2,
+                         int64_t M, float* out, void* stream);
+
+/*
+ * Op-level drop-in for the inline score expression (test_co3d.py:143):
+ * scores[b][n] = mean_pos sum_ch f_src[b][n][ch][pos] * f_tgt[b][ch][pos].
+ * f_src [B][N][32][64], f_tgt [B][32][64], scores [B][N].
+ */
+int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_t N, float* scores,
+                           void* stream);
+
+/*
+ * Arg-max over materialised scores (test_co3d.py:145): merges scores[b][0..N)
+ * into best_key[b] with the same packing as the fused scorer.
+ */
+int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key,
+                   unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AHV_H */
