@@ -55,6 +55,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: import it FIRST so that libahv_hip.so binds to the same
+    # libamdhip64 (one runtime per process: shared device context, streams and pointers).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "

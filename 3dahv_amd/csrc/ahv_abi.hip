@@ -73,8 +73,9 @@ int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const 
                              const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
                              unsigned flags, void* stream)
 {
-    if (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2) return fail(AHV_EINVAL, "score: null input pointer");
     if (B < 0 || N < 0) return fail(AHV_EINVAL, "score: negative size (B=%d, N=%lld)", B, (long long)N);
+    if (B > 0 && N > 0 && (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2))
+        return fail(AHV_EINVAL, "score: null input pointer");
     if (r_batch_stride != 0 && r_batch_stride < N * 9)
         return fail(AHV_EINVAL, "score: r_batch_stride %lld must be 0 or >= N*9", (long long)r_batch_stride);
     if (n_offset < 0 || n_offset + N > 4294967296ll)
@@ -107,11 +108,11 @@ int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t*
 int ahv_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C, int D,
                           int H, int W, float* out, void* stream)
 {
-    if (!vol || !R || !out) return fail(AHV_EINVAL, "rotate_volume: null pointer");
     if (N < 0 || C < 1 || D < 1 || H < 1 || W < 1)
         return fail(AHV_EINVAL, "rotate_volume: bad shape N=%lld C=%d D=%d H=%d W=%d", (long long)N, C, D, H, W);
     if (vol_batch_stride < 0) return fail(AHV_EINVAL, "rotate_volume: negative batch stride");
-    if (N == 0) return AHV_OK;
+    if (N == 0) return AHV_OK; /* empty batch: nothing to read or write, pointers may be null */
+    if (!vol || !R || !out) return fail(AHV_EINVAL, "rotate_volume: null pointer");
     const int cu = cu_count();
     if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
     hipError_t e = ahv::launch_rotate_volume(vol, vol_batch_stride, R, N, C, D, H, W, out, cu,
@@ -123,9 +124,9 @@ int ahv_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, const floa
 int ahv_forward_3d2d_f32(const float* vol, const float* W1, const float* W2, const float* b2, int64_t M,
                          float* out, void* stream)
 {
-    if (!vol || !W1 || !W2 || !b2 || !out) return fail(AHV_EINVAL, "forward_3d2d: null pointer");
     if (M < 0) return fail(AHV_EINVAL, "forward_3d2d: negative M");
     if (M == 0) return AHV_OK;
+    if (!vol || !W1 || !W2 || !b2 || !out) return fail(AHV_EINVAL, "forward_3d2d: null pointer");
     const int cu = cu_count();
     if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
     hipError_t e = ahv::launch_forward_3d2d(vol, W1, W2, b2, M, out, cu, static_cast<hipStream_t>(stream));
@@ -135,9 +136,9 @@ int ahv_forward_3d2d_f32(const float* vol, const float* W1, const float* W2, con
 
 int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_t N, float* scores, void* stream)
 {
-    if (!f_src || !f_tgt || !scores) return fail(AHV_EINVAL, "score_features: null pointer");
     if (B < 0 || N < 0) return fail(AHV_EINVAL, "score_features: negative size");
     if (B == 0 || N == 0) return AHV_OK;
+    if (!f_src || !f_tgt || !scores) return fail(AHV_EINVAL, "score_features: null pointer");
     const int cu = cu_count();
     if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
     hipError_t e = ahv::launch_score_features(f_src, f_tgt, B, N, scores, cu, static_cast<hipStream_t>(stream));

@@ -1,0 +1,117 @@
+"""Sharding the hypothesis axis across GPUs (one process per GPU, RCCL over xGMI).
+
+Hypotheses are independent given the per-pair constants (source volume, target
+feature, head weights: 94 KB, replicated on every rank), so N is partitioned
+contiguously: rank r scores [lo_r, hi_r) with ``n_offset = lo_r``.  The data
+path has ONE exchange: an all-reduce(max) of B packed 64-bit keys
+``(ordered_u32(score) << 32) | (0xFFFFFFFF - global_idx)``, i.e. 8*B bytes --
+latency-bound, bandwidth-irrelevant.  Unsigned max on the key = largest score,
+lowest global index among equal scores (torch.max semantics, test_co3d.py:145),
+independent of how N was split.
+
+torch has no unsigned 64-bit reductions, so keys travel as int64 XOR
+0x8000...0, which maps unsigned order onto signed order (works on ``nccl`` =
+RCCL and on ``gloo``).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_SIGN = -(1 << 63)
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of range(n): sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def merge_keys(keys: torch.Tensor) -> torch.Tensor:
+    """Unsigned max over dim 0 of packed int64 keys: (G,B) -> (B,)."""
+    return (keys ^ _SIGN).max(dim=0).values ^ _SIGN
+
+
+def all_reduce_best(key: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place global merge of per-rank packed keys (B,) int64; returns ``key``."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        key.bitwise_xor_(_SIGN)
+        dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
+        key.bitwise_xor_(_SIGN)
+    return key
+
+
+# ---- host-side key codec (numpy): used by host logic and CPU tests ------------------
+
+def pack_keys_host(scores: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """Same packing as the device code (csrc/ahv_device.h pack_key); returns int64 bit patterns."""
+    s = np.asarray(scores, dtype=np.float32) + np.float32(0.0)
+    u = s.view(np.uint32).copy()
+    u[np.isnan(s)] = np.uint32(0x7FC00000)
+    neg = (u & np.uint32(0x80000000)) != 0
+    u = np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+    k = (u << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.asarray(idx, dtype=np.uint64))
+    return k.view(np.int64)
+
+
+def unpack_keys_host(keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    k = np.asarray(keys, dtype=np.int64).view(np.uint64)
+    u = (k >> np.uint64(32)).astype(np.uint32)
+    pos = (u & np.uint32(0x80000000)) != 0
+    bits = np.where(pos, u & np.uint32(0x7FFFFFFF), ~u).astype(np.uint32)
+    score = bits.view(np.float32).copy()
+    idx = (np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    empty = k == 0
+    score[empty] = -np.inf
+    idx[empty] = -1
+    return score, idx
+
+
+# ---- sharded verify step -------------------------------------------------------------
+
+def score_hypotheses_sharded(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1, W2, b2,
+                             rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                             want_scores: bool = False, r_is_local: bool = False, n_total: Optional[int] = None,
+                             score_fn: Optional[Callable] = None):
+    """One verify step with N sharded over the process group.
+
+    ``R`` is the full (N,3,3) hypothesis set present on every rank (the reference samples one
+    codebook per category and reuses it, test_co3d.py:106) unless ``r_is_local``; in that case it
+    is this rank's slice and ``n_total`` gives N.  Returns ``(local_scores or None, best_score (B,),
+    best_idx (B,) global int64)`` -- identical on every rank.
+    ``score_fn`` defaults to the HIP fused scorer; tests inject a CPU scorer to exercise the
+    partition/merge logic without a GPU.
+    """
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if score_fn is None:
+        from . import ops
+        score_fn = ops.score_hypotheses
+        unpack = ops.unpack_best
+    else:
+        unpack = None
+    if r_is_local:
+        if n_total is None:
+            raise ValueError("n_total is required with r_is_local")
+        lo, hi = shard_range(n_total, rank, world)
+        R_loc = R
+        if R.shape[-3] != hi - lo:
+            raise ValueError("local R has %d hypotheses, shard expects %d" % (R.shape[-3], hi - lo))
+    else:
+        n = R.shape[-3]
+        lo, hi = shard_range(n, rank, world)
+        R_loc = R[..., lo:hi, :, :]
+    scores, key = score_fn(vol_src, feat_tgt, R_loc.contiguous(), W1, W2, b2, n_offset=lo, want_scores=want_scores)
+    key = all_reduce_best(key, group=group)
+    if unpack is not None:
+        best, idx = unpack(key)
+    else:
+        b, i = unpack_keys_host(key.cpu().numpy())
+        best, idx = torch.from_numpy(b), torch.from_numpy(i)
+    return scores, best, idx

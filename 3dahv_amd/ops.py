@@ -139,12 +139,13 @@ def argmax(scores: torch.Tensor, n_offset: int = 0, return_key: bool = False):
 @torch.no_grad()
 def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
                      W2: torch.Tensor, b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True,
-                     best_key: torch.Tensor | None = None):
+                     best_key: torch.Tensor | None = None, reset_best: bool | None = None):
     """Fused hot loop (one launch): returns ``(scores (B,N) or None, best_key (B,) int64)``.
 
     vol_src (B,16,8,8,8); feat_tgt (B,32,64) = forward_3d2d(vol_tgt); R (N,3,3) shared by the
     batch (modules/model.py:184) or (B,N,3,3) per sample (modules/model.py:51).  ``best_key``
-    given: merge into it (chunked / multi-call N); else a fresh key tensor is reset and returned.
+    given: merge into it (chunked / multi-call N) unless ``reset_best``; else a fresh key tensor
+    is reset and returned.
     Decode with ``unpack_best``; ``n_offset`` is the global index of R[0] when N is sharded.
     """
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
@@ -162,12 +163,12 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
     W1, W2, b2 = _head(W1, W2, b2)
     vs, ft, Rc = vol_src.detach().contiguous(), feat_tgt.detach().contiguous(), R.detach().contiguous()
     scores = torch.empty((B, N), dtype=torch.float32, device=dev) if want_scores else None
-    flags = 0
     if best_key is None:
         best_key = torch.empty((B,), dtype=torch.int64, device=dev)
-        flags = _lib.AHV_SCORE_RESET_BEST
+        reset_best = True
     elif best_key.dtype != torch.int64 or best_key.numel() != B or not best_key.is_cuda:
         raise RuntimeError("best_key must be a GPU int64 tensor of B elements")
+    flags = _lib.AHV_SCORE_RESET_BEST if reset_best else 0
     lib = _lib.load()
     _lib.check(lib.ahv_score_hypotheses_f32(vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset,
                                             W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), B, N,

@@ -1,0 +1,74 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol include/ahv.h
+declares.  No compute calls here (no GPU in the CPU test tier)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from .conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib(ahv):
+    ahv._lib.build()
+    return ahv._lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "ahv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ahv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib, ahv):
+    syms = declared_symbols()
+    assert len(syms) >= 9
+    for s in syms:
+        assert hasattr(lib, s), "libahv_hip.so lacks %s declared in include/ahv.h" % s
+    assert sorted(ahv._lib.SIGNATURES) == syms  # the ctypes table mirrors the header one to one
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ahv._lib.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r" T (ahv_[a-z0-9_]+)", out)))
+    assert exported == syms  # nothing undeclared leaks out of the ABI
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.ahv_abi_version() == (1 << 16)
+    assert isinstance(lib.ahv_last_error(), bytes)
+
+
+def test_argument_validation_needs_no_gpu(lib, ahv):
+    # validation happens before any HIP call, so it is testable on a CPU-only box
+    rc = lib.ahv_score_hypotheses_f32(None, None, None, 0, 0, None, None, None, 1, 1, None, None, 0, None)
+    assert rc == -1 and b"null" in lib.ahv_last_error()
+    rc = lib.ahv_rotate_volume_f32(1, 0, 1, -5, 16, 8, 8, 8, 1, None)
+    assert rc == -1 and b"bad shape" in lib.ahv_last_error()
+    rc = lib.ahv_score_hypotheses_f32(1, 1, 1, 5, 0, 1, 1, 1, 1, 10, None, None, 0, None)
+    assert rc == -1 and b"r_batch_stride" in lib.ahv_last_error()
+    rc = lib.ahv_score_hypotheses_f32(1, 1, 1, 0, 1 << 32, 1, 1, 1, 1, 10, None, None, 0, None)
+    assert rc == -1 and b"32 bits" in lib.ahv_last_error()
+    rc = lib.ahv_score_hypotheses_f32(1, 1, 1, 0, 0, 1, 1, 1, 1, 10, None, None, 8, None)
+    assert rc == -1 and b"flags" in lib.ahv_last_error()
+    with pytest.raises(ahv._lib.AhvError):
+        ahv._lib.check(rc, "x")
+
+
+def test_ops_refuse_cpu_tensors(ahv):
+    import torch
+    v = torch.zeros(2, 16, 8, 8, 8)
+    R = torch.eye(3)[None].repeat(2, 1, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ahv.ops.rotate_volume(v, R)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ahv.ops.forward_3d2d(v, torch.zeros(32, 384), torch.zeros(32, 32), torch.zeros(32))
+
+
+def test_product_does_not_import_oracle():
+    """The shipped path must never route through the CPU oracle."""
+    pkg = os.path.join(REPO, "3dahv_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "libahv_oracle" not in text, f

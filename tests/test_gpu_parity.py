@@ -1,0 +1,317 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+
+Bar (BASELINE.json north_star): per-hypothesis scores within 1e-4 relative of the reference PyTorch
+path on identical inputs, arg-max index bit-exact.  Scores are mean cosine similarities in [-1, 1]
+that can pass through zero, so "relative" is taken against max(|ref|, SCORE_FLOOR); tensors
+(rotated volumes, features) are compared with max|diff| / max|ref|.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+SCORE_RTOL = 1e-4   # north-star tolerance
+SCORE_FLOOR = 1e-2  # |score| floor for the relative measure
+TENSOR_RTOL = 1e-5  # rotated volumes / features: fp32 with a different summation order
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(ahv):
+    ahv._lib.load()  # raises if libahv_hip.so is missing: no fallback
+    return ahv.ops
+
+
+@pytest.fixture(scope="module")
+def G(dev, g128):
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g128[k])).to(dev)
+    return {k: t(k) for k in ["vol_src", "vol_tgt", "R", "W1", "W2", "b2"]}
+
+
+def to_dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def score_relerr(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), SCORE_FLOOR)))
+
+
+def tensor_relerr(got, ref):
+    return float(np.max(np.abs(got - ref)) / max(float(np.max(np.abs(ref))), 1e-30))
+
+
+# ---------------------------------------------------------------- op-level kernels
+
+def test_rotate_volume_golden_and_oracle(ops, oracle, G, g128):
+    vol = G["vol_src"][0][None].expand(128, -1, -1, -1, -1)  # the reference's stride-0 expand
+    assert vol.stride(0) == 0
+    out = ops.rotate_volume(vol, G["R"])
+    assert out.shape == (128, 16, 8, 8, 8) and out.is_contiguous()
+    got = out.cpu().numpy()
+    assert tensor_relerr(got[:2], g128["rot_first2"]) < TENSOR_RTOL
+    assert tensor_relerr(got, oracle.rotate_volume(g128["vol_src"], g128["R"])) < TENSOR_RTOL
+
+
+def test_rotate_volume_edge_cases(ops, G, g128, dev):
+    g = load_golden("edge_rotations")
+    R = to_dev(g["R"], dev)
+    n = R.shape[0]
+    got = ops.rotate_volume(G["vol_src"][0][None].expand(n, -1, -1, -1, -1), R).cpu().numpy()
+    names = list(g["names"])
+    assert np.array_equal(got[names.index("identity")], g128["vol_src"][0])  # bit-exact copy
+    for i in range(1, 25):  # cube rotations permute voxels exactly
+        assert np.array_equal(np.sort(got[i].ravel()), np.sort(g128["vol_src"][0].ravel()))
+    assert tensor_relerr(got[g["rot_keep_idx"]], g["rot_keep"]) < TENSOR_RTOL
+    zero_frac = (got == 0).reshape(n, -1).mean(axis=1)
+    assert zero_frac[names.index("double")] == pytest.approx(0.875)  # zeros padding
+    assert zero_frac[names.index("half")] == 0.0
+    assert np.allclose(zero_frac, g["rot_zero_frac"], atol=2e-3)
+
+
+def test_rotate_volume_materialised_batch_and_n1(ops, oracle, G, g128):
+    # same volume materialised N times (non-zero batch stride): generic path
+    vol = G["vol_src"][0][None].repeat(5, 1, 1, 1, 1)
+    got = ops.rotate_volume(vol, G["R"][:5]).cpu().numpy()
+    assert tensor_relerr(got, oracle.rotate_volume(g128["vol_src"], g128["R"][:5])) < TENSOR_RTOL
+    got1 = ops.rotate_volume(G["vol_src"], G["R"][:1]).cpu().numpy()  # N == 1
+    assert tensor_relerr(got1, got[:1]) < 1e-6
+
+
+def test_rotate_volume_generic_shape(ops, oracle, dev):
+    rng = np.random.RandomState(0)
+    vol = rng.standard_normal((7, 3, 4, 5, 6)).astype(np.float32)
+    R = rng.standard_normal((7, 3, 3)).astype(np.float32) * 0.7
+    got = ops.rotate_volume(to_dev(vol, dev), to_dev(R, dev)).cpu().numpy()
+    ref = np.concatenate([oracle.rotate_volume(vol[i:i + 1], R[i:i + 1]) for i in range(7)])
+    assert tensor_relerr(got, ref) < TENSOR_RTOL
+
+
+def test_rotate_volume_errors(ops, G):
+    with pytest.raises(NotImplementedError):
+        ops.rotate_volume(G["vol_src"], G["R"][:1], padding_mode="border")
+    with pytest.raises(RuntimeError):
+        ops.rotate_volume(G["vol_src"], G["R"][:3])  # batch mismatch
+    with pytest.raises(RuntimeError):
+        ops.rotate_volume(G["vol_src"].cpu(), G["R"][:1].cpu())  # no CPU fallback
+    out = ops.rotate_volume(G["vol_src"][:0], G["R"][:0])  # empty batch
+    assert out.shape == (0, 16, 8, 8, 8)
+
+
+def test_forward_3d2d_golden_and_oracle(ops, oracle, G, g128, dev):
+    f_tgt = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"]).cpu().numpy()
+    assert tensor_relerr(f_tgt, g128["f_tgt"]) < TENSOR_RTOL
+    rot = oracle.rotate_volume(g128["vol_src"], g128["R"])
+    got = ops.forward_3d2d(to_dev(rot, dev), G["W1"], G["W2"], G["b2"]).cpu().numpy()
+    assert tensor_relerr(got[:2], g128["f_src_first2"]) < TENSOR_RTOL
+    assert tensor_relerr(got, oracle.forward_3d2d(rot, g128["W1"], g128["W2"], g128["b2"])) < TENSOR_RTOL
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    # conv-shaped weights, as stored in the reference state dict
+    got2 = ops.forward_3d2d(G["vol_tgt"], G["W1"].reshape(32, 384, 1, 1), G["W2"].reshape(32, 32, 1, 1), G["b2"])
+    assert np.array_equal(got2.cpu().numpy(), f_tgt)
+
+
+def test_forward_3d2d_zero_volume_eps(ops, oracle, G, g128, dev):
+    # zero volume and zero bias -> v = 0 -> normalise clamps the norm at 1e-12 -> exact zeros
+    z = torch.zeros(3, 16, 8, 8, 8, device=dev)
+    out = ops.forward_3d2d(z, G["W1"], G["W2"], torch.zeros_like(G["b2"]))
+    assert torch.count_nonzero(out) == 0
+    out_b = ops.forward_3d2d(z, G["W1"], G["W2"], G["b2"]).cpu().numpy()
+    ref = oracle.forward_3d2d(np.zeros((1, 16, 8, 8, 8), np.float32), g128["W1"], g128["W2"], g128["b2"])
+    assert tensor_relerr(out_b[:1], ref) < TENSOR_RTOL
+
+
+def test_score_features_and_argmax(ops, oracle, dev):
+    rng = np.random.RandomState(1)
+    fs = rng.standard_normal((2, 300, 32, 64)).astype(np.float32)
+    ft = rng.standard_normal((2, 32, 64)).astype(np.float32)
+    got = ops.score_features(to_dev(fs, dev), to_dev(ft, dev))
+    ref = oracle.score_features(fs, ft)
+    assert tensor_relerr(got.cpu().numpy(), ref) < TENSOR_RTOL
+    val, idx = ops.argmax(got)
+    rv, ri = torch.max(got.cpu(), dim=1)
+    assert torch.equal(idx.cpu(), ri) and torch.equal(val.cpu(), rv)
+
+
+def test_argmax_ties_nan_and_signed_zero(ops, dev):
+    s = torch.tensor([[0.1, 0.7, 0.7, 0.2], [float("nan"), 1.0, float("nan"), 0.0], [-0.0, 0.0, -1.0, -2.0],
+                      [-3.0, -1.5, -1.5, -9.0]], device=dev)
+    val, idx = ops.argmax(s)
+    rv, ri = torch.max(s.cpu(), dim=1)
+    assert idx.cpu().tolist() == ri.tolist() == [1, 0, 0, 1]
+    assert torch.isnan(val[1]) and val[0].item() == rv[0].item() and val[3].item() == -1.5
+    big = torch.zeros(1, 100000, device=dev)
+    big[0, 77777] = 1e-30
+    big[0, 99999] = 1e-30
+    assert ops.argmax(big)[1].item() == 77777
+
+
+# ---------------------------------------------------------------- fused scorer
+
+def fused(ops, G, R, **kw):
+    ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
+    scores, key = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], **kw)
+    val, idx = ops.unpack_best(key)
+    return scores, val, idx
+
+
+def test_fused_n128_config1(ops, G, g128):
+    scores, val, idx = fused(ops, G, G["R"])
+    assert score_relerr(scores.cpu().numpy(), g128["scores"]) < SCORE_RTOL
+    assert idx.item() == int(g128["best_idx"][0])
+    assert abs(val.item() - float(g128["best"][0])) <= SCORE_RTOL * abs(float(g128["best"][0]))
+    assert val.item() == scores[0, idx.item()].item()  # the key carries the exact fp32 score
+
+
+def test_fused_n4096(ops, G, dev):
+    g = load_golden("score_n4096")
+    scores, val, idx = fused(ops, G, to_dev(g["R"], dev))
+    assert score_relerr(scores.cpu().numpy(), g["scores"]) < SCORE_RTOL
+    assert idx.item() == int(g["best_idx"][0])
+
+
+def test_fused_n50k_config2_digest(ops, ahv, oracle, G, g128, dev):
+    g = load_golden("score_n50k_digest")
+    R = ahv.rotations.haar_rotations_np(int(g["n"]), int(g["seed"]))
+    assert hashlib.sha256(R.tobytes()).hexdigest() == str(g["R_sha256"])
+    scores, val, idx = fused(ops, G, to_dev(R, dev))
+    s = scores[0].cpu().numpy()
+    assert idx.item() == int(g["best_idx"][0])  # bit-exact arg-max at the reference's test size
+    assert score_relerr(s[::97], g["every97_score"]) < SCORE_RTOL
+    assert score_relerr(s[g["top16_idx"]], g["top16_score"]) < SCORE_RTOL
+    assert list(np.argsort(-s, kind="stable")[:16]) == list(g["top16_idx"])
+    # without the score tensor (arg-max only) the same key comes back
+    _, val2, idx2 = fused(ops, G, to_dev(R, dev), want_scores=False)
+    assert idx2.item() == idx.item() and val2.item() == val.item()
+    # fused == op-level pipeline == oracle on a slice
+    sl = slice(20000, 20512)
+    ref, _, _ = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], R[sl], g128["W1"], g128["W2"], g128["b2"])
+    assert score_relerr(s[sl], ref[0]) < SCORE_RTOL
+
+
+def test_fused_equals_op_level_pipeline(ops, G, ahv, dev):
+    R = to_dev(ahv.rotations.haar_rotations_np(3000, 21), dev)
+    scores, val, idx = fused(ops, G, R)
+    rot = ops.rotate_volume(G["vol_src"][0][None].expand(3000, -1, -1, -1, -1), R)
+    fs = ops.forward_3d2d(rot, G["W1"], G["W2"], G["b2"]).reshape(1, 3000, 32, 64)
+    ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
+    s2 = ops.score_features(fs, ft)
+    assert score_relerr(scores.cpu().numpy(), s2.cpu().numpy()) < 1e-5
+    assert ops.argmax(s2)[1].item() == idx.item()
+
+
+def test_fused_edge_rotations(ops, G, dev):
+    g = load_golden("edge_rotations")
+    scores, val, idx = fused(ops, G, to_dev(g["R"], dev))
+    assert np.max(np.abs(scores.cpu().numpy() - g["scores"])) < 2e-6
+    assert idx.item() == int(g["best_idx"][0])
+
+
+def test_fused_batched_shared_and_per_sample(ops, G, dev):
+    g = load_golden("batched")
+    vs, vt = to_dev(g["vol_src"], dev), to_dev(g["vol_tgt"], dev)
+    ft = ops.forward_3d2d(vt, G["W1"], G["W2"], G["b2"])
+    s, key = ops.score_hypotheses(vs, ft, to_dev(g["R_shared"], dev), G["W1"], G["W2"], G["b2"])
+    assert score_relerr(s.cpu().numpy(), g["scores_shared"]) < SCORE_RTOL
+    assert ops.unpack_best(key)[1].cpu().tolist() == list(g["best_idx_shared"])
+    s2, _ = ops.score_hypotheses(vs, ft, to_dev(g["R_per"], dev), G["W1"], G["W2"], G["b2"])
+    assert score_relerr(s2.cpu().numpy(), g["scores_per"]) < SCORE_RTOL
+
+
+def test_fused_ragged_sizes_and_empty(ops, oracle, G, g128, ahv, dev):
+    Rall = ahv.rotations.haar_rotations_np(1031, 5)
+    ref, _, ref_idx = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], Rall, g128["W1"], g128["W2"],
+                                              g128["b2"])
+    for n in (1, 3, 4, 5, 63, 1023, 1024, 1025, 1031):
+        scores, val, idx = fused(ops, G, to_dev(Rall[:n], dev))
+        assert score_relerr(scores.cpu().numpy(), ref[:, :n]) < SCORE_RTOL
+        assert idx.item() == int(np.argmax(ref[0, :n]))
+    scores, val, idx = fused(ops, G, to_dev(Rall[:0], dev))  # N = 0: nothing scored
+    assert scores.shape == (1, 0) and idx.item() == -1 and val.item() == float("-inf")
+
+
+def test_fused_tie_break_lowest_index(ops, G, dev, ahv):
+    # every hypothesis identical -> identical scores -> torch.max returns index 0
+    R = to_dev(ahv.rotations.haar_rotations_np(1, 9), dev).expand(5000, -1, -1).contiguous()
+    scores, val, idx = fused(ops, G, R)
+    assert torch.unique(scores).numel() == 1
+    assert idx.item() == 0
+    # best hypothesis duplicated later in the list: the first copy wins
+    R2 = to_dev(ahv.rotations.haar_rotations_np(4000, 10), dev)
+    _, _, i0 = fused(ops, G, R2)
+    R2[3999] = R2[i0.item()]
+    _, _, i1 = fused(ops, G, R2)
+    assert i1.item() == i0.item()
+
+
+def test_fused_sharded_offsets_merge(ops, G, dev, ahv):
+    """N split into shards with n_offset (what each rank does); max over packed keys = global arg-max."""
+    R = to_dev(ahv.rotations.haar_rotations_np(10000, 11), dev)
+    ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
+    s_full, k_full = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
+    keys, parts = [], []
+    for r in range(4):
+        lo, hi = r * 2500, (r + 1) * 2500
+        s, k = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo)
+        keys.append(k)
+        parts.append(s)
+    assert torch.equal(torch.cat(parts, dim=1), s_full)  # per-hypothesis results do not depend on the shard
+    merged = ahv.dist.merge_keys(torch.stack(keys))  # unsigned max over ranks
+    assert torch.equal(merged, k_full)
+    assert ops.unpack_best(merged)[1].item() == ops.unpack_best(k_full)[1].item()
+    # chunked accumulation into one key tensor (flags = 0: merge into the caller's keys)
+    key = None
+    for r in range(4):
+        lo, hi = r * 2500, (r + 1) * 2500
+        _, key = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo,
+                                      want_scores=False, best_key=key)
+    assert torch.equal(key, k_full)
+
+
+def test_fused_properties_full_size(ops, G, dev, ahv):
+    """Size-independent properties at BASELINE.json's full N (50 000) and the LINEMOD-grid size (200 000)."""
+    ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
+    for n, gen in ((50000, lambda: ahv.rotations.haar_rotations_np(50000, 31)),
+                   (200000, lambda: ahv.rotations.so3_grid_np(200000))):
+        R = to_dev(gen(), dev)
+        s, k = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
+        val, idx = ops.unpack_best(k)
+        rv, ri = torch.max(s, dim=1)
+        assert idx.item() == ri.item() and val.item() == rv.item()        # key == torch.max of the scores
+        assert torch.all(s.abs() <= 1.0 + 1e-5)                           # mean cosine similarity
+        perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+        s_p, _ = ops.score_hypotheses(G["vol_src"], ft, R[perm].contiguous(), G["W1"], G["W2"], G["b2"])
+        assert torch.equal(s_p[0], s[0, perm])                            # order independence, bit for bit
+        s_again, k_again = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
+        assert torch.equal(s_again, s) and torch.equal(k_again, k)        # deterministic
+    # identity hypothesis == un-rotated source features scored against the target
+    eye = torch.eye(3, device=dev)[None]
+    s_id, _ = ops.score_hypotheses(G["vol_src"], ft, eye, G["W1"], G["W2"], G["b2"])
+    f_src = ops.forward_3d2d(G["vol_src"], G["W1"], G["W2"], G["b2"])
+    assert abs(s_id.item() - ops.score_features(f_src[None], ft).item()) < 1e-6
+    # scoring the target volume against its own features with R = I gives exactly-normalised 1.0
+    s_self, _ = ops.score_hypotheses(G["vol_tgt"], ft, eye, G["W1"], G["W2"], G["b2"])
+    assert abs(s_self.item() - 1.0) < 1e-5
+
+
+def test_fused_argument_errors(ops, ahv, G):
+    ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
+    with pytest.raises(RuntimeError):
+        ops.score_hypotheses(G["vol_src"], ft, G["R"].reshape(-1, 9), G["W1"], G["W2"], G["b2"])
+    with pytest.raises(RuntimeError):
+        ops.score_hypotheses(G["vol_src"].cpu(), ft.cpu(), G["R"].cpu(), G["W1"].cpu(), G["W2"].cpu(), G["b2"].cpu())
+    lib = ahv._lib.load()
+    rc = lib.ahv_score_hypotheses_f32(None, None, None, 0, 0, None, None, None, 1, 1, None, None, 0, None)
+    assert rc == -1 and b"null" in lib.ahv_last_error()
+    with pytest.raises(ahv._lib.AhvError):
+        ahv._lib.check(rc, "ahv_score_hypotheses_f32")

@@ -1,0 +1,83 @@
+"""Host-side logic (no GPU): hypothesis samplers, key codec, shard partition, error metric."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden
+
+
+def test_haar_sampler_reproducible_and_orthonormal(ahv):
+    R = ahv.rotations.haar_rotations_np(2000, 3)
+    assert R.dtype == np.float32 and R.shape == (2000, 3, 3)
+    assert np.array_equal(R, ahv.rotations.haar_rotations_np(50000, 3)[:2000])
+    eye = np.einsum("nij,nkj->nik", R.astype(np.float64), R.astype(np.float64))
+    assert np.allclose(eye, np.eye(3), atol=1e-6)
+    assert np.allclose(np.linalg.det(R.astype(np.float64)), 1.0, atol=1e-6)
+    g = load_golden("score_n50k_digest")
+    assert hashlib.sha256(ahv.rotations.haar_rotations_np(50000, 3).tobytes()).hexdigest() == str(g["R_sha256"])
+
+
+def test_haar_statistics(ahv):
+    # Haar measure: rotation angle density (1-cos t)/pi -> E[trace] = 0, E[angle] = pi/2 + 2/pi
+    R = ahv.rotations.random_rotations(20000, generator=torch.Generator().manual_seed(0)).double()
+    tr = R.diagonal(dim1=1, dim2=2).sum(-1)
+    assert abs(tr.mean().item()) < 0.03
+    ang = torch.arccos(((tr - 1) / 2).clamp(-1, 1))
+    assert abs(ang.mean().item() - (np.pi / 2 + 2 / np.pi)) < 0.02
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand_as(R), atol=1e-6)
+
+
+def test_so3_grid_covers_uniformly(ahv):
+    G = ahv.rotations.so3_grid_np(4096).astype(np.float64)
+    assert np.allclose(np.einsum("nij,nkj->nik", G, G), np.eye(3), atol=1e-5)
+    Q = ahv.rotations.haar_rotations_np(200, 1).astype(np.float64)
+    tr = np.einsum("qij,nij->qn", Q, G)  # trace(Q^T G)
+    nearest = np.degrees(np.arccos(np.clip((tr.max(axis=1) - 1) / 2, -1, 1)))
+    assert nearest.max() < 25.0 and nearest.mean() < 12.0  # 4096 points: ~10 deg spacing
+
+
+def test_refine_rotations_stay_local(ahv):
+    Rs = torch.from_numpy(ahv.rotations.haar_rotations_np(1, 2)[0])
+    out = ahv.rotations.refine_rotations(Rs, 500, 10.0, generator=torch.Generator().manual_seed(1))
+    assert torch.allclose(out[0], Rs, atol=1e-6)
+    err = ahv.rotations.geodesic_deg(out, Rs[None].expand_as(out))
+    assert err.max().item() <= 10.0 + 1e-2 and err.mean().item() > 4.0
+
+
+def test_geodesic_metric_golden(ahv):
+    g = load_golden("metric")
+    err = ahv.rotations.geodesic_deg(torch.from_numpy(g["R_pred"]), torch.from_numpy(g["R_gt"])).numpy()
+    assert np.array_equal(err, g["err_deg"], equal_nan=True)  # same torch expression: bit-exact
+
+
+def test_key_codec_matches_torch_max(ahv):
+    d = ahv.dist
+    rng = np.random.RandomState(0)
+    s = rng.standard_normal(1000).astype(np.float32)
+    s[[5, 17]] = s.max() + 1  # tie: lowest index wins
+    keys = d.pack_keys_host(s, np.arange(1000))
+    merged = d.merge_keys(torch.from_numpy(keys)[:, None])
+    score, idx = d.unpack_keys_host(merged.numpy())
+    assert idx[0] == 5 and score[0] == s[5]
+    # ordering across sign, zero and NaN
+    vals = np.array([-np.inf, -2.0, -0.0, 0.0, 1e-30, 3.0, np.inf, np.nan], dtype=np.float32)
+    k = d.pack_keys_host(vals, np.zeros(8)).view(np.uint64)
+    assert k[2] == k[3] and all(k[i] < k[i + 1] for i in (0, 1, 3, 4, 5, 6))
+    sc, ix = d.unpack_keys_host(d.pack_keys_host(vals, np.arange(8)))
+    assert np.array_equal(sc[[0, 1, 4, 5, 6]], vals[[0, 1, 4, 5, 6]]) and np.isnan(sc[7]) and list(ix) == list(range(8))
+    sc, ix = d.unpack_keys_host(np.zeros(2, dtype=np.int64))
+    assert list(ix) == [-1, -1] and np.all(np.isneginf(sc))
+
+
+def test_shard_range_partitions(ahv):
+    for n in (0, 1, 7, 50000, 200000):
+        for w in (1, 2, 3, 8):
+            parts = [ahv.dist.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        ahv.dist.shard_range(10, 2, 2)
