@@ -25,6 +25,7 @@ _u32 = ctypes.c_uint
 SIGNATURES = {
     "ahv_abi_version": (_int, []),
     "ahv_last_error": (ctypes.c_char_p, []),
+    "ahv_set_option": (_int, [ctypes.c_char_p, _int]),
     "ahv_device_cu_count": (_int, []),
     "ahv_score_hypotheses_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32, _vp]),
     "ahv_unpack_best": (_int, [_vp, _int, _vp, _vp, _vp]),

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 #include "../../include/ahv.h"
 
@@ -17,6 +18,7 @@ hipError_t launch_forward_3d2d(const float*, const float*, const float*, const f
                                hipStream_t);
 hipError_t launch_score_features(const float*, const float*, int, int64_t, float*, int, hipStream_t);
 hipError_t launch_argmax(const float*, int, int64_t, int64_t, uint64_t*, int, hipStream_t);
+extern int g_score_variant;
 }  // namespace ahv
 
 namespace {
@@ -60,6 +62,17 @@ extern "C" {
 int ahv_abi_version(void) { return (1 << 16) | 0; }
 
 const char* ahv_last_error(void) { return g_err; }
+
+int ahv_set_option(const char* name, int value)
+{
+    if (name && std::strcmp(name, "score_variant") == 0) {
+        if (value < 0 || value > 2) return fail(AHV_EINVAL, "set_option: score_variant must be 0, 1 or 2");
+        const int prev = ahv::g_score_variant;
+        ahv::g_score_variant = value;
+        return prev;
+    }
+    return fail(AHV_EINVAL, "set_option: unknown option '%s'", name ? name : "(null)");
+}
 
 int ahv_device_cu_count(void)
 {

@@ -10,7 +10,8 @@
 // budget), a persistent grid of ~one workgroup per CU; blockIdx.y strides over
 // the batch, (blockIdx.x, wave) strides over hypotheses.  LDS per workgroup:
 // 40 KiB source image + 4 waves x 2 quarter buffers x 8 KiB = 104 KiB.
-#include "ahv_device.h"
+#include "ahv_pipeline.h"
+#include "ahv_wide.h"
 
 namespace ahv {
 
@@ -120,6 +121,228 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Pipelined variant (default).  Same arithmetic as above, but the trilinear gather of the NEXT
+// quarter is interleaved, instruction by instruction, with the MFMAs of the CURRENT quarter:
+// one wave per SIMD cannot rely on another wave to fill the matrix pipe's shadow, so the
+// overlap is built into the instruction stream (sched_group_barrier: 1 MFMA : a few VALU/DS).
+// The pipeline also crosses hypotheses: quarter 0 of hypothesis h+1 is gathered under the
+// last GEMM quarter of hypothesis h.
+//
+// The two quarter buffers and the source image are separate __shared__ arrays so that the
+// compiler knows a stage's LDS writes (other buffer) cannot alias its LDS reads and may
+// interleave them freely; wave_lds_fence() between stages keeps the cross-lane RAW/WAR order.
+// ---------------------------------------------------------------------------------------
+#ifdef AHV_STAMPS
+// Diagnostic build only (tools/kbench.cpp): per-wave cycle sums of the loop segments.  The stamps
+// leave the kernel through this buffer alone; no output value depends on them.
+__device__ unsigned long long g_stamps[1024 * 8];
+#define AHV_STAMP(var)                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define AHV_STAMP(var)
+#endif
+
+__global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_pipelined_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
+    long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int B, long N, float* __restrict__ scores,
+    unsigned long long* __restrict__ best_key)
+{
+    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_even[4 * kQuarterFloats];
+    __shared__ __attribute__((aligned(16))) float lds_odd[4 * kQuarterFloats];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* srcT = lds_src;
+    float* bufE = lds_even + wave * kQuarterFloats;
+    float* bufO = lds_odd + wave * kQuarterFloats;
+
+    HeadFrags f;
+    load_head_frags(f, W1, W2, b2, lane);
+    const LaneConst lc = make_lane_const(lane);
+    TriState ts;
+
+    const int n16 = lane & 15, kq = lane >> 4;
+    const long hstep = (long)gridDim.x * 4;
+
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kScoreThreads);
+        f32x4 tg[4][2];
+        {
+            const float* ft = feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tg[t][m2][r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16];
+        }
+        __syncthreads();
+
+        unsigned long long best = 0ull;
+        const float* Rb = R + (long)b * r_batch_stride;
+        long h = (long)blockIdx.x * 4 + wave;
+        float Rm[9];
+        if (h < N) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
+            tri_quarter<0>(bufE, srcT, Rm, lane);  // pipeline prologue
+            wave_lds_fence();
+        }
+#ifdef AHV_STAMPS
+        unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+        for (; h < N; h += hstep) {
+#ifdef AHV_STAMPS
+            unsigned long long t0, t1, t2, t3, t4, t5, t6;
+#endif
+            AHV_STAMP(t0)
+            const long hn = (h + hstep < N) ? h + hstep : h;  // last round re-gathers its own q0 (unused)
+            float Rn[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rn[i] = Rb[hn * 9 + i];
+
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            pipelined_stage<0>(acc, f, bufE, bufO, srcT, Rm, lc, ts);
+            AHV_STAMP(t1)
+            pipelined_stage<1>(acc, f, bufO, bufE, srcT, Rm, lc, ts);
+            AHV_STAMP(t2)
+            pipelined_stage<2>(acc, f, bufE, bufO, srcT, Rm, lc, ts);
+            AHV_STAMP(t3)
+            pipelined_stage<3>(acc, f, bufO, bufE, srcT, Rn, lc, ts);
+            AHV_STAMP(t4)
+
+            f32x4 v[2][4];
+            gemm2(v, acc, f);
+            AHV_STAMP(t5)
+            const float s = hyp_score(v, tg);
+            if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
+            const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
+            best = key > best ? key : best;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rn[i];
+            AHV_STAMP(t6)
+#ifdef AHV_STAMPS
+            tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3;
+            tsum[4] += t5 - t4; tsum[5] += t6 - t5; tsum[6] += 1;
+#endif
+        }
+#ifdef AHV_STAMPS
+        if (lane == 0) {
+            const int gw = (blockIdx.x * 4 + wave) & 1023;
+            for (int i = 0; i < 7; ++i) g_stamps[gw * 8 + i] = tsum[i];
+        }
+#endif
+        if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Wide variant (default): 32x32x2 fp32 MFMA, half-volume phases (ahv_wide.h).
+// LDS: 40 KiB source image + 4 waves x 16 KiB half-volume image = 104 KiB.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_wide_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
+    long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int B, long N, float* __restrict__ scores,
+    unsigned long long* __restrict__ best_key)
+{
+    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_half[4 * kHalfFloats];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* srcT = lds_src;
+    float* buf = lds_half + wave * kHalfFloats;
+
+    WideFrags f;
+    load_wide_frags(f, W1, W2, b2, lane);
+    const WideLane L = make_wide_lane(lane);
+    const long hstep = (long)gridDim.x * 4;
+
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();  // every wave is done with the previous sample's source image
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kScoreThreads);
+        f32x16 tg[2];
+        {
+            const float* ft = feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tg[t][r] = ft[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 64 + 32 * t + (lane & 31)];
+        }
+        __syncthreads();
+
+        unsigned long long best = 0ull;
+        const float* Rb = R + (long)b * r_batch_stride;
+#ifdef AHV_STAMPS
+        unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+        for (long h = (long)blockIdx.x * 4 + wave; h < N; h += hstep) {
+#ifdef AHV_STAMPS
+            unsigned long long t0, t1, t2, t3, t4, t5, t6;
+#endif
+            float Rm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];  // wave-uniform -> scalar loads
+
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+            AHV_STAMP(t0)
+            gather_half<0>(buf, srcT, Rm, L);
+            wave_lds_fence();
+            AHV_STAMP(t1)
+            gemm1_half<0>(acc, f, buf, L);
+            wave_lds_fence();
+            AHV_STAMP(t2)
+            gather_half<1>(buf, srcT, Rm, L);
+            wave_lds_fence();
+            AHV_STAMP(t3)
+            gemm1_half<1>(acc, f, buf, L);
+            wave_lds_fence();
+            AHV_STAMP(t4)
+
+            f32x16 v[2];
+            gemm2_wide(v, acc, f);
+            AHV_STAMP(t5)
+            const float s = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, score_wide(v, tg)), 63));  // total is in lane 63
+            if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
+            const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
+            best = key > best ? key : best;
+            AHV_STAMP(t6)
+#ifdef AHV_STAMPS
+            tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3;
+            tsum[4] += t5 - t4; tsum[5] += t6 - t5; tsum[6] += 1;
+#endif
+        }
+#ifdef AHV_STAMPS
+        if (lane == 0) {
+            const int gw = (blockIdx.x * 4 + wave) & 1023;
+            for (int i = 0; i < 7; ++i) g_stamps[gw * 8 + i] = tsum[i];
+        }
+#endif
+        if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
+    }
+}
+
 __global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_key, int B,
                                    float* __restrict__ best_score, long* __restrict__ best_idx)
 {
@@ -134,6 +357,20 @@ __global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_k
 
 // ---- host-side launchers (called by the C ABI in ahv_abi.hip) ----------------------
 namespace ahv {
+
+int g_score_variant = 2;  // 0 = 16x16x4 phase-sequential, 1 = 16x16x4 micro-step pipelined, 2 = 32x32x2 wide (default)
+
+template <typename K>
+static hipError_t launch_score_kernel(K kernel, size_t lds, dim3 grid, hipStream_t stream, const float* vol_src,
+                                      const float* feat_tgt, const float* R, int64_t r_batch_stride,
+                                      int64_t n_offset, const float* W1, const float* W2, const float* b2, int B,
+                                      int64_t N, float* scores, uint64_t* best_key)
+{
+    hipLaunchKernelGGL(kernel, grid, dim3(kScoreThreads), lds, stream, vol_src, feat_tgt, R, (long)r_batch_stride,
+                       (long)n_offset, W1, W2, b2, B, (long)N, scores,
+                       reinterpret_cast<unsigned long long*>(best_key));
+    return hipGetLastError();
+}
 
 hipError_t launch_score_hypotheses(const float* vol_src, const float* feat_tgt, const float* R,
                                    int64_t r_batch_stride, int64_t n_offset, const float* W1,
@@ -158,10 +395,15 @@ hipError_t launch_score_hypotheses(const float* vol_src, const float* feat_tgt, 
     const int64_t need = (N + 3) / 4;  // workgroups that can get at least one hypothesis per wave
     if (gx > need) gx = (int)need;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(score_hypotheses_kernel, dim3(gx, gy), dim3(kScoreThreads), lds, stream, vol_src,
-                       feat_tgt, R, (long)r_batch_stride, (long)n_offset, W1, W2, b2, B, (long)N, scores,
-                       reinterpret_cast<unsigned long long*>(best_key));
-    return hipGetLastError();
+    const dim3 grid(gx, gy);
+#define AHV_LAUNCH(K, L) \
+    launch_score_kernel(K, L, grid, stream, vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key)
+    switch (g_score_variant) {
+        case 0: return AHV_LAUNCH(score_hypotheses_kernel, lds);
+        case 1: return AHV_LAUNCH(score_hypotheses_pipelined_kernel, 0);
+        default: return AHV_LAUNCH(score_hypotheses_wide_kernel, 0);
+    }
+#undef AHV_LAUNCH
 }
 
 hipError_t launch_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx,

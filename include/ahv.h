@@ -54,6 +54,14 @@ int ahv_abi_version(void);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ahv_last_error(void);
 
+/*
+ * Tuning / diagnostic knob (not part of the reference's interface).  Known names:
+ *   "score_variant"  fused-scorer kernel: 0 = 16x16x4 MFMA, phase-sequential; 1 = 16x16x4 MFMA,
+ *                    micro-step software pipeline; 2 = 32x32x2 MFMA, half-volume phases (default)
+ * Returns the previous value, or AHV_EINVAL for an unknown name / value.
+ */
+int ahv_set_option(const char* name, int value);
+
 /* Number of compute units of the current device (for sizing / reporting); <0 on error. */
 int ahv_device_cu_count(void);
 

@@ -315,3 +315,16 @@ def test_fused_argument_errors(ops, ahv, G):
     assert rc == -1 and b"null" in lib.ahv_last_error()
     with pytest.raises(ahv._lib.AhvError):
         ahv._lib.check(rc, "ahv_score_hypotheses_f32")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_fused_kernel_variants_agree(ops, ahv, G, g128, variant):
+    """All fused-kernel variants (diagnostic knob) meet the same parity bar."""
+    lib = ahv._lib.load()
+    prev = lib.ahv_set_option(b"score_variant", variant)
+    try:
+        scores, val, idx = fused(ops, G, G["R"])
+        assert score_relerr(scores.cpu().numpy(), g128["scores"]) < SCORE_RTOL
+        assert idx.item() == int(g128["best_idx"][0])
+    finally:
+        lib.ahv_set_option(b"score_variant", prev)

@@ -28,7 +28,12 @@ print("fused score abs err", e.max(), "rel", (e / np.abs(g["scores"])).max())
 print("fused best", [x.tolist() for x in ops.unpack_best(key)])
 # timing at N=50000
 Rn = T(ahv.rotations.haar_rotations_np(50000, 3))
-for want in (True, False):
+lib = ahv._lib.load()
+for variant in (0, 1, 0, 1):
+  lib.ahv_set_option(b"score_variant", variant)
+  sv, kv = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+  print("variant", variant, "n128 abs err", np.abs(sv.cpu().numpy() - g["scores"]).max(), [x.tolist() for x in ops.unpack_best(kv)])
+  for want in (False,):
     for _ in range(3):
         ops.score_hypotheses(vs, ft, Rn, W1, W2, b2, want_scores=want)
     torch.cuda.synchronize()
@@ -38,7 +43,7 @@ for want in (True, False):
         s50, k50 = ops.score_hypotheses(vs, ft, Rn, W1, W2, b2, want_scores=want)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / it
-    print("fused N=50000 want_scores=%s: %.3f ms -> %.3e hyp/s (%.1f TFLOP/s)" % (want, dt * 1e3, 50000 / dt, 50000 / dt * 1839104 / 1e12))
+    print("variant", variant, "fused N=50000 want_scores=%s: %.3f ms -> %.3e hyp/s (%.1f TFLOP/s)" % (want, dt * 1e3, 50000 / dt, 50000 / dt * 1839104 / 1e12))
 g50 = np.load(os.path.join(REPO, "tests/golden/score_n50k_digest.npz"))
 s50, k50 = ops.score_hypotheses(vs, ft, Rn, W1, W2, b2)
 print("50k best", [x.tolist() for x in ops.unpack_best(k50)], g50["best"], g50["best_idx"])

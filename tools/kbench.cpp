@@ -1,0 +1,89 @@
+// kbench.cpp -- developer micro-benchmark for the fused scorer (not part of the product).
+// Includes the kernel source directly so that diagnostic builds (-DAHV_STAMPS) can read the
+// in-kernel cycle stamps.  Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DAHV_STAMPS] \
+//                                   -I3dahv_amd/csrc tools/kbench.cpp -o tools/kbench
+// Run (on the GPU box):  tools/kbench [N] [iters]
+#include "../3dahv_amd/csrc/ahv_score.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv)
+{
+    const long N = argc > 1 ? atol(argv[1]) : 50000;
+    const int iters = argc > 2 ? atoi(argv[2]) : 20;
+    std::mt19937 rng(0);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> vol(8192), ft(2048), R(N * 9), W1(32 * 384), W2(1024), b2(32);
+    for (auto& x : vol) x = 1.15f * nd(rng);
+    for (auto& x : ft) x = nd(rng) / 5.6f;
+    for (auto& x : W1) x = nd(rng) * 0.03f;
+    for (auto& x : W2) x = nd(rng) * 0.1f;
+    for (auto& x : b2) x = nd(rng) * 0.1f;
+    for (long n = 0; n < N; ++n) {  // Haar rotations from normalised Gaussian quaternions
+        double q[4], s = 0;
+        for (double& c : q) { c = nd(rng); s += c * c; }
+        const double t = 2.0 / s, r = q[0], i = q[1], j = q[2], k = q[3];
+        const double m[9] = {1 - t * (j * j + k * k), t * (i * j - k * r), t * (i * k + j * r),
+                             t * (i * j + k * r), 1 - t * (i * i + k * k), t * (j * k - i * r),
+                             t * (i * k - j * r), t * (j * k + i * r), 1 - t * (i * i + j * j)};
+        for (int e = 0; e < 9; ++e) R[n * 9 + e] = (float)m[e];
+    }
+    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dsc;
+    uint64_t* dkey;
+    CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
+    CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
+    CK(hipMalloc(&dsc, N * 4)); CK(hipMalloc(&dkey, 8));
+    CK(hipMemcpy(dvol, vol.data(), vol.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dft, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW1, W1.data(), W1.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW2, W2.data(), W2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dkey, 0, 8));
+    int cu = 0;
+    CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ref(N);
+    for (int variant = 0; variant < 3; ++variant) {
+        ahv::g_score_variant = variant;
+        for (int rep = 0; rep < 3; ++rep) {
+            for (int w = 0; w < 3; ++w)
+                CK(ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, 0));
+            CK(hipEventRecord(e0, 0));
+            for (int it = 0; it < iters; ++it)
+                CK(ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= iters;
+            printf("variant %d: %.4f ms  %.3e hyp/s  %.1f TFLOP/s (%.1f%% of 157.3)\n", variant, ms, N / (ms * 1e-3),
+                   N / (ms * 1e-3) * 1839104 / 1e12, N / (ms * 1e-3) * 1839104 / 1e12 / 157.3 * 100);
+        }
+        std::vector<float> sc(N);
+        CK(hipMemcpy(sc.data(), dsc, N * 4, hipMemcpyDeviceToHost));
+        if (variant == 0) ref = sc;
+        double md = 0;
+        for (long n = 0; n < N; ++n) md = std::max(md, (double)std::abs(sc[n] - ref[n]));
+        printf("variant %d: max |score - variant0| = %.3g, score[0]=%.6f\n", variant, md, sc[0]);
+    }
+#ifdef AHV_STAMPS
+    // stamps belong to the last variant run (2 = wide): gather0, gemm0, gather1, gemm1, gemm2, score
+    std::vector<unsigned long long> st(1024 * 8);
+    CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(ahv::g_stamps), st.size() * 8));
+    double sum[7] = {0};
+    for (int w = 0; w < 1024; ++w) for (int i = 0; i < 7; ++i) sum[i] += (double)st[w * 8 + i];
+    const char* names[6] = {"seg0", "seg1", "seg2", "seg3", "gemm2", "score+tail"};
+    double tot = 0;
+    for (int i = 0; i < 6; ++i) tot += sum[i] / sum[6];
+    for (int i = 0; i < 6; ++i) printf("  %-10s %8.0f cycles/hyp (%.1f%%)\n", names[i], sum[i] / sum[6], 100 * sum[i] / sum[6] / tot);
+    printf("  total      %8.0f cycles/hyp (s_memtime ticks), rounds/wave %.1f\n", tot, sum[6] / 1024);
+#endif
+    return 0;
+}
