@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's ``Feature_Aligner`` (modules/modules.py:49-124).
+
+Same constructor, method names, argument meaning and -- attribute for attribute -- the same
+``state_dict`` keys, so a Lightning ``.ckpt`` of the reference loads
+with ``load_state_dict``.
+
+* ``forward_3d2d`` (per hypothesis, hot) runs the HIP kernel through the C ABI.
+* ``forward_2d3d`` (once per pair: conv embedding, sin/cos position code, the
+  bidirectional 3D-aware transformer of transformer/attention.py:196-396, 3-D res-block) is
+  issued with stock PyTorch-ROCm operators for now; its fused kernels are the next row of
+  SURVEY.md section 8(f).  It is pinned by the ``encoder_small`` golden fixture.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- encoder pieces
+class _GatedProj(nn.Module):
+    """GEGLU input projection (transformer/attention.py:81-88): Linear -> (x, gate) -> x * gelu(gate)."""
+
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, 2 * dim_out)
+
+    def forward(self, t):
+        val, gate = self.proj(t).chunk(2, dim=-1)
+        return val * F.gelu(gate)  # exact erf GELU, as in the reference
+
+
+class _FF(nn.Module):
+    """FeedForward(2*dim -> dim, mult 4, gated) (transformer/attention.py:91-108); keys net.0.proj.*, net.2.*"""
+
+    def __init__(self, dim_in: int, dim_out: int, mult: int = 4):
+        super().__init__()
+        inner = int(dim_in * mult)
+        self.net = nn.ModuleList([_GatedProj(dim_in, inner), nn.Identity(), nn.Linear(inner, dim_out)])
+
+    def forward(self, t):
+        return self.net[2](self.net[0](t))
+
+
+class _Attention(nn.Module):
+    """Multi-head attention, q/k/v without bias, output projection with bias
+    (transformer/attention.py:196-237); keys to_q/to_k/to_v.weight, to_out.0.{weight,bias}."""
+
+    def __init__(self, dim: int, heads: int, dim_head: int):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(dim, inner, bias=False)
+        self.to_v = nn.Linear(dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, dim)])
+
+    def forward(self, x, ctx):
+        B, n, _ = x.shape
+        split = lambda t: t.reshape(B, t.shape[1], self.heads, -1).transpose(1, 2)  # (B,h,n,d)
+        q, k, v = split(self.to_q(x)), split(self.to_k(ctx)), split(self.to_v(ctx))
+        att = torch.softmax((q @ k.transpose(-1, -2)) * self.scale, dim=-1)
+        out = (att @ v).transpose(1, 2).reshape(B, n, -1)
+        return self.to_out[0](out)
+
+
+class _Block(nn.Module):
+    """BasicTransformerBlock (transformer/attention.py:240-258):
+    m = LN1(attn(x, ctx)); m = LN2(FF(cat[x, m])); return x + m."""
+
+    def __init__(self, dim: int, heads: int, dim_head: int):
+        super().__init__()
+        self.attn = _Attention(dim, heads, dim_head)
+        self.ff = _FF(2 * dim, dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+
+    def forward(self, x, ctx=None):
+        m = self.norm1(self.attn(x, x if ctx is None else ctx))
+        m = self.norm2(self.ff(torch.cat([x, m], dim=2)))
+        return x + m
+
+
+class _BiBlock(nn.Module):
+    """BidirectionTransformerBlock (transformer/attention.py:260-274): self(src), self(tgt),
+    cross(src<-tgt), cross(tgt<-src), the two crosses reading the SAME post-self tensors."""
+
+    def __init__(self, dim: int, heads: int, dim_head: int):
+        super().__init__()
+        self.attn_self_1 = _Block(dim, heads, dim_head)
+        self.attn_self_2 = _Block(dim, heads, dim_head)
+        self.attn_cross_1 = _Block(dim, heads, dim_head)
+        self.attn_cross_2 = _Block(dim, heads, dim_head)
+
+    def forward(self, x, ctx):
+        x, ctx = self.attn_self_1(x), self.attn_self_2(ctx)
+        return self.attn_cross_1(x, ctx), self.attn_cross_2(ctx, x)
+
+
+class BidirectionTransformer(nn.Module):
+    """The reference's "3D-aware encoder" (transformer/attention.py:336-396): ONE shared GroupNorm
+    (32 groups, eps 1e-6), separate 1x1 in/out projections per stream, `depth` bidirectional blocks
+    over 64 tokens, residual to the un-normalised inputs."""
+
+    def __init__(self, in_channels: int, n_heads: int, d_head: int, depth: int = 1, dropout: float = 0.0,
+                 context_dim=None, normalize: bool = True):
+        super().__init__()
+        if dropout != 0.0 or not normalize:
+            raise NotImplementedError("the reference always uses dropout=0 and normalize=True")
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.proj_context_in = nn.Conv2d(in_channels if context_dim is None else context_dim, inner, 1)
+        self.transformer_blocks = nn.ModuleList([_BiBlock(inner, n_heads, d_head) for _ in range(depth)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+        self.proj_context_out = nn.Conv2d(inner, in_channels, 1)
+
+    def forward(self, x, context):
+        b, _, h, w = x.shape
+        tok = lambda t: t.flatten(2).transpose(1, 2)                      # (B, hw, C)
+        img = lambda t, hh, ww: t.transpose(1, 2).reshape(b, -1, hh, ww)  # back to (B, C, h, w)
+        xs = tok(self.proj_in(self.norm(x)))
+        cs = tok(self.proj_context_in(self.norm(context)))
+        for blk in self.transformer_blocks:
+            xs, cs = blk(xs, cs)
+        hc, wc = context.shape[-2:]
+        return self.proj_out(img(xs, h, w)) + x, self.proj_context_out(img(cs, hc, wc)) + context
+
+
+class _ResBlock(nn.Module):
+    """ResNetBlock_2D / _3D with BN=False (modules/modules.py:9-47,126-164): conv-relu-conv + skip
+    (1x1 conv skip when channels change).  ``bn_down`` exists in the reference's state dict but is
+    never applied in its forward (modules/modules.py:28-30 vs :32-47); kept for key parity only."""
+
+    def __init__(self, cin: int, cout: int, three_d: bool):
+        super().__init__()
+        conv = nn.Conv3d if three_d else nn.Conv2d
+        self.conv1 = conv(cin, cout, 3, padding=1, bias=False)
+        self.conv2 = conv(cout, cout, 3, padding=1, bias=False)
+        self.downsample = None
+        if cin != cout:
+            self.downsample = nn.Sequential(conv(cin, cout, 1, bias=False))
+            self.bn_down = (nn.BatchNorm3d if three_d else nn.BatchNorm2d)(cout)
+
+    def forward(self, x):
+        out = self.conv2(F.relu(self.conv1(x)))
+        return out + (x if self.downsample is None else self.downsample(x))
+
+
+def random_masking(x: torch.Tensor, mask_ratio: float) -> torch.Tensor:
+    """Train-time voxel masking (utils.py:133-158): keep a random (1-ratio) subset of the L=D*H*W
+    sites per sample; with probability 1/2 a sample is left unmasked.  Returns (N, L) float mask."""
+    N, L = x.shape[0], x[0, 0].numel()
+    keep = int(L * (1 - mask_ratio))
+    order = torch.argsort(torch.rand(N, L, device=x.device), dim=1)
+    gate = torch.rand(N, device=x.device) > 0.5
+    ranked = torch.zeros(N, L, device=x.device)
+    ranked[:, :keep] = 1
+    mask = torch.gather(ranked, 1, order)
+    return ((mask + gate[:, None].float()) > 0).float()
+
+
+# ----------------------------------------------------------------------------- the aligner
+class Feature_Aligner(nn.Module):
+    """Drop-in for the reference class of the same name (modules/modules.py:49-124)."""
+
+    def __init__(self, in_channel: int = 256, mid_channel: int = 256, out_channel: int = 32, n_heads: int = 4,
+                 depth: int = 4):
+        super().__init__()
+        self.in_channel, self.mid_channel, self.out_channel = in_channel, mid_channel, out_channel
+        self.feature_embedding = nn.Sequential(nn.Conv2d(in_channel, mid_channel, 1, bias=False),
+                                               _ResBlock(mid_channel, mid_channel, three_d=False))
+        self.att = BidirectionTransformer(mid_channel, n_heads=n_heads, d_head=mid_channel // n_heads, depth=depth,
+                                          dropout=0.0, context_dim=mid_channel, normalize=True)
+        self.feature_embedding_3d = _ResBlock(mid_channel // 8, 16, three_d=True)
+        self.feature_embedding_2d = nn.Sequential(nn.Conv2d(3 * 8 * 16, out_channel, 1, bias=False),
+                                                  nn.ReLU(inplace=True), nn.Conv2d(out_channel, out_channel, 1))
+
+    def posemb_sincos_2d(self, patches, channel=128, temperature=10000, dtype=torch.float32):
+        """cat(sin x, cos x, sin y, cos y) with channel/4 frequencies 1/T^(k/(channel/4-1))
+        (modules/modules.py:72-84); returns (channel, h, w)."""
+        h, w = patches.shape[-2:]
+        assert channel % 4 == 0, "feature dimension must be multiple of 4 for sincos emb"
+        n = channel // 4
+        omega = 1.0 / (temperature ** (torch.arange(n, device=patches.device) / (n - 1)))
+        ys, xs = torch.meshgrid(torch.arange(h, device=patches.device), torch.arange(w, device=patches.device),
+                                indexing="ij")
+        ay, ax = ys[None] * omega[:, None, None], xs[None] * omega[:, None, None]
+        return torch.cat((ax.sin(), ax.cos(), ay.sin(), ay.cos()), dim=0).type(dtype)
+
+    def forward_2d3d(self, img_feat_src, img_feat_tgt, random_mask=True, mask_ratio=0.25):
+        """(B,in,8,8) x2 -> (B,16,8,8,8) x2 (modules/modules.py:86-110)."""
+        bs = img_feat_src.shape[0]
+        src, tgt = self.feature_embedding(img_feat_src), self.feature_embedding(img_feat_tgt)
+        pe = self.posemb_sincos_2d(src, channel=self.mid_channel)[None]
+        src, tgt = self.att(src + pe, tgt + pe)
+        # channel index = c' * 8 + d: the 2-D map's channels become (c', depth)
+        src = self.feature_embedding_3d(src.reshape(bs, self.mid_channel // 8, 8, 8, 8))
+        tgt = self.feature_embedding_3d(tgt.reshape(bs, self.mid_channel // 8, 8, 8, 8))
+        if random_mask is True:
+            src = src * random_masking(src, mask_ratio).reshape(-1, 1, 8, 8, 8)
+            tgt = tgt * random_masking(tgt, mask_ratio).reshape(-1, 1, 8, 8, 8)
+        return src, tgt
+
+    def head_weights(self):
+        """(W1 (32,384), W2 (32,32), b2 (32,)) views of feature_embedding_2d for the C ABI."""
+        c1, c2 = self.feature_embedding_2d[0], self.feature_embedding_2d[2]
+        return c1.weight.reshape(c1.out_channels, -1), c2.weight.reshape(c2.out_channels, -1), c2.bias
+
+    def forward_3d2d(self, img_feat):
+        """(M,16,8,8,8) -> (M,32,64), unit norm over dim 1 (modules/modules.py:112-124). HIP kernel."""
+        if self.out_channel != 32:
+            raise NotImplementedError("the HIP head is built for out_channel=32 (the reference's only value)")
+        return ops.forward_3d2d(img_feat, *self.head_weights())
+
+    # ---- fused entry point (not in the reference: its call sites inline these three steps) ----
+    def score_hypotheses(self, img_feat_src, img_feat_tgt, proposals, n_offset: int = 0, want_scores: bool = True):
+        """rotate_volume + forward_3d2d + score + running arg-max for every proposal in ONE launch
+        (test_co3d.py:137-145).  Returns (scores (B,N) | None, packed best keys (B,))."""
+        f_tgt = self.forward_3d2d(img_feat_tgt)
+        return ops.score_hypotheses(img_feat_src, f_tgt, proposals, *self.head_weights(), n_offset=n_offset,
+                                    want_scores=want_scores)

@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference ``Estimator`` call surface.
+
+Two variants exist in the reference, both Lightning modules:
+
+* ``modules/model_co3d.py:26-101``  -- ``forward(img_src, img_tgt)``           (test_co3d.py)
+* ``modules/model.py:28-218``       -- ``forward(img_src, mask_src, img_tgt, mask_tgt)``,
+  ``validation_step`` / ``test_step``                                          (test_objaverse.py, test_linemod.py)
+
+Mirrored here as plain ``nn.Module`` s: constructor ``Estimator(cfg)``, attributes
+``feature_extractor / feature_aligner / num_rota / step_outputs / gt_dis / pred_Rs``,
+``feature_extraction``, ``forward``, ``test_step``, ``validation_step``, ``eval()``,
+``load_from_checkpoint(path, cfg=cfg)`` and the ``state_dict`` prefixes
+``feature_extractor.*`` / ``feature_aligner.*``.  The per-hypothesis loop inside the steps runs
+as ONE fused HIP launch.  Lightning's trainer machinery, ``training_step`` and ``infoNCE_loss``
+(backward pass) are out of scope of this round.
+
+The MiDaS DPT/Swin-V2 backbone (``feature_extractor``) is stock timm code that is neither
+installed nor downloadable offline; it is injected (``feature_extractor=`` or
+``backbone_factory=``) and only its ``layer_4`` contract is relied on: images
+``(B,3,256,256)`` -> ``(B,768,8,8)`` (MiDaS/midas/backbones/swin_common.py:47-50).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from . import checkpoint as _ckpt
+from . import ops
+from .aligner import Feature_Aligner
+from .rotations import geodesic_deg, random_rotations
+
+
+class PatchifyBackbone(nn.Module):
+    """Stand-in ``feature_extractor`` with the same I/O contract as the reference's Swin stage-4 hook
+    (images (B,3,256,256) -> layer_4 (B,768,8,8)): one stride-32 patch embedding.  For synthetic
+    runs and tests only; real accuracy needs the real MiDaS weights."""
+
+    def __init__(self, out_channels: int = 768, patch: int = 32, seed: int = 0):
+        super().__init__()
+        self.proj = nn.Conv2d(3, out_channels, patch, stride=patch)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            self.proj.weight.copy_(torch.randn(self.proj.weight.shape, generator=g) * 0.02)
+            self.proj.bias.zero_()
+
+    def forward(self, img):
+        return self.proj(img)
+
+
+class _EstimatorBase(nn.Module):
+    def __init__(self, cfg, feature_extractor: Optional[nn.Module] = None,
+                 backbone_factory: Optional[Callable[[], nn.Module]] = None):
+        super().__init__()
+        self.cfg = cfg
+        self.num_rota = cfg["DATA"]["NUM_ROTA"]
+        self.mid_channel = 256
+        if feature_extractor is None and backbone_factory is not None:
+            feature_extractor = backbone_factory()
+        if feature_extractor is None:
+            feature_extractor = _try_midas_backbone()
+        self.feature_extractor = feature_extractor
+        self.feature_aligner = Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4)
+        self.step_outputs = []
+        self.gt_dis = []
+        self.pred_Rs = []
+        self.logged = {}  # stands in for Lightning's self.log
+
+    # -- reference: modules/model_co3d.py:37-39, modules/model.py:39-41
+    def feature_extraction(self, img):
+        fx = self.feature_extractor
+        if fx is None:
+            raise RuntimeError("no feature_extractor: pass feature_extractor= (timm / MiDaS weights are not "
+                               "available offline) or use synthetic layer_4 features via forward_features()")
+        if hasattr(fx, "forward_transformer"):  # the real MiDaS DPT object
+            return fx.forward_transformer(fx.pretrained, img)[3]
+        return fx(img)
+
+    def forward_features(self, layer4_src, layer4_tgt):
+        """Everything after the backbone: (B,768,8,8) x2 -> volumes (B,16,8,8,8) x2."""
+        return self.feature_aligner.forward_2d3d(layer4_src, layer4_tgt, random_mask=False, mask_ratio=0.0)
+
+    def log(self, name, value, **_):
+        self.logged.setdefault(name, []).append(float(value))
+
+    # -- the verify step shared by test_step / validation_step / the harness
+    @torch.no_grad()
+    def verify(self, img_feat_src, img_feat_tgt, proposals, want_scores: bool = False):
+        """For B volume pairs and shared proposals (N,3,3): scores (optional), best score, best index,
+        R_pred = proposals[idx]  (test_co3d.py:137-146, modules/model.py:186-196)."""
+        scores, key = self.feature_aligner.score_hypotheses(img_feat_src, img_feat_tgt, proposals,
+                                                            want_scores=want_scores)
+        best, idx = ops.unpack_best(key)
+        return scores, best, idx, proposals[idx]
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, cfg=None, map_location="cpu", strict: bool = True, **kw):
+        """Reads a Lightning ``.ckpt`` written by the reference (``state_dict`` with prefixes
+        ``feature_aligner.*`` / ``feature_extractor.*``).  ``cfg`` is required, as in test_co3d.py:218."""
+        if cfg is None:
+            raise TypeError("load_from_checkpoint() missing cfg (the reference passes cfg=cfg, test_co3d.py:218)")
+        model = cls(cfg, **kw)
+        sd = _ckpt.read_state_dict(checkpoint_path, map_location=map_location)
+        _ckpt.load_into(model, sd, strict=strict)
+        return model
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("training (infoNCE_loss backward through the rotation/projection path) is the "
+                                  "next row of SURVEY.md section 8(f); this build covers inference")
+
+    infoNCE_loss = training_step
+
+
+class EstimatorCo3d(_EstimatorBase):
+    """modules/model_co3d.py::Estimator."""
+
+    def forward(self, img_src, img_tgt):
+        f_src, f_tgt = self.feature_extraction(img_src), self.feature_extraction(img_tgt)
+        return self.forward_features(f_src, f_tgt)
+
+
+class EstimatorObjaverse(_EstimatorBase):
+    """modules/model.py::Estimator (Objaverse / LINEMOD)."""
+
+    def forward(self, img_src, mask_src, img_tgt, mask_tgt):
+        if self.cfg["DATA"]["BG"] is False:  # modules/model.py:67-69
+            img_src, img_tgt = img_src * mask_src, img_tgt * mask_tgt
+        f_src, f_tgt = self.feature_extraction(img_src), self.feature_extraction(img_tgt)
+        return self.forward_features(f_src, f_tgt)
+
+    def _too_small(self, mask_src, mask_tgt):
+        thr = self.cfg["DATA"]["SIZE_THR"]
+        return bool(torch.any(mask_src.flatten(1).sum(dim=-1) < thr) or torch.any(mask_tgt.flatten(1).sum(dim=-1) < thr))
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx, proposals=None):
+        """modules/model.py:168-209.  ``proposals`` defaults to fresh Haar samples shared by the batch."""
+        mask_src, mask_tgt = batch["src_mask"], batch["ref_mask"]
+        img_src, img_tgt = batch["src_img"], batch["ref_img"]
+        R_src, R_tgt = batch["src_R"], batch["ref_R"]
+        if self._too_small(mask_src, mask_tgt):
+            print("Skip bad case")
+            return 0
+        vol_src, vol_tgt = self.forward(img_src, mask_src, img_tgt, mask_tgt)
+        gt_src_2_tgt_R = torch.bmm(R_tgt, torch.inverse(R_src))
+        if proposals is None:
+            proposals = random_rotations(self.num_rota, device=img_src.device)
+        _, _, _, pred_R = self.verify(vol_src, vol_tgt, proposals)
+        geo_dis = geodesic_deg(pred_R, gt_src_2_tgt_R)
+        gt_dis = geodesic_deg(R_src, R_tgt)
+        self.step_outputs.append(geo_dis)
+        self.gt_dis.append(gt_dis)
+        self.pred_Rs.append(pred_R.cpu().numpy().reshape(-1))
+        self.log("test_error", geo_dis.mean().item())
+        return geo_dis
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx, proposals=None):
+        """modules/model.py:118-158: test_step plus the GT-rotation score and Acc@15/30 (<=)."""
+        mask_src, mask_tgt = batch["src_mask"], batch["ref_mask"]
+        img_src, img_tgt = batch["src_img"], batch["ref_img"]
+        R_src, R_tgt = batch["src_R"], batch["ref_R"]
+        vol_src, vol_tgt = self.forward(img_src, mask_src, img_tgt, mask_tgt)
+        gt_src_2_tgt_R = torch.bmm(R_tgt, torch.inverse(R_src))
+        if proposals is None:
+            proposals = random_rotations(self.num_rota, device=img_src.device)
+        _, pred_sim, _, pred_R = self.verify(vol_src, vol_tgt, proposals)
+        # gt_sim: each sample's own GT rotation = per-sample R with N = 1 (modules/model.py:137-143)
+        f_tgt = self.feature_aligner.forward_3d2d(vol_tgt)
+        gt_sim, _ = ops.score_hypotheses(vol_src, f_tgt, gt_src_2_tgt_R[:, None].contiguous(),
+                                         *self.feature_aligner.head_weights())
+        geo_dis = geodesic_deg(pred_R, gt_src_2_tgt_R)
+        self.log("val_acc_15", (geo_dis <= 15).float().mean().item())
+        self.log("val_acc_30", (geo_dis <= 30).float().mean().item())
+        self.step_outputs.append(geo_dis)
+        return {"geo_dis": geo_dis, "pred_sim": pred_sim, "gt_sim": gt_sim[:, 0]}
+
+    def on_validation_epoch_end(self):
+        geo_dis = torch.cat(self.step_outputs)
+        out = (100 * (geo_dis <= 15).float().mean(), 100 * (geo_dis <= 30).float().mean())
+        self.step_outputs.clear()
+        return out
+
+
+Estimator = EstimatorCo3d  # the class test_co3d.py imports from modules.model_co3d
+
+
+def _try_midas_backbone():
+    """The reference builds ``DPT_SwinV2_T_256(pretrained=True)`` (MiDaS/hubconf.py:124-145), which needs
+    timm==0.6.12 and a weight download.  Neither exists offline: return None and let the caller inject."""
+    return None

@@ -1,0 +1,166 @@
+"""Evaluation-harness counterpart of the reference's ``test_co3d.py`` / ``test_linemod.py`` (SURVEY.md
+section 8a row H1) with a synthetic-pair mode (no dataset or checkpoint exists offline).
+
+What is reproduced from the reference scripts:
+* seeding ``torch.manual_seed(0); np.random.seed(0)``                      test_co3d.py:24-25
+* ONE proposal set per category, reused for every pair                      test_co3d.py:106
+* ``key_frames = np.random.choice(n, num_frames, replace=False)``            test_co3d.py:112
+* ordered pairs (i, j), i != j                                               test_co3d.py:47-53
+* ``R_gt = R_i^T R_j`` (pytorch3d row-vector convention)                     test_co3d.py:121-124
+* per pair: model -> volumes -> verify step -> ``R_pred`` -> angular error   test_co3d.py:133-152
+* per category: mean error, ``100*mean(err<30)``, ``100*mean(err<15)``        test_co3d.py:180-182
+* "mean" over categories, ``repeats`` repetitions averaged, result lines
+  ``f"{category:>10s}{err:6.02f}{acc15:6.02f}{acc30:6.02f}"`` appended to
+  ``models/<RUN_NAME>/co3d_result.txt``                                      test_co3d.py:186-252
+* LINEMOD: per-object loop, ``np.savetxt(linemod_pred_Rs_%06d.txt)``          test_linemod.py:20-86
+
+The verify step (rotate + project + score + arg-max over all proposals) is the fused HIP launch
+(``model.verify``).  ``verify_fn`` can be injected: the CPU-tier tests pass the oracle there to
+exercise this file's plumbing without a GPU -- the product default has no CPU path.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from .rotations import geodesic_deg, random_rotations
+
+
+def get_permutations(num_frames: int) -> torch.Tensor:
+    return torch.tensor([(i, j) for i in range(num_frames) for j in range(num_frames) if i != j])
+
+
+class SyntheticSequences:
+    """Synthetic stand-in for ``Co3dDataset``: ``n_seq`` sequences of ``n_frames`` views.  Each item is a
+    dict ``{"n", "model_id", "R" (n,3,3)}`` plus either ``"image" (n,3,256,256)`` or, when
+    ``layer4=True``, ``"layer4" (n,768,8,8)`` backbone features (for models without a backbone)."""
+
+    def __init__(self, n_seq: int = 4, n_frames: int = 6, layer4: bool = True, seed: int = 0, in_channel: int = 768):
+        self.n_seq, self.n_frames, self.layer4, self.seed, self.in_channel = n_seq, n_frames, layer4, seed, in_channel
+
+    def __len__(self):
+        return self.n_seq
+
+    def __iter__(self):
+        for s in range(self.n_seq):
+            g = torch.Generator().manual_seed(self.seed * 1000 + s)
+            item = {"n": self.n_frames, "model_id": "synthetic_%03d" % s,
+                    "R": random_rotations(self.n_frames, generator=g)}
+            if self.layer4:
+                item["layer4"] = torch.randn(self.n_frames, self.in_channel, 8, 8, generator=g)
+            else:
+                item["image"] = torch.rand(self.n_frames, 3, 256, 256, generator=g) * 2 - 1
+            yield item
+
+
+@torch.no_grad()
+def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2, device=None,
+                      proposals: Optional[torch.Tensor] = None, verify_fn: Optional[Callable] = None,
+                      return_details: bool = False):
+    """Counterpart of ``evaluate_category`` (test_co3d.py:93-154).  Returns the array of angular errors."""
+    if device is None:
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    permutations = get_permutations(num_frames)
+    if proposals is None:
+        proposals = random_rotations(cfg["DATA"]["NUM_ROTA"])
+    proposals = proposals.to(device)
+    if verify_fn is None:
+        verify_fn = lambda vs, vt, P: model.verify(vs, vt, P)[1:3]  # (best, idx): fused HIP launch
+    errors, details = [], []
+    for meta in sequences:
+        key_frames = np.random.choice(meta["n"], num_frames, replace=False)
+        rot = meta["R"][key_frames][permutations].to(device)               # (P, 2, 3, 3)
+        R_gt = torch.bmm(rot[:, 0].transpose(1, 2), rot[:, 1])
+        feats = meta["layer4"] if "layer4" in meta else meta["image"]
+        feats = feats[key_frames][permutations].to(device)                 # (P, 2, ...)
+        for i in range(len(permutations)):
+            if "layer4" in meta:
+                vol_src, vol_tgt = model.forward_features(feats[i, 0][None], feats[i, 1][None])
+            else:
+                vol_src, vol_tgt = model(feats[i, 0][None], feats[i, 1][None])
+            best, idx = verify_fn(vol_src, vol_tgt, proposals)
+            R_pred = proposals[idx]
+            err = geodesic_deg(R_pred, R_gt[i][None])
+            errors.append(err.mean().item())
+            if return_details:
+                details.append({"model_id": meta["model_id"], "pair": tuple(permutations[i].tolist()),
+                                "best": float(best.reshape(-1)[0]), "idx": int(idx.reshape(-1)[0]),
+                                "R_pred": R_pred[0].cpu().numpy(), "err": errors[-1]})
+    errors = np.array(errors)
+    return (errors, details) if return_details else errors
+
+
+def evaluate_pairwise(cfg, model, categories: Dict[str, Iterable[dict]], num_frames: int = 2, print_results=True,
+                      **kw):
+    """Counterpart of ``evaluate_pairwise`` (test_co3d.py:157-198)."""
+    errors, errors_15, errors_30 = {}, {}, {}
+    for category, sequences in categories.items():
+        e = evaluate_category(cfg, model, sequences, num_frames=num_frames, **kw)
+        errors[category] = np.mean(e)
+        errors_15[category] = 100 * np.mean(e < 15)
+        errors_30[category] = 100 * np.mean(e < 30)
+        if print_results:
+            print(category + " err: %.2f || acc_30: %.2f || acc_15: %.2f " % (errors[category], errors_30[category],
+                                                                                errors_15[category]))
+    errors["mean"] = np.mean(list(errors.values()))
+    errors_15["mean"] = np.mean(list(errors_15.values()))
+    errors_30["mean"] = np.mean(list(errors_30.values()))
+    return errors, errors_30, errors_15
+
+
+def format_result_line(category: str, err: float, acc15: float, acc30: float) -> str:
+    return f"{category:>10s}{err:6.02f}{acc15:6.02f}{acc30:6.02f}"
+
+
+def run_co3d(cfg, model, categories: Dict[str, Iterable[dict]], repeats: int = 5, out_dir: Optional[str] = None,
+             **kw):
+    """Counterpart of ``test_co3d.py.__main__`` (:201-253): seeds, ``repeats`` runs averaged, result file."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    acc = {}
+    for _ in range(repeats):
+        e, e30, e15 = evaluate_pairwise(cfg, model, categories, print_results=False, **kw)
+        for c in e:
+            acc.setdefault(c, []).append((e[c], e15[c], e30[c]))
+    lines = []
+    for c, vals in acc.items():
+        m = np.asarray(vals).mean(axis=0)
+        lines.append(format_result_line(c, m[0], m[1], m[2]))
+    if out_dir is None:
+        out_dir = os.path.join("models", cfg["RUN_NAME"])
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "co3d_result.txt"), "a") as f:
+        for line in lines:
+            f.write(line + " \n")
+    return lines
+
+
+@torch.no_grad()
+def test_linemod_category(cfg, model, loader: Iterable[dict], clsID: int, out_dir: Optional[str] = None,
+                          proposals_fn: Optional[Callable] = None):
+    """Evident intent of ``test_category`` (test_linemod.py:20-86; the shipped script does not run, SURVEY.md
+    section 2 row 7): per batch a fresh codebook, verify, angular error (<, not <=), ``linemod_pred_Rs`` file."""
+    pred_Rs, errs = [], []
+    for data in loader:
+        mask_src, mask_tgt = data["src_mask"], data["ref_mask"]
+        thr = cfg["DATA"]["SIZE_THR"]
+        if torch.any(mask_src.flatten(1).sum(dim=-1) < thr) or torch.any(mask_tgt.flatten(1).sum(dim=-1) < thr):
+            print("Skip bad case")
+            continue
+        dev = data["src_img"].device
+        codebook = proposals_fn() if proposals_fn else random_rotations(model.num_rota, device=dev)
+        vol_src, vol_tgt = model(data["src_img"], mask_src, data["ref_img"], mask_tgt)
+        gt = torch.bmm(data["ref_R"], torch.inverse(data["src_R"]))
+        _, _, _, R_pred = model.verify(vol_src, vol_tgt, codebook.to(dev))
+        errs.append(geodesic_deg(R_pred, gt))
+        pred_Rs.append(R_pred.cpu().numpy().reshape(-1))
+    err = torch.cat(errs)
+    acc30, acc15 = 100 * (err < 30).float().mean().item(), 100 * (err < 15).float().mean().item()
+    if out_dir is None:
+        out_dir = os.path.join("models", cfg["RUN_NAME"])
+    os.makedirs(out_dir, exist_ok=True)
+    np.savetxt(os.path.join(out_dir, "linemod_pred_Rs_%06d.txt" % clsID), np.asarray(pred_Rs))
+    return err.mean().item(), acc30, acc15
