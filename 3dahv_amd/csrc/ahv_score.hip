@@ -291,13 +291,22 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_wide_kernel
 #ifdef AHV_STAMPS
         unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
-        for (long h = (long)blockIdx.x * 4 + wave; h < N; h += hstep) {
+        long h = (long)blockIdx.x * 4 + wave;
+        float Rn[9];  // rotation of the NEXT hypothesis: its scalar loads fly during the current one
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rn[i] = Rb[(h < N ? h : 0) * 9 + i];
+        for (; h < N; h += hstep) {
 #ifdef AHV_STAMPS
             unsigned long long t0, t1, t2, t3, t4, t5, t6;
 #endif
             float Rm[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];  // wave-uniform -> scalar loads
+            for (int i = 0; i < 9; ++i) Rm[i] = Rn[i];
+            {
+                const long hn = (h + hstep < N) ? h + hstep : h;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rn[i] = Rb[hn * 9 + i];  // wave-uniform -> scalar loads
+            }
 
             f32x16 acc[2];
 #pragma unroll

@@ -100,42 +100,64 @@ __device__ __forceinline__ WideLane make_wide_lane(int lane)
 // ---- gather of one half volume ---------------------------------------------------------
 // 4 passes x 8 corners, flattened into 32 steps; the 4x ds_read_b128 of step s+AHEAD are issued
 // before the 16 FMAs of step s, so the LDS latency hides behind the wave's own arithmetic.
+#ifndef AHV_GATHER_AHEAD
+#define AHV_GATHER_AHEAD 3
+#endif
+
 template <int H>
 __device__ __forceinline__ void gather_half(float* buf, const float* srcT, const float* Rm, const WideLane& L)
 {
-    constexpr int AHEAD = 3;
+    constexpr int AHEAD = AHV_GATHER_AHEAD, RING = AHEAD + 1;
     TriCoef k[4];
-    const float z = L.z0 + 0.5f * H * 2.0f;  // d += 4 per half -> +1.0 in normalised units
+    const float z = L.z0 + (float)H;  // d += 4 per half -> +1.0 in normalised units
 #pragma unroll
     for (int p = 0; p < 4; ++p) tri_coef(k[p], Rm, L.x, L.y[p], z);
-    f32x4 ld[AHEAD + 1][4];
+#ifdef AHV_DIAG_LINEAR_GATHER  // diagnostic only: conflict-free addresses (wrong results) to price bank conflicts
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) k[p].a[n] = (((int)threadIdx.x & 63) + 64 * n) * kSrcStride;
+#endif
+    f32x4 ld[RING][4];
+    // Source order = loads of step s+AHEAD, then the FMAs of step s.  AHV_GATHER_PIN pins that order with
+    // sched_barrier(0); measured slower than letting hipcc re-place the loads (it also hoists the next
+    // half's coordinate math into the GEMM phase), so it is off by default.
+#ifdef AHV_GATHER_PIN
+#define AHV_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AHV_PIN()
+#endif
+    AHV_PIN();
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) {
         const f32x4* row = reinterpret_cast<const f32x4*>(srcT + k[s >> 3].a[s & 7]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ld[s % (AHEAD + 1)][q] = row[q];
+        for (int q = 0; q < 4; ++q) ld[s % RING][q] = row[q];
     }
+    AHV_PIN();
     float out[16];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         if (s + AHEAD < 32) {
             const f32x4* row = reinterpret_cast<const f32x4*>(srcT + k[(s + AHEAD) >> 3].a[(s + AHEAD) & 7]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ld[(s + AHEAD) % (AHEAD + 1)][q] = row[q];
+            for (int q = 0; q < 4; ++q) ld[(s + AHEAD) % RING][q] = row[q];
         }
+        AHV_PIN();
         const float w = k[s >> 3].w[s & 7];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if ((s & 7) == 0) out[4 * q + e] = w * ld[s % (AHEAD + 1)][q][e];
-                else out[4 * q + e] += w * ld[s % (AHEAD + 1)][q][e];
+                if ((s & 7) == 0) out[4 * q + e] = w * ld[s % RING][q][e];
+                else out[4 * q + e] += w * ld[s % RING][q][e];
             }
         if ((s & 7) == 7) {
             float* dst = buf + L.wr[s >> 3];
 #pragma unroll
             for (int c = 0; c < 16; ++c) dst[c * 256] = out[c];
         }
+        AHV_PIN();
     }
 }
 
