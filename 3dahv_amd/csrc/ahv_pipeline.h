@@ -94,7 +94,7 @@ __device__ __forceinline__ void tri_step_axes(TriState& s, const float* Rm, floa
     const float gz = Rm[6] * x + Rm[7] * y + Rm[8] * z;
     axis_coef(gx, s.w0[0], s.w1[0], s.o0[0], s.o1[0], kSrcStride);
     axis_coef(gy, s.w0[1], s.w1[1], s.o0[1], s.o1[1], 8 * kSrcStride);
-    axis_coef(gz, s.w0[2], s.w1[2], s.o0[2], s.o1[2], 64 * kSrcStride);
+    axis_coef(gz, s.w0[2], s.w1[2], s.o0[2], s.o1[2], kSrcPlaneRows * kSrcStride);
 }
 
 __device__ __forceinline__ void tri_step_corners(TriState& s)

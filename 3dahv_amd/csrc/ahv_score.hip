@@ -12,6 +12,7 @@
 // 40 KiB source image + 4 waves x 2 quarter buffers x 8 KiB = 104 KiB.
 #include "ahv_pipeline.h"
 #include "ahv_wide.h"
+#include "ahv_dual.h"
 
 namespace ahv {
 
@@ -352,6 +353,97 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_wide_kernel
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Dual variant: 512 threads = two waves per SIMD, 16x16x4 MFMA, W1 fragments in LDS (ahv_dual.h).
+// ---------------------------------------------------------------------------------------
+constexpr int kDualThreads = 512;
+
+__global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
+    long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int B, long N, float* __restrict__ scores,
+    unsigned long long* __restrict__ best_key)
+{
+    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
+    __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* srcT = lds_src;
+    float* buf = lds_q + wave * kQuarterFloats;
+
+    stage_w1_table(lds_w1, W1, tid, kDualThreads);
+    DualFrags f;
+    load_dual_frags(f, W2, b2, lane);
+    const int n16 = lane & 15, kq = lane >> 4;
+    const long hstep = (long)gridDim.x * 8;
+
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+        f32x4 tg[4][2];
+        {
+            const float* ft = feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tg[t][m2][r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16];
+        }
+        __syncthreads();
+
+        unsigned long long best = 0ull;
+        const float* Rb = R + (long)b * r_batch_stride;
+        long h = (long)blockIdx.x * 8 + wave;
+        float Rn[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rn[i] = Rb[(h < N ? h : 0) * 9 + i];
+        for (; h < N; h += hstep) {
+            float Rm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rn[i];
+            {
+                const long hn = (h + hstep < N) ? h + hstep : h;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rn[i] = Rb[hn * 9 + i];
+            }
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            tri_quarter<0>(buf, srcT, Rm, lane);
+            wave_lds_fence();
+            gemm1_quarter_lds<0>(acc, lds_w1, buf, lane);
+            wave_lds_fence();
+            tri_quarter<1>(buf, srcT, Rm, lane);
+            wave_lds_fence();
+            gemm1_quarter_lds<1>(acc, lds_w1, buf, lane);
+            wave_lds_fence();
+            tri_quarter<2>(buf, srcT, Rm, lane);
+            wave_lds_fence();
+            gemm1_quarter_lds<2>(acc, lds_w1, buf, lane);
+            wave_lds_fence();
+            tri_quarter<3>(buf, srcT, Rm, lane);
+            wave_lds_fence();
+            gemm1_quarter_lds<3>(acc, lds_w1, buf, lane);
+            wave_lds_fence();
+
+            f32x4 v[2][4];
+            gemm2_dual(v, acc, f);
+            const float s = hyp_score(v, tg);
+            if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
+            const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
+            best = key > best ? key : best;
+        }
+        if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
+    }
+}
+
 __global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_key, int B,
                                    float* __restrict__ best_score, long* __restrict__ best_idx)
 {
@@ -367,15 +459,15 @@ __global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_k
 // ---- host-side launchers (called by the C ABI in ahv_abi.hip) ----------------------
 namespace ahv {
 
-int g_score_variant = 2;  // 0 = 16x16x4 phase-sequential, 1 = 16x16x4 micro-step pipelined, 2 = 32x32x2 wide (default)
+int g_score_variant = 3;  // 0 = 16x16x4 phase-sequential, 1 = 16x16x4 micro-step pipelined, 2 = 32x32x2 wide, 3 = dual: 2 waves/SIMD, W1 in LDS (default)
 
 template <typename K>
-static hipError_t launch_score_kernel(K kernel, size_t lds, dim3 grid, hipStream_t stream, const float* vol_src,
+static hipError_t launch_score_kernel(K kernel, size_t lds, dim3 grid, int threads, hipStream_t stream, const float* vol_src,
                                       const float* feat_tgt, const float* R, int64_t r_batch_stride,
                                       int64_t n_offset, const float* W1, const float* W2, const float* b2, int B,
                                       int64_t N, float* scores, uint64_t* best_key)
 {
-    hipLaunchKernelGGL(kernel, grid, dim3(kScoreThreads), lds, stream, vol_src, feat_tgt, R, (long)r_batch_stride,
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, stream, vol_src, feat_tgt, R, (long)r_batch_stride,
                        (long)n_offset, W1, W2, b2, B, (long)N, scores,
                        reinterpret_cast<unsigned long long*>(best_key));
     return hipGetLastError();
@@ -404,13 +496,17 @@ hipError_t launch_score_hypotheses(const float* vol_src, const float* feat_tgt, 
     const int64_t need = (N + 3) / 4;  // workgroups that can get at least one hypothesis per wave
     if (gx > need) gx = (int)need;
     if (gx < 1) gx = 1;
+    const int waves_per_wg = (g_score_variant == 3) ? 8 : 4;
+    const int64_t need_w = (N + waves_per_wg - 1) / waves_per_wg;
+    if (g_score_variant == 3 && gx > need_w) gx = (int)(need_w < 1 ? 1 : need_w);
     const dim3 grid(gx, gy);
-#define AHV_LAUNCH(K, L) \
-    launch_score_kernel(K, L, grid, stream, vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key)
+#define AHV_LAUNCH(K, L, T) \
+    launch_score_kernel(K, L, grid, T, stream, vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key)
     switch (g_score_variant) {
-        case 0: return AHV_LAUNCH(score_hypotheses_kernel, lds);
-        case 1: return AHV_LAUNCH(score_hypotheses_pipelined_kernel, 0);
-        default: return AHV_LAUNCH(score_hypotheses_wide_kernel, 0);
+        case 0: return AHV_LAUNCH(score_hypotheses_kernel, lds, kScoreThreads);
+        case 1: return AHV_LAUNCH(score_hypotheses_pipelined_kernel, 0, kScoreThreads);
+        case 3: return AHV_LAUNCH(score_hypotheses_dual_kernel, 0, kDualThreads);
+        default: return AHV_LAUNCH(score_hypotheses_wide_kernel, 0, kScoreThreads);
     }
 #undef AHV_LAUNCH
 }

@@ -116,7 +116,7 @@ __device__ __forceinline__ void gather_half(float* buf, const float* srcT, const
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) k[p].a[n] = (((int)threadIdx.x & 63) + 64 * n) * kSrcStride;
+        for (int n = 0; n < 8; ++n) k[p].a[n] = (((int)threadIdx.x & 63) + 64 * n) * kSrcStride;  // rows 0..511 < 8 * kSrcPlaneRows
 #endif
     f32x4 ld[RING][4];
     // Source order = loads of step s+AHEAD, then the FMAs of step s.  AHV_GATHER_PIN pins that order with

@@ -186,7 +186,7 @@ def main():
                        "step": "forward_3d2d(tgt) + fused score/argmax + unpack + gather R_pred"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "score_hypotheses_wide_kernel", "kernel_ms": kern_ms,
+                         "kernel": "score_hypotheses_dual_kernel", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
                          "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP},
         }

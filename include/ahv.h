@@ -56,8 +56,9 @@ const char* ahv_last_error(void);
 
 /*
  * Tuning / diagnostic knob (not part of the reference's interface).  Known names:
- *   "score_variant"  fused-scorer kernel: 0 = 16x16x4 MFMA, phase-sequential; 1 = 16x16x4 MFMA,
- *                    micro-step software pipeline; 2 = 32x32x2 MFMA, half-volume phases (default)
+ *   "score_variant"  fused-scorer kernel: 0 = 16x16x4 MFMA, W1 in registers, phase-sequential;
+ *                    1 = same with a micro-step software pipeline; 2 = 32x32x2 MFMA, half-volume phases;
+ *                    3 = two waves per SIMD, 16x16x4 MFMA, W1 fragments in LDS (default)
  * Returns the previous value, or AHV_EINVAL for an unknown name / value.
  */
 int ahv_set_option(const char* name, int value);

@@ -317,7 +317,7 @@ def test_fused_argument_errors(ops, ahv, G):
         ahv._lib.check(rc, "ahv_score_hypotheses_f32")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_fused_kernel_variants_agree(ops, ahv, G, g128, variant):
     """All fused-kernel variants (diagnostic knob) meet the same parity bar."""
     lib = ahv._lib.load()
@@ -326,5 +326,10 @@ def test_fused_kernel_variants_agree(ops, ahv, G, g128, variant):
         scores, val, idx = fused(ops, G, G["R"])
         assert score_relerr(scores.cpu().numpy(), g128["scores"]) < SCORE_RTOL
         assert idx.item() == int(g128["best_idx"][0])
+        g = load_golden("batched")  # B > 1 and per-sample R through every variant
+        vs, vt = to_dev(g["vol_src"], G["R"].device), to_dev(g["vol_tgt"], G["R"].device)
+        ft = ops.forward_3d2d(vt, G["W1"], G["W2"], G["b2"])
+        s2, _ = ops.score_hypotheses(vs, ft, to_dev(g["R_per"], G["R"].device), G["W1"], G["W2"], G["b2"])
+        assert score_relerr(s2.cpu().numpy(), g["scores_per"]) < SCORE_RTOL
     finally:
         lib.ahv_set_option(b"score_variant", prev)
