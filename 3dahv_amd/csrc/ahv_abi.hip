@@ -18,6 +18,10 @@ hipError_t launch_forward_3d2d(const float*, const float*, const float*, const f
                                hipStream_t);
 hipError_t launch_score_features(const float*, const float*, int, int64_t, float*, int, hipStream_t);
 hipError_t launch_argmax(const float*, int, int64_t, int64_t, uint64_t*, int, hipStream_t);
+hipError_t launch_compose_rotations(const uint64_t*, const float*, int64_t, int64_t, int64_t, const float*, int64_t,
+                                    int, float*, hipStream_t);
+hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*,
+                                  int64_t*, hipStream_t);
 extern int g_score_variant;
 }  // namespace ahv
 
@@ -156,6 +160,34 @@ int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_
     if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
     hipError_t e = ahv::launch_score_features(f_src, f_tgt, B, N, scores, cu, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("score_features: launch", e);
+    return AHV_OK;
+}
+
+int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                                 int64_t N, const float* D, int64_t N2, int B, float* out, void* stream)
+{
+    if (B < 0 || N < 0 || N2 < 0) return fail(AHV_EINVAL, "compose_rotations: negative size");
+    if (B == 0 || N2 == 0) return AHV_OK;
+    if (!best_key || !R || !D || !out) return fail(AHV_EINVAL, "compose_rotations: null pointer");
+    if (N == 0) return fail(AHV_EINVAL, "compose_rotations: empty rotation set");
+    if (r_batch_stride != 0 && r_batch_stride < N * 9) return fail(AHV_EINVAL, "compose_rotations: bad r_batch_stride");
+    hipError_t e = ahv::launch_compose_rotations(best_key, R, r_batch_stride, n_offset, N, D, N2, B, out,
+                                                 static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("compose_rotations: launch", e);
+    return AHV_OK;
+}
+
+int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                            int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, void* stream)
+{
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "select_rotation: negative size");
+    if (B == 0) return AHV_OK;
+    if (!best_key) return fail(AHV_EINVAL, "select_rotation: null best_key");
+    if (R_out && (!R || N == 0)) return fail(AHV_EINVAL, "select_rotation: R_out needs a rotation set");
+    if (r_batch_stride != 0 && r_batch_stride < N * 9) return fail(AHV_EINVAL, "select_rotation: bad r_batch_stride");
+    hipError_t e = ahv::launch_select_rotation(best_key, R, r_batch_stride, n_offset, N, B, R_out, best_score,
+                                               best_idx, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("select_rotation: launch", e);
     return AHV_OK;
 }
 

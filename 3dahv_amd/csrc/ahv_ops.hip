@@ -223,6 +223,53 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ s
     if ((threadIdx.x & 63) == 0 && best != 0ull) atomicMax(best_key + b, best);
 }
 
+// ---------------------------------------------------------------------------------
+// Coarse-to-fine support (BASELINE.json configs[4]; build-defined, the reference scores one flat
+// set): refinement hypotheses R_fine[b][n] = R[idx_b] * D[n], where idx_b is decoded on the device from
+// the packed key of the coarse stage and D is a fixed set of small rotations.  Graph-capturable.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compose_rotations_kernel(const unsigned long long* __restrict__ best_key,
+                                                                const float* __restrict__ R, long r_batch_stride,
+                                                                long n_offset, long N, const float* __restrict__ D,
+                                                                long N2, int B, float* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * N2) return;
+    const int b = (int)(i / N2);
+    const long n = i - (long)b * N2;
+    const unsigned long long key = best_key[b];
+    long idx = (long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) - n_offset;
+    idx = (key == 0ull || idx < 0 || idx >= N) ? 0 : idx;  // nothing scored / foreign shard: stay in bounds
+    const float* r = R + (long)b * r_batch_stride + idx * 9;
+    const float* d = D + n * 9;
+    float* o = out + i * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[a * 3 + c] = r[a * 3] * d[c] + r[a * 3 + 1] * d[3 + c] + r[a * 3 + 2] * d[6 + c];
+}
+
+// unpack + gather in one launch: (best score, global index, R_pred = R[idx]) of test_co3d.py:145-146
+__global__ void select_rotation_kernel(const unsigned long long* __restrict__ best_key, const float* __restrict__ R,
+                                       long r_batch_stride, long n_offset, long N, int B,
+                                       float* __restrict__ R_out, float* __restrict__ best_score,
+                                       long* __restrict__ best_idx)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long k = best_key[b];
+    const long gidx = (k == 0ull) ? -1l : (long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    if (best_score) best_score[b] = (k == 0ull) ? -INFINITY : key_score(k);
+    if (best_idx) best_idx[b] = gidx;
+    if (R_out) {
+        const long loc = gidx - n_offset;
+        const bool mine = (k != 0ull) && loc >= 0 && loc < N;  // with sharding only the owner rank holds the row
+        const float* r = R + (long)b * r_batch_stride + (mine ? loc : 0) * 9;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R_out[b * 9 + e] = mine ? r[e] : 0.0f;
+    }
+}
+
 // ---- launchers ----------------------------------------------------------------------
 hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C,
                                 int D, int H, int W, float* out, int num_cu, hipStream_t stream)
@@ -273,6 +320,27 @@ hipError_t launch_score_features(const float* f_src, const float* f_tgt, int B, 
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(score_features_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f_src, f_tgt, B,
                        (long)N, scores);
+    return hipGetLastError();
+}
+
+hipError_t launch_compose_rotations(const uint64_t* best_key, const float* R, int64_t r_batch_stride,
+                                    int64_t n_offset, int64_t N, const float* D, int64_t N2, int B, float* out,
+                                    hipStream_t stream)
+{
+    const long total = (long)B * N2;
+    hipLaunchKernelGGL(compose_rotations_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned long long*>(best_key), R, (long)r_batch_stride,
+                       (long)n_offset, (long)N, D, (long)N2, B, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_rotation(const uint64_t* best_key, const float* R, int64_t r_batch_stride,
+                                  int64_t n_offset, int64_t N, int B, float* R_out, float* best_score,
+                                  int64_t* best_idx, hipStream_t stream)
+{
+    hipLaunchKernelGGL(select_rotation_kernel, dim3((B + 63) / 64), dim3(64), 0, stream,
+                       reinterpret_cast<const unsigned long long*>(best_key), R, (long)r_batch_stride,
+                       (long)n_offset, (long)N, B, R_out, best_score, reinterpret_cast<long*>(best_idx));
     return hipGetLastError();
 }
 

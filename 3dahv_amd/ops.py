@@ -175,3 +175,50 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
                                             scores.data_ptr() if scores is not None else None,
                                             best_key.data_ptr(), flags, _stream()), "ahv_score_hypotheses_f32")
     return scores, best_key
+
+
+def _rot_layout(R: torch.Tensor, B: int):
+    if R.dim() == 3 and tuple(R.shape[1:]) == (3, 3):
+        return R.shape[0], 0
+    if R.dim() == 4 and R.shape[0] == B and tuple(R.shape[2:]) == (3, 3):
+        return R.shape[1], R.shape[1] * 9
+    raise RuntimeError("R must be (N,3,3) or (B,N,3,3), got %s" % (tuple(R.shape),))
+
+
+@torch.no_grad()
+def select_rotation(best_key: torch.Tensor, R: torch.Tensor, n_offset: int = 0):
+    """(best_score (B,), best_idx (B,) global int64, R_pred (B,3,3)) in ONE launch:
+    ``pred_sim, pred_index = torch.max(...)``; ``proposals[pred_index]`` (test_co3d.py:145-146)."""
+    B = best_key.numel()
+    _need_gpu(R)
+    N, rstride = _rot_layout(R, B)
+    Rc = R.detach().contiguous()
+    dev = Rc.device
+    score = torch.empty((B,), dtype=torch.float32, device=dev)
+    idx = torch.empty((B,), dtype=torch.int64, device=dev)
+    R_out = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ahv_select_rotation_f32(best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, B,
+                                           R_out.data_ptr(), score.data_ptr(), idx.data_ptr(), _stream()),
+               "ahv_select_rotation_f32")
+    return score, idx, R_out
+
+
+@torch.no_grad()
+def compose_rotations(best_key: torch.Tensor, R: torch.Tensor, D: torch.Tensor, n_offset: int = 0,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+    """Refinement hypotheses ``out[b, n] = R[idx_b] @ D[n]`` with idx_b decoded from the packed key on the
+    device (coarse-to-fine, BASELINE.json configs[4]).  R (N,3,3) or (B,N,3,3); D (N2,3,3) -> (B,N2,3,3)."""
+    B = best_key.numel()
+    _need_gpu(R, D)
+    N, rstride = _rot_layout(R, B)
+    if D.dim() != 3 or tuple(D.shape[1:]) != (3, 3):
+        raise RuntimeError("D must be (N2,3,3)")
+    N2 = D.shape[0]
+    Rc, Dc = R.detach().contiguous(), D.detach().contiguous()
+    if out is None:
+        out = torch.empty((B, N2, 3, 3), dtype=torch.float32, device=Rc.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_compose_rotations_f32(best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, Dc.data_ptr(),
+                                             N2, B, out.data_ptr(), _stream()), "ahv_compose_rotations_f32")
+    return out

@@ -141,6 +141,25 @@ int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_
 int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key,
                    unsigned flags, void* stream);
 
+/*
+ * Unpack + gather in one launch: best_score[b], best_idx[b] (global index) and
+ * R_out[b] = R[b*r_batch_stride + (idx - n_offset)*9 ...], i.e. the pair
+ * `pred_sim, pred_index = torch.max(...)`; `proposals[pred_index]` of test_co3d.py:145-146.
+ * With N sharded across GPUs only the rank whose slice [n_offset, n_offset+N) holds the
+ * winner writes the row; the others write zeros (sum over ranks = R_pred).  Any output may be NULL.
+ */
+int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                            int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, void* stream);
+
+/*
+ * Coarse-to-fine refinement set, composed on the device (no host round trip, graph-capturable):
+ * out[b][n] = R[idx_b] * D[n] for n < N2, where idx_b is decoded from best_key[b] (minus n_offset)
+ * and D [N2][3][3] is a fixed set of small rotations.  Not in the reference (it scores one flat
+ * set, test_objaverse.py:17); BASELINE.json configs[4].  out [B][N2][3][3].
+ */
+int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                              int64_t N, const float* D, int64_t N2, int B, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
