@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[2..4] on ONE GPU (the headline number is bench.py).
+Prints one JSON object per line; run through gpurun and keep the output under profiles/."""
+import importlib, json, os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+ahv = importlib.import_module("3dahv_amd")
+ops = ahv.ops
+dev = torch.device("cuda:0")
+FLOPS = 1_839_104
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+g = torch.Generator().manual_seed(0)
+W1 = ((torch.rand(32, 384, generator=g) * 2 - 1) / np.sqrt(384.0)).to(dev)
+W2 = ((torch.rand(32, 32, generator=g) * 2 - 1) / np.sqrt(32.0)).to(dev)
+b2 = ((torch.rand(32, generator=g) * 2 - 1) / np.sqrt(32.0)).to(dev)
+vol = (torch.randn(2, 32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
+only = sys.argv[1:]
+
+if not only or "3" in only:
+    # configs[2]: LINEMOD pair, dense SO(3) grid N=200k; fused and op-level (materialising, HBM-bound) pipelines
+    N = 200_000
+    R = torch.from_numpy(ahv.rotations.so3_grid_np(N)).to(dev)
+    vs, vt = vol[0, :1], vol[1, :1]
+    ft = ops.forward_3d2d(vt, W1, W2, b2)
+    ms = timeit(lambda: ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False), 10)
+    print(json.dumps({"config": "3 fused", "N": N, "ms": ms, "hyp_per_s": N / ms * 1e3, "tflops": N * FLOPS / ms / 1e9,
+                      "frac_fp32_mfma_peak": N * FLOPS / ms / 1e9 / 157.3}))
+    src = vs[0][None].expand(N, -1, -1, -1, -1)
+    rot = ops.rotate_volume(src, R)
+    ms_rot = timeit(lambda: ops.rotate_volume(src, R), 5)
+    f = ops.forward_3d2d(rot, W1, W2, b2)
+    ms_f = timeit(lambda: ops.forward_3d2d(rot, W1, W2, b2), 5)
+    fs = f.reshape(1, N, 32, 64)
+    ms_s = timeit(lambda: ops.score_features(fs, ft), 5)
+    sc = ops.score_features(fs, ft)
+    ms_a = timeit(lambda: ops.argmax(sc), 5)
+    s_fused, key = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    assert ops.argmax(sc)[1].item() == ops.unpack_best(key)[1].item()
+    tot = ms_rot + ms_f + ms_s + ms_a
+    print(json.dumps({"config": "3 op-level", "N": N, "ms_total": tot, "hyp_per_s": N / tot * 1e3,
+                      "rotate_volume": {"ms": ms_rot, "GBps": N * 32804 / ms_rot / 1e6},
+                      "forward_3d2d": {"ms": ms_f, "GBps": N * 40960 / ms_f / 1e6, "tflops": N * 1703936 / ms_f / 1e9},
+                      "score_features": {"ms": ms_s, "GBps": N * 8196 / ms_s / 1e6}, "argmax": {"ms": ms_a},
+                      "algorithmic_bytes_per_hyp": 81960, "GBps_pipeline": N * 81960 / tot / 1e6,
+                      "max_abs_diff_vs_fused": (sc - s_fused).abs().max().item()}))
+    del rot, f, fs, src
+
+if not only or "4" in only:
+    # configs[3]: B=32 pairs, shared proposals; one rank's 1/8 shard and the whole set on one GPU
+    vs, vt = vol[0], vol[1]
+    ft = ops.forward_3d2d(vt, W1, W2, b2)
+    for N in (6250, 50_000):
+        R = torch.from_numpy(ahv.rotations.haar_rotations_np(N, 9)).to(dev)
+        ms = timeit(lambda: ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False), 5)
+        print(json.dumps({"config": "4 B=32", "N_per_gpu": N, "ms": ms, "hyp_per_s": 32 * N / ms * 1e3,
+                          "frac_fp32_mfma_peak": 32 * N * FLOPS / ms / 1e9 / 157.3}))
+
+if not only or "5" in only:
+    # configs[4]: coarse 10k + 1k refined hypotheses, the whole verify step replayed from one hipGraph
+    vs, vt = vol[0, :1], vol[1, :1]
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(10_000, 11)).to(dev)
+    for use_graph in (False, True):
+        c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, max_angle_deg=10.0, batch=1, use_graph=use_graph)
+        ms = timeit(lambda: c2f(vs, vt), 200, warm=5)
+        out = c2f(vs, vt)
+        print(json.dumps({"config": "5 coarse10k+fine1k", "graph": use_graph, "us_per_step": ms * 1e3,
+                          "hyp_per_s": 11_000 / ms * 1e3, "fine_score": out[0].item(), "coarse_score": out[3].item()}))
