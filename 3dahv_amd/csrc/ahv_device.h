@@ -150,6 +150,10 @@ __device__ __forceinline__ void tri_coef(TriCoef& k, const float* Rm, float x, f
     const int a00 = oz0 + oy0, a01 = oz0 + oy1, a10 = oz1 + oy0, a11 = oz1 + oy1;
     k.a[0] = a00 + ox0; k.a[1] = a00 + ox1; k.a[2] = a01 + ox0; k.a[3] = a01 + ox1;
     k.a[4] = a10 + ox0; k.a[5] = a10 + ox1; k.a[6] = a11 + ox0; k.a[7] = a11 + ox1;
+#ifdef AHV_DIAG_LINEAR_GATHER  // diagnostic only (wrong results): conflict-free rows, to price LDS bank conflicts
+#pragma unroll
+    for (int n = 0; n < 8; ++n) k.a[n] = (((int)threadIdx.x & 63) + 64 * n) * kSrcStride;
+#endif
 }
 
 // Blend the 16 channels of one output voxel from the LDS source image.

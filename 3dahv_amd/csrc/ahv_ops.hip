@@ -180,6 +180,114 @@ __global__ __launch_bounds__(kF32Threads, 1) void forward_3d2d_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// forward_3d2d for a handful of items (the per-pair target feature, test_co3d.py:141): latency matters,
+// not throughput.  One workgroup per item; wave q contracts quarter q with only the W1 fragments that
+// quarter needs, the four partial accumulators meet in LDS, wave 0 runs ReLU/GEMM2/normalise.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void forward_3d2d_small_kernel(
+    const float* __restrict__ vol, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float qbuf[4][kQuarterFloats];
+    __shared__ __attribute__((aligned(16))) float part[4][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4, i0 = n >> 3, j = n & 7, row = lane & 15;
+    const float* V = vol + (long)blockIdx.x * (16 * 512);
+    float* buf = qbuf[q];
+    {   // quarter q of channel c = 128 contiguous floats at c*512 + q*128
+        const int i = 2 * lane, a0 = i >> 6, bb = (i >> 3) & 7, e = i & 7;
+        const int o0 = qoff(a0, bb, e), o1 = qoff(a0, bb, e + 1);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float2 v = *reinterpret_cast<const float2*>(V + c * 512 + q * 128 + i);
+            buf[c * 128 + o0] = v.x;
+            buf[c * 128 + o1] = v.y;
+        }
+    }
+    wave_lds_fence();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w0 = W1 + row * 384;
+    const float* w1 = W1 + (16 + row) * 384;
+    // x / y slabs land in n-tile q; which tile that is must be a compile-time register index
+#define AHV_XY(T)                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 16; ++c) _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {       \
+        const float bx = buf[c * 128 + qoff(i0, j, 4 * hh + kq)];                                         \
+        acc[0][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c * 8 + 4 * hh + kq], bx, acc[0][T], 0, 0, 0); \
+        acc[1][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c * 8 + 4 * hh + kq], bx, acc[1][T], 0, 0, 0); \
+        const float by = buf[c * 128 + qoff(i0, 4 * hh + kq, j)];                                         \
+        acc[0][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[128 + c * 8 + 4 * hh + kq], by, acc[0][T], 0, 0, 0); \
+        acc[1][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[128 + c * 8 + 4 * hh + kq], by, acc[1][T], 0, 0, 0); \
+    }
+    if (q == 0) { AHV_XY(0) } else if (q == 1) { AHV_XY(1) } else if (q == 2) { AHV_XY(2) } else { AHV_XY(3) }
+#undef AHV_XY
+#pragma unroll
+    for (int cp = 0; cp < 8; ++cp) {
+        const int kz = 256 + (2 * cp + (kq >> 1)) * 8 + 2 * q + (kq & 1);
+        const float a0 = w0[kz], a1 = w1[kz];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float bz = buf[(2 * cp + (kq >> 1)) * 128 + qoff(kq & 1, 2 * t + i0, j)];
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bz, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bz, acc[1][t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part[q][m * 4 + t][lane]) = acc[m][t];
+    __syncthreads();
+    if (q != 0) return;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int w = 1; w < 4; ++w) acc[m][t] += *reinterpret_cast<const f32x4*>(part[w][m * 4 + t][lane]);
+    f32x4 v[2][4];
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+        f32x4 bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = b2[16 * m2 + 4 * kq + r];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[m2][t] = bias;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a20 = W2[row * 32 + 16 * m + 4 * kq + r], a21 = W2[(16 + row) * 32 + 16 * m + 4 * kq + r];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float u = fmaxf(acc[m][t][r], 0.0f);
+                v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, u, v[0][t], 0, 0, 0);
+                v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, u, v[1][t], 0, 0, 0);
+            }
+        }
+    float* o = out + (long)blockIdx.x * (32 * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss += v[m2][t][r] * v[m2][t][r];
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n] = v[m2][t][r] / nrm;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // score (test_co3d.py:143): one wave per (b, n); 8 KiB of f_src streamed per hypothesis.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void score_features_kernel(const float* __restrict__ f_src,
@@ -304,6 +412,10 @@ hipError_t launch_forward_3d2d(const float* vol, const float* W1, const float* W
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_dev = dev;
+    }
+    if (M <= 64) {  // latency path: one workgroup per item, quarters split over its 4 waves
+        hipLaunchKernelGGL(forward_3d2d_small_kernel, dim3((unsigned)M), dim3(256), 0, stream, vol, W1, W2, b2, out);
+        return hipGetLastError();
     }
     long blocks = (M + 3) / 4;
     if (blocks > num_cu) blocks = num_cu;

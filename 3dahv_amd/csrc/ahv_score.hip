@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_kernel(
 #ifdef AHV_STAMPS
 // Diagnostic build only (tools/kbench.cpp): per-wave cycle sums of the loop segments.  The stamps
 // leave the kernel through this buffer alone; no output value depends on them.
-__device__ unsigned long long g_stamps[1024 * 8];
+__device__ unsigned long long g_stamps[2048 * 16];
 #define AHV_STAMP(var)                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_pipelined_k
 #ifdef AHV_STAMPS
         if (lane == 0) {
             const int gw = (blockIdx.x * 4 + wave) & 1023;
-            for (int i = 0; i < 7; ++i) g_stamps[gw * 8 + i] = tsum[i];
+            for (int i = 0; i < 7; ++i) g_stamps[gw * 16 + i] = tsum[i];
         }
 #endif
         if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_wide_kernel
 #ifdef AHV_STAMPS
         if (lane == 0) {
             const int gw = (blockIdx.x * 4 + wave) & 1023;
-            for (int i = 0; i < 7; ++i) g_stamps[gw * 8 + i] = tsum[i];
+            for (int i = 0; i < 7; ++i) g_stamps[gw * 16 + i] = tsum[i];
         }
 #endif
         if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
@@ -395,12 +395,26 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         }
         __syncthreads();
 
+#ifdef AHV_DUAL_STAGGER
+        // Waves 4-7 (the second wave of each SIMD) start late, so that the two waves of a SIMD sit in
+        // complementary phases (one gathers while the other contracts) instead of in lockstep.
+        if (wave >= 4) {
+#pragma unroll
+            for (int i = 0; i < AHV_DUAL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+#endif
         unsigned long long best = 0ull;
         const float* Rb = R + (long)b * r_batch_stride;
-        long h = (long)blockIdx.x * 8 + wave;
+        // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): the last, partial round of
+        // the persistent grid then spreads over ALL CUs with few waves each (a lone wave on a SIMD runs
+        // ~1.6x faster than a pair) instead of filling some CUs completely and leaving the rest idle.
+        long h = (long)wave * gridDim.x + blockIdx.x;
         float Rn[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rn[i] = Rb[(h < N ? h : 0) * 9 + i];
+#ifdef AHV_STAMPS
+        unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
@@ -416,30 +430,57 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef AHV_STAMPS
+            unsigned long long ts[11];
+#define AHV_TS(i) AHV_STAMP(ts[i])
+#else
+#define AHV_TS(i)
+#endif
+            AHV_TS(0)
             tri_quarter<0>(buf, srcT, Rm, lane);
             wave_lds_fence();
+            AHV_TS(1)
             gemm1_quarter_lds<0>(acc, lds_w1, buf, lane);
             wave_lds_fence();
+            AHV_TS(2)
             tri_quarter<1>(buf, srcT, Rm, lane);
             wave_lds_fence();
+            AHV_TS(3)
             gemm1_quarter_lds<1>(acc, lds_w1, buf, lane);
             wave_lds_fence();
+            AHV_TS(4)
             tri_quarter<2>(buf, srcT, Rm, lane);
             wave_lds_fence();
+            AHV_TS(5)
             gemm1_quarter_lds<2>(acc, lds_w1, buf, lane);
             wave_lds_fence();
+            AHV_TS(6)
             tri_quarter<3>(buf, srcT, Rm, lane);
             wave_lds_fence();
+            AHV_TS(7)
             gemm1_quarter_lds<3>(acc, lds_w1, buf, lane);
             wave_lds_fence();
+            AHV_TS(8)
 
             f32x4 v[2][4];
             gemm2_dual(v, acc, f);
+            AHV_TS(9)
             const float s = hyp_score(v, tg);
             if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
             const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
             best = key > best ? key : best;
+            AHV_TS(10)
+#ifdef AHV_STAMPS
+            for (int i = 0; i < 10; ++i) tsum[i] += ts[i + 1] - ts[i];
+            tsum[10] += 1;
+#endif
         }
+#ifdef AHV_STAMPS
+        if (lane == 0) {
+            const int gw = (blockIdx.x * 8 + wave) & 2047;
+            for (int i = 0; i < 11; ++i) g_stamps[gw * 16 + i] = tsum[i];
+        }
+#endif
         if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
     }
 }

@@ -114,9 +114,8 @@ def main():
         if work is not None:
             work.wait()  # stream-level dependency only, the host does not block
             key.bitwise_xor_(adist._SIGN)
-        best, idx = ops.unpack_best(key)
-        loc = (idx - n_offset).clamp(0, N_HYP - 1)  # with sharding the owner rank holds the winning row
-        out["best"], out["idx"], out["R_pred"] = best, idx, R.index_select(0, loc)
+        # unpack + gather in one launch; with sharding the owner rank holds the winning row, the others get zeros
+        out["best"], out["idx"], out["R_pred"] = ops.select_rotation(key, R, n_offset=n_offset)
 
     def step(i, ev=None):
         feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
@@ -191,7 +190,7 @@ def main():
                                    "source volume 16x8x8x8 (P=512 voxel sites x 16 ch), head 384->32->32, 64 positions",
                        "n_hyp_per_gpu": N_HYP, "n_hyp_total": N_HYP * world,
                        "parallelism": "hypothesis axis sharded x%d, 8-byte key all-reduce(max)" % world,
-                       "step": "forward_3d2d(tgt) + fused score/argmax + unpack + gather R_pred"},
+                       "step": "forward_3d2d(tgt) + fused score/argmax + select (unpack + gather R_pred)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "score_hypotheses_dual_kernel", "kernel_ms": kern_ms,

@@ -74,16 +74,16 @@ int main(int argc, char** argv)
         printf("variant %d: max |score - variant0| = %.3g, score[0]=%.6f\n", variant, md, sc[0]);
     }
 #ifdef AHV_STAMPS
-    // stamps belong to the last variant run (2 = wide): gather0, gemm0, gather1, gemm1, gemm2, score
-    std::vector<unsigned long long> st(1024 * 8);
+    // stamps belong to the last variant run (3 = dual): 4 x (gather, gemm1) quarters, gemm2, score+tail
+    std::vector<unsigned long long> st(2048 * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(ahv::g_stamps), st.size() * 8));
-    double sum[7] = {0};
-    for (int w = 0; w < 1024; ++w) for (int i = 0; i < 7; ++i) sum[i] += (double)st[w * 8 + i];
-    const char* names[6] = {"seg0", "seg1", "seg2", "seg3", "gemm2", "score+tail"};
+    double sum[11] = {0};
+    for (int w = 0; w < 2048; ++w) for (int i = 0; i < 11; ++i) sum[i] += (double)st[w * 16 + i];
+    const char* names[10] = {"gather0", "gemm0", "gather1", "gemm1", "gather2", "gemm2q", "gather3", "gemm3", "gemm2", "score+tail"};
     double tot = 0;
-    for (int i = 0; i < 6; ++i) tot += sum[i] / sum[6];
-    for (int i = 0; i < 6; ++i) printf("  %-10s %8.0f cycles/hyp (%.1f%%)\n", names[i], sum[i] / sum[6], 100 * sum[i] / sum[6] / tot);
-    printf("  total      %8.0f cycles/hyp (s_memtime ticks), rounds/wave %.1f\n", tot, sum[6] / 1024);
+    for (int i = 0; i < 10; ++i) tot += sum[i] / sum[10];
+    for (int i = 0; i < 10; ++i) printf("  %-10s %8.0f ticks/hyp (%.1f%%)\n", names[i], sum[i] / sum[10], 100 * sum[i] / sum[10] / tot);
+    printf("  total      %8.0f ticks/hyp per wave (two waves share a SIMD), rounds/wave %.1f\n", tot, sum[10] / 2048);
 #endif
     return 0;
 }
