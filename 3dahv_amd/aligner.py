@@ -217,6 +217,38 @@ class Feature_Aligner(nn.Module):
             raise NotImplementedError("the HIP head is built for out_channel=32 (the reference's only value)")
         return ops.forward_3d2d(img_feat, *self.head_weights())
 
+    # ---- once-per-pair encoder replayed from a hipGraph -------------------------------------------
+    def graphed_forward_2d3d(self, batch: int = 1):
+        """Returns ``fn(layer4_src, layer4_tgt) -> (vol_src, vol_tgt)`` that replays ``forward_2d3d``
+        (inference form: no masking) from ONE captured hipGraph.  The encoder is ~250 small kernels on 64
+        tokens; at B = 1 their launch gaps dominate, so replaying a graph (static shapes, static buffers)
+        is the MI355X-native way to run it until it gets fused kernels of its own.  The returned volumes
+        are static buffers, overwritten by the next call."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("graph capture needs the GPU")
+        xs = torch.zeros(batch, self.in_channel, 8, 8, device=dev)
+        xt = torch.zeros_like(xs)
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up: lazy library initialisation must not be captured
+                    self.forward_2d3d(xs, xt, random_mask=False, mask_ratio=0.0)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.forward_2d3d(xs, xt, random_mask=False, mask_ratio=0.0)
+
+        def run(layer4_src, layer4_tgt):
+            xs.copy_(layer4_src)
+            xt.copy_(layer4_tgt)
+            graph.replay()
+            return out
+
+        run.graph = graph
+        return run
+
     # ---- fused entry point (not in the reference: its call sites inline these three steps) ----
     def score_hypotheses(self, img_feat_src, img_feat_tgt, proposals, n_offset: int = 0, want_scores: bool = True):
         """rotate_volume + forward_3d2d + score + running arg-max for every proposal in ONE launch

@@ -143,3 +143,17 @@ def test_patched_reference_callables_run_on_hip(ahv, dev, g128):
         ahv.patch.uninstall()
     assert pred_index.item() == int(g128["best_idx"][0])
     assert abs(pred_sim.item() - float(g128["best"][0])) < 1e-5
+
+
+def test_graphed_encoder_matches_eager(ahv, dev):
+    torch.manual_seed(5)
+    fa = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).to(dev).eval()
+    run = fa.graphed_forward_2d3d(batch=1)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(2):
+        a, b = torch.randn(1, 768, 8, 8, generator=g).to(dev), torch.randn(1, 768, 8, 8, generator=g).to(dev)
+        with torch.no_grad():
+            ref = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+        got = run(a, b)
+        for x, y in zip(got, ref):
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-5)

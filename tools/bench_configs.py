@@ -80,3 +80,15 @@ if not only or "5" in only:
         out = c2f(vs, vt)
         print(json.dumps({"config": "5 coarse10k+fine1k", "graph": use_graph, "us_per_step": ms * 1e3,
                           "hyp_per_s": 11_000 / ms * 1e3, "fine_score": out[0].item(), "coarse_score": out[3].item()}))
+
+if not only or "enc" in only:
+    # once-per-pair encoder (forward_2d3d), stock PyTorch-ROCm operators: eager vs one hipGraph replay
+    torch.manual_seed(0)
+    fa = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).to(dev).eval()
+    a, b = torch.randn(1, 768, 8, 8, device=dev), torch.randn(1, 768, 8, 8, device=dev)
+    with torch.no_grad():
+        ms_eager = timeit(lambda: fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0), 30)
+    run = fa.graphed_forward_2d3d(1)
+    ms_graph = timeit(lambda: run(a, b), 100)
+    print(json.dumps({"config": "encoder forward_2d3d B=1", "eager_us": ms_eager * 1e3, "hipgraph_us": ms_graph * 1e3,
+                      "weights_MB": sum(p.numel() for p in fa.parameters()) * 4 / 1e6}))
