@@ -37,6 +37,16 @@ SIGNATURES = {
     "ahv_compose_rotations_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp]),
 }
 
+class BlockWeights(ctypes.Structure):
+    """Mirror of ``ahv_block_weights`` (include/ahv.h)."""
+    _fields_ = [(n, _vp) for n in ("w_qkv", "w_out", "b_out", "ln1_g", "ln1_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
+                                   "ln2_g", "ln2_b")]
+
+
+SIGNATURES["ahv_transformer_workspace_bytes"] = (ctypes.c_size_t, [_int])
+SIGNATURES["ahv_transformer_blocks_f32"] = (_int, [ctypes.POINTER(BlockWeights), _int, _vp, _vp, _int, _vp,
+                                                   ctypes.c_size_t, _vp])
+
 _lib = None
 
 

@@ -13,12 +13,17 @@ with ``load_state_dict``.
 from __future__ import annotations
 
 import math
+import weakref
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+
+
+# packed ahv_block_weights tables, kept outside the modules so that they are neither pickled nor deep-copied
+_PACKED = weakref.WeakKeyDictionary()
 
 
 # ----------------------------------------------------------------------------- encoder pieces
@@ -119,14 +124,68 @@ class BidirectionTransformer(nn.Module):
         self.proj_out = nn.Conv2d(inner, in_channels, 1)
         self.proj_context_out = nn.Conv2d(inner, in_channels, 1)
 
+        self.inner_dim, self.n_heads, self.d_head = inner, n_heads, d_head
+        self.use_hip = True  # token stage on the HIP kernels when the tensors are on the GPU
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    # ---- HIP token stage (csrc/ahv_encoder.hip) -------------------------------------------------
+    def invalidate_packed(self):
+        """Drop the packed weight table (call after changing parameters in place)."""
+        _PACKED.pop(self, None)
+
+    def _hip_eligible(self, xs):
+        return (self.use_hip and xs.is_cuda and xs.dtype == torch.float32 and self.inner_dim == 256
+                and self.n_heads == 4 and self.d_head == 64 and xs.shape[1] == 64 and not torch.is_grad_enabled())
+
+    def _pack(self, device):
+        """ahv_block_weights table: per layer attn_self_1, attn_self_2, attn_cross_1, attn_cross_2; q|k|v
+        weights concatenated to one [768][256] matrix (one GEMM for self-attention, row slices for cross)."""
+        from . import _lib
+        keep, table = [], (_lib.BlockWeights * (4 * len(self.transformer_blocks)))()
+        i = 0
+        for layer in self.transformer_blocks:
+            for blk in (layer.attn_self_1, layer.attn_self_2, layer.attn_cross_1, layer.attn_cross_2):
+                a, ff = blk.attn, blk.ff
+                tensors = dict(
+                    w_qkv=torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dim=0),
+                    w_out=a.to_out[0].weight, b_out=a.to_out[0].bias, ln1_g=blk.norm1.weight, ln1_b=blk.norm1.bias,
+                    w_ff1=ff.net[0].proj.weight, b_ff1=ff.net[0].proj.bias, w_ff2=ff.net[2].weight,
+                    b_ff2=ff.net[2].bias, ln2_g=blk.norm2.weight, ln2_b=blk.norm2.bias)
+                for name, t in tensors.items():
+                    t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+                    keep.append(t)
+                    setattr(table[i], name, t.data_ptr())
+                i += 1
+        _PACKED[self] = (table, keep, device)
+        return _PACKED[self]
+
+    def _hip_blocks(self, xs, cs):
+        from . import _lib
+        packed = _PACKED.get(self)
+        if packed is None or packed[2] != xs.device:
+            packed = self._pack(xs.device)
+        table = packed[0]
+        B = xs.shape[0]
+        xs, cs = xs.contiguous().clone(), cs.contiguous().clone()  # the kernels update the streams in place
+        lib = _lib.load()
+        nbytes = lib.ahv_transformer_workspace_bytes(B)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=xs.device)
+        _lib.check(lib.ahv_transformer_blocks_f32(table, len(self.transformer_blocks), xs.data_ptr(), cs.data_ptr(), B,
+                                                  ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+                   "ahv_transformer_blocks_f32")
+        return xs, cs
+
     def forward(self, x, context):
         b, _, h, w = x.shape
         tok = lambda t: t.flatten(2).transpose(1, 2)                      # (B, hw, C)
         img = lambda t, hh, ww: t.transpose(1, 2).reshape(b, -1, hh, ww)  # back to (B, C, h, w)
         xs = tok(self.proj_in(self.norm(x)))
         cs = tok(self.proj_context_in(self.norm(context)))
-        for blk in self.transformer_blocks:
-            xs, cs = blk(xs, cs)
+        if self._hip_eligible(xs):
+            xs, cs = self._hip_blocks(xs, cs)
+        else:  # other widths (test fixtures), autograd, CPU tensors: stock torch operators
+            for blk in self.transformer_blocks:
+                xs, cs = blk(xs, cs)
         hc, wc = context.shape[-2:]
         return self.proj_out(img(xs, h, w)) + x, self.proj_context_out(img(cs, hc, wc)) + context
 

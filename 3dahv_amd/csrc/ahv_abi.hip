@@ -23,6 +23,8 @@ hipError_t launch_compose_rotations(const uint64_t*, const float*, int64_t, int6
 hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*,
                                   int64_t*, hipStream_t);
 extern int g_score_variant;
+size_t transformer_workspace_floats(int B);
+int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
 }  // namespace ahv
 
 namespace {
@@ -188,6 +190,33 @@ int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_
     hipError_t e = ahv::launch_select_rotation(best_key, R, r_batch_stride, n_offset, N, B, R_out, best_score,
                                                best_idx, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("select_rotation: launch", e);
+    return AHV_OK;
+}
+
+size_t ahv_transformer_workspace_bytes(int B) { return sizeof(float) * ahv::transformer_workspace_floats(B); }
+
+int ahv_transformer_blocks_f32(const ahv_block_weights* blocks, int depth, float* x_src, float* x_tgt, int B,
+                               void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (depth < 0 || B < 0) return fail(AHV_EINVAL, "transformer_blocks: negative size");
+    if (depth == 0 || B == 0) return AHV_OK;
+    if (!blocks || !x_src || !x_tgt || !workspace) return fail(AHV_EINVAL, "transformer_blocks: null pointer");
+    if (workspace_bytes < ahv_transformer_workspace_bytes(B))
+        return fail(AHV_EINVAL, "transformer_blocks: workspace of %zu bytes, need %zu", workspace_bytes,
+                    ahv_transformer_workspace_bytes(B));
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(x_src) & 15) ||
+        (reinterpret_cast<uintptr_t>(x_tgt) & 15))
+        return fail(AHV_EINVAL, "transformer_blocks: buffers must be 16-byte aligned");
+    for (int i = 0; i < 4 * depth; ++i) {
+        const ahv_block_weights& w = blocks[i];
+        if (!w.w_qkv || !w.w_out || !w.b_out || !w.ln1_g || !w.ln1_b || !w.w_ff1 || !w.b_ff1 || !w.w_ff2 || !w.b_ff2 ||
+            !w.ln2_g || !w.ln2_b)
+            return fail(AHV_EINVAL, "transformer_blocks: null weight pointer in block %d", i);
+    }
+    const char* what = "";
+    const int rc = ahv::transformer_blocks(blocks, depth, x_src, x_tgt, B, static_cast<float*>(workspace),
+                                           static_cast<hipStream_t>(stream), &what);
+    if (rc != 0) return fail(AHV_ELAUNCH, "transformer_blocks: %s: %s", what, hipGetErrorString((hipError_t)rc));
     return AHV_OK;
 }
 

@@ -160,6 +160,40 @@ int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_
 int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
                               int64_t N, const float* D, int64_t N2, int B, float* out, void* stream);
 
+/*
+ * Weights of one BasicTransformerBlock of the reference's encoder (transformer/attention.py:240-258),
+ * device pointers, fp32, torch layouts (Linear weight = [out][in]).  State-dict names in comments.
+ */
+typedef struct ahv_block_weights {
+    const float* w_qkv;  /* [768][256] = cat(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight) (no bias) */
+    const float* w_out;  /* [256][256]  attn.to_out.0.weight */
+    const float* b_out;  /* [256]       attn.to_out.0.bias   */
+    const float* ln1_g;  /* [256]       norm1.weight */
+    const float* ln1_b;  /* [256]       norm1.bias   */
+    const float* w_ff1;  /* [4096][512] ff.net.0.proj.weight (GEGLU: value half, then gate half) */
+    const float* b_ff1;  /* [4096]      ff.net.0.proj.bias   */
+    const float* w_ff2;  /* [256][2048] ff.net.2.weight */
+    const float* b_ff2;  /* [256]       ff.net.2.bias   */
+    const float* ln2_g;  /* [256]       norm2.weight */
+    const float* ln2_b;  /* [256]       norm2.bias   */
+} ahv_block_weights;
+
+/* Workspace (bytes, device memory) that ahv_transformer_blocks_f32 needs for B sample pairs. */
+size_t ahv_transformer_workspace_bytes(int B);
+
+/*
+ * The token stage of the reference's "3D-aware encoder": `depth` BidirectionTransformerBlocks
+ * (transformer/attention.py:260-274, the loop at :386-387) applied IN PLACE to the two token streams
+ * x_src, x_tgt [B][64][256] (already GroupNorm'ed + proj_in'ed, :378-384).  blocks is a HOST array of
+ * 4*depth entries in the order attn_self_1, attn_self_2, attn_cross_1, attn_cross_2 per layer.
+ * Per layer: x = self_1(x); ctx = self_2(ctx); x, ctx = cross_1(x, ctx), cross_2(ctx, x), where a block is
+ *   m = LN1(attn(x, ctx)); m = LN2(FF(cat[x, m])); x + m,   attn = 4 heads x 64, softmax(QK^T/8)V,
+ *   FF = Linear(512 -> 2*2048) GEGLU (exact erf GELU) Linear(2048 -> 256).
+ * Built for dim 256 / 4 heads / 64 tokens (the reference's only configuration).
+ */
+int ahv_transformer_blocks_f32(const ahv_block_weights* blocks, int depth, float* x_src, float* x_tgt, int B,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

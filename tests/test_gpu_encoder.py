@@ -1,0 +1,75 @@
+"""HIP token stage of the 3D-aware encoder (csrc/ahv_encoder.hip) against the stock-torch operator path of
+the host mirror -- itself pinned to the reference by the encoder_small fixture (tests/test_aligner_cpu.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa(ahv):
+    torch.manual_seed(0)
+    m = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).cuda().eval()
+    return m
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_transformer_blocks_match_torch_ops(fa, B):
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 256, 8, 8, generator=g).cuda()
+    c = torch.randn(B, 256, 8, 8, generator=g).cuda()
+    with torch.no_grad():
+        fa.att.use_hip = False
+        ref_x, ref_c = fa.att(x, c)
+        fa.att.use_hip = True
+        got_x, got_c = fa.att(x, c)
+    assert rel(got_x, ref_x) < 2e-5 and rel(got_c, ref_c) < 2e-5
+
+
+def test_single_block_and_attention_against_modules(ahv, fa):
+    """depth-1 slice: isolates one BidirectionTransformerBlock."""
+    import copy
+    att1 = copy.deepcopy(fa.att)
+    att1.transformer_blocks = torch.nn.ModuleList([att1.transformer_blocks[2]])
+    att1.invalidate_packed()
+    g = torch.Generator().manual_seed(9)
+    xs, cs = torch.randn(2, 64, 256, generator=g).cuda(), torch.randn(2, 64, 256, generator=g).cuda()
+    with torch.no_grad():
+        rx, rc = att1.transformer_blocks[0](xs, cs)
+        gx, gc = att1._hip_blocks(xs, cs)
+    assert rel(gx, rx) < 1e-5 and rel(gc, rc) < 1e-5
+    assert torch.equal(xs, xs.clone())  # inputs untouched (the kernels work on copies)
+
+
+def test_forward_2d3d_hip_vs_torch_and_graph(fa):
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.randn(1, 768, 8, 8, generator=g).cuda(), torch.randn(1, 768, 8, 8, generator=g).cuda()
+    with torch.no_grad():
+        fa.att.use_hip = False
+        ref = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+        fa.att.use_hip = True
+        got = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+    for x, y in zip(got, ref):
+        assert rel(x, y) < 2e-5
+    run = fa.graphed_forward_2d3d(batch=1)  # the HIP launches are captured into the hipGraph too
+    out = run(a, b)
+    for x, y in zip(out, ref):
+        assert rel(x, y) < 2e-5
+
+
+def test_state_dict_reload_invalidates_packed_weights(fa):
+    import copy
+    m = copy.deepcopy(fa)
+    x = torch.randn(1, 256, 8, 8, device="cuda")
+    with torch.no_grad():
+        y0, _ = m.att(x, x)
+        sd = {k: (v * 1.01 if "ff.net.2.weight" in k else v) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        y1, _ = m.att(x, x)
+        m.att.use_hip = False
+        y2, _ = m.att(x, x)
+    assert rel(y1, y2) < 2e-5 and rel(y0, y2) > 1e-4
