@@ -1,12 +1,17 @@
 // ahv_encoder.hip -- HIP kernels for the transformer blocks of the reference's "3D-aware encoder"
 // (transformer/attention.py: BasicTransformerBlock :240-258, CrossAttention :196-237, FeedForward/GEGLU
 // :81-108, BidirectionTransformerBlock :260-274).  Once per image pair; 64 tokens x 256 channels per
-// stream, so every GEMM is "skinny" (M = 64*B rows) and its cost is streaming the weights once.
+// stream, so every GEMM is "skinny" (M = 64*B rows): its cost is streaming the weights once and the
+// launch count.  The two streams of a layer (self_1 | self_2, then cross_1 | cross_2) are independent, so
+// every launch carries BOTH blocks (and, for cross-attention, both the q and the k|v projections) as
+// separate "problems": 7 launches per half layer, 56 for the whole depth-4 encoder.
 //
-//   linear_partial_kernel   P[ks][M][N] = X[M][K-slice ks] . W[N][K-slice]^T     fp32 MFMA 16x16x4, split-K
-//   attention_kernel        softmax(Q K^T / 8) V for one (sample, head) per wave, scores kept transposed
-//                           so that softmax runs down registers and P feeds the second MFMA in place
-//   finish_*_kernel         sum of split-K slabs + bias, fused with LayerNorm / residual / GEGLU / concat
+//   linear_kernel       P[ks][M][N] = X[M][K-slice ks] . W[N][K-slice]^T   fp32 MFMA 16x16x4, split-K,
+//                       up to 4 problems per launch; the X staging can apply GEGLU on the fly
+//   attention_kernel    softmax(Q K^T / 8) V, one wave per (sample, head, 16 queries); scores are kept
+//                       transposed so that softmax runs down registers and P feeds the 2nd MFMA in place
+//   ln1_concat_kernel   cat[row] = [x[row], LayerNorm(sum_ks P + bias)]          (attention.py:255-256)
+//   ln2_residual_kernel out[row] = x[row] + LayerNorm(sum_ks P + bias)           (attention.py:257-258)
 //
 // fp32 throughout (the reference runs set_float32_matmul_precision("highest")).
 #include <hip/hip_runtime.h>
@@ -18,71 +23,108 @@ namespace ahv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kMaxProb = 4;
+
+struct LinProb {
+    const float* X;     // [M][ldx]  (GEGLU mode: the [M][2H] slab of the previous linear)
+    const float* W;     // [N][ldw]
+    float* P;           // [KS][M][N]
+    const float* bias;  // GEGLU mode: bias of the previous linear [2H]
+    int N;
+    int tile0;          // first n-tile (of 16*NT columns) of this problem in blockIdx.x
+};
+
+struct LinArgs {
+    LinProb p[kMaxProb];
+    int nprob, M, Kc;
+    long ldx, ldw;
+    int geglu_h;  // 0: plain X;  H > 0: X[r][k] = (h[r][k] + b[k]) * gelu(h[r][H + k] + b[H + k])
+};
+
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+
 // -------------------------------------------------------------------------------------------------
-// Skinny linear.  grid = (N / (16*NT), KS, M / 64); 256 threads.  The workgroup owns 64 rows x 16*NT
-// columns and the K range [ks*Kc, (ks+1)*Kc); its 4 waves split that range (each streams its own part of
-// the W rows exactly once from HBM), stage their X slice in LDS, and meet in LDS at the end.
+// Skinny linear.  grid = (sum of n-tiles, KS, M / 64); 256 threads.  The workgroup owns 64 rows x 16*NT
+// columns and the K range [ks*Kc, (ks+1)*Kc); its 4 waves split that range (each streams its own part
+// of the W rows exactly once), stage their X slice in LDS and meet in LDS at the end.  All W operands of a
+// wave (<= 8 float4 per n-tile) are requested up front, so HBM latency is paid once, not per k-step.
 // k ordering inside a 16-wide step: MFMA k-step s, lane group kq <-> column k0 + 4*kq + s, so that both
 // operands are one aligned float4 per lane.
 // -------------------------------------------------------------------------------------------------
-constexpr int kLinMaxKw = 128;            // K columns per wave
-constexpr int kLinLdx = kLinMaxKw + 4;    // +4 floats: ds_read_b128 of 16 rows hits 16 distinct slots
+constexpr int kLinMaxKw = 128;          // K columns per wave
+constexpr int kLinLdx = kLinMaxKw + 4;  // +4 floats: ds_read_b128 of 16 rows hits 16 distinct slots
 
 template <int NT>
-__global__ __launch_bounds__(256) void linear_partial_kernel(const float* __restrict__ X, long ldx,
-                                                             const float* __restrict__ W, long ldw,
-                                                             float* __restrict__ P, int M, int N, int Kc)
+__global__ __launch_bounds__(256) void linear_kernel(const LinArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * 16 * NT;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxProb; ++i)
+        if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile0) pi = i;
+    const LinProb pr = a.p[pi];
+    const int n0 = ((int)blockIdx.x - pr.tile0) * 16 * NT;
     const int ks = blockIdx.y;
     const int m0 = blockIdx.z * 64;
-    const int Kw = Kc >> 2;
-    const int kbase = ks * Kc + wave * Kw;
-    float* Xs = lds + wave * (64 * kLinLdx);
+    const int Kw = a.Kc >> 2;
+    const int kbase = ks * a.Kc + wave * Kw;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // request every W operand of this wave now
+    f32x4 b[8][NT];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (it * 16 < Kw)
+                b[it][nt] = *reinterpret_cast<const f32x4*>(pr.W + (long)(n0 + nt * 16 + r16) * a.ldw + kbase + 16 * it + 4 * kq);
+
     // stage X[m0..m0+63][kbase..kbase+Kw) -> Xs[row][k]
+    float* Xs = lds + wave * (64 * kLinLdx);
     {
         const int q4 = Kw >> 2;  // float4 per row
+        const int H = a.geglu_h;
         for (int i = lane; i < 64 * q4; i += 64) {
             const int r = i / q4, c = i - r * q4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (long)(m0 + r) * ldx + kbase + 4 * c);
+            const float* src = pr.X + (long)(m0 + r) * a.ldx + kbase + 4 * c;
+            f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            if (H > 0) {
+                f32x4 g = *reinterpret_cast<const f32x4*>(src + H);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(pr.bias + kbase + 4 * c);
+                const f32x4 bg = *reinterpret_cast<const f32x4*>(pr.bias + H + kbase + 4 * c);
+                v += bv;
+                g += bg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf(g[e]);
+            }
             *reinterpret_cast<f32x4*>(Xs + r * kLinLdx + 4 * c) = v;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     asm volatile("" ::: "memory");
-    const int r16 = lane & 15, kq = lane >> 4;
+
     f32x4 acc[4][NT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wrow[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n0 + nt * 16 + r16) * ldw + kbase + 4 * kq;
-    f32x4 bnext[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bnext[nt] = *reinterpret_cast<const f32x4*>(wrow[nt]);
-    for (int k = 0; k < Kw; k += 16) {
-        f32x4 b[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = bnext[nt];
-        if (k + 16 < Kw) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bnext[nt] = *reinterpret_cast<const f32x4*>(wrow[nt] + k + 16);
-        }
-        f32x4 a[4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(Xs + (rt * 16 + r16) * kLinLdx + k + 4 * kq);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
+    for (int it = 0; it < 8; ++it) {
+        if (it * 16 < Kw) {
+            f32x4 x[4];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
+                x[rt] = *reinterpret_cast<const f32x4*>(Xs + (rt * 16 + r16) * kLinLdx + 16 * it + 4 * kq);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], b[nt][s], acc[rt][nt], 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], b[it][nt][s], acc[rt][nt], 0, 0, 0);
+        }
     }
     // cross-wave reduction through LDS (re-using the X staging area), then one coalesced store
     __syncthreads();
@@ -95,112 +137,109 @@ __global__ __launch_bounds__(256) void linear_partial_kernel(const float* __rest
             for (int r = 0; r < 4; ++r)
                 red[(wave * 64 + rt * 16 + 4 * kq + r) * (16 * NT) + nt * 16 + r16] = acc[rt][nt][r];
     __syncthreads();
-    float* out = P + ((long)ks * M + m0) * N + n0;
+    float* out = pr.P + ((long)ks * a.M + m0) * pr.N + n0;
     for (int i = tid; i < 64 * 16 * NT; i += 256) {
         const int r = i / (16 * NT), c = i - r * (16 * NT);
         const float v = red[i] + red[i + 64 * 16 * NT] + red[i + 2 * 64 * 16 * NT] + red[i + 3 * 64 * 16 * NT];
-        out[(long)r * N + c] = v;
+        out[(long)r * pr.N + c] = v;
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// Attention for 64 queries x 64 keys x 64 head dims: one wave per (sample, head).
-// S^T[j][i] = sum_d K[j][d] Q[i][d]   (keys on rows/registers, queries on lanes)
-// softmax over j = down the registers (+ lane groups l^16, l^32);  O^T[d][i] = sum_j V[j][d] P^T[j][i],
-// whose B operand is the S^T accumulator itself.
+// Attention, 64 keys x 64 head dims; grid = (B * nprob, heads), wave = 16 queries.
+// S^T[j][i] = sum_d K[j][d] Q[i][d]  (keys on rows/registers, queries on lanes);  softmax over j runs
+// down the registers (+ lane groups l^16, l^32);  O^T[d][i] = sum_j V[j][d] P^T[j][i], whose B operand
+// is the S^T accumulator itself.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ Q, long ldq,
-                                                        const float* __restrict__ K, long ldk,
-                                                        const float* __restrict__ V, long ldv,
-                                                        float* __restrict__ O, long ldo, int heads, float scale)
+struct AttnProb {
+    const float *Q, *K, *V;
+    float* O;
+    long ldq, ldkv;
+};
+struct AttnArgs {
+    AttnProb p[2];
+    int B;  // samples per problem
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int h = threadIdx.x >> 6;  // blockDim = 64 * heads
-    const int b = blockIdx.x;
+    const int it = threadIdx.x >> 6;  // query tile of this wave
+    const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
+    const AttnProb pr = a.p[pi];
+    const int h = blockIdx.y;
     const int c16 = lane & 15, kq = lane >> 4;
-    const float* q = Q + (long)b * 64 * ldq + h * 64;
-    const float* k = K + (long)b * 64 * ldk + h * 64;
-    const float* v = V + (long)b * 64 * ldv + h * 64;
-    f32x4 st[4][4];  // [jt][it]
+    const float* q = pr.Q + (long)b * 64 * pr.ldq + h * 64 + (long)(it * 16 + c16) * pr.ldq + 4 * kq;
+    const float* k = pr.K + (long)b * 64 * pr.ldkv + h * 64 + (long)c16 * pr.ldkv + 4 * kq;
+    const float* v = pr.V + (long)b * 64 * pr.ldkv + h * 64 + c16;
+    // every operand is requested before the first MFMA
+    f32x4 ka[4][4], qb[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+        qb[ds] = *reinterpret_cast<const f32x4*>(q + 16 * ds);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ka[ds][jt] = *reinterpret_cast<const f32x4*>(k + (long)(jt * 16) * pr.ldkv + 16 * ds);
+    }
+    float va[4][4][4];  // [jt][r][dt]: V[jt*16 + 4kq + r][dt*16 + c16]
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) st[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int d0 = 0; d0 < 64; d0 += 16) {
-        f32x4 ka[4], qb[4];
+            for (int dt = 0; dt < 4; ++dt) va[jt][r][dt] = v[(long)(jt * 16 + 4 * kq + r) * pr.ldkv + dt * 16];
+    f32x4 st[4];  // [jt]
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            ka[t] = *reinterpret_cast<const f32x4*>(k + (long)(t * 16 + c16) * ldk + d0 + 4 * kq);
-            qb[t] = *reinterpret_cast<const f32x4*>(q + (long)(t * 16 + c16) * ldq + d0 + 4 * kq);
-        }
+    for (int jt = 0; jt < 4; ++jt) st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    st[jt][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[jt][s], qb[it][s], st[jt][it], 0, 0, 0);
-    }
-    // softmax over keys (rows) for each query column i = it*16 + c16
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[jt][it][r] *= scale;
-                m = fmaxf(m, st[jt][it][r]);
-            }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.0f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = expf(st[jt][it][r] - m);
-                st[jt][it][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st[jt][it][r] *= inv;
-    }
-    // O^T[d][i]: k-step (jt, r) has k-values j = jt*16 + 4*kq + r
-    f32x4 ot[4][4];  // [dt][it]
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) ot[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                st[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][jt][s], qb[ds][s], st[jt], 0, 0, 0);
+    // softmax over the 64 keys of query column i = it*16 + c16
+    float m = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float va[4];
+            st[jt][r] *= a.scale;
+            m = fmaxf(m, st[jt][r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) va[dt] = v[(long)(jt * 16 + 4 * kq + r) * ldv + dt * 16 + c16];
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = expf(st[jt][r] - m);
+            st[jt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    f32x4 ot[4];  // [dt]
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = st[jt][r] * inv;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    ot[dt][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[dt], st[jt][it][r], ot[dt][it], 0, 0, 0);
+                ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[jt][r][dt], p, ot[dt], 0, 0, 0);
         }
-    float* o = O + (long)b * 64 * ldo + h * 64;
+    float* o = pr.O + (long)b * 64 * 256 + h * 64 + (long)(it * 16 + c16) * 256 + 4 * kq;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<f32x4*>(o + (long)(it * 16 + c16) * ldo + dt * 16 + 4 * kq) = ot[dt][it];
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + dt * 16) = ot[dt];
 }
 
 // -------------------------------------------------------------------------------------------------
-// Finish kernels: one wave per row.
+// Row kernels (one wave per 256-wide row; blockIdx.y = problem).
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float x)
 {
@@ -209,146 +248,161 @@ __device__ __forceinline__ float wave_sum(float x)
     return x;
 }
 
-// y = LayerNorm(sum_ks P[ks][row][:] + bias) * g + be   (256 columns, eps 1e-5, biased variance);
-// RESIDUAL: out[row][0:256] = res[row] + y        (BasicTransformerBlock :258)
-// else    : out[row][col_off : col_off+256] = y    (the "message" half of cat([x, m]), :256)
-template <bool RESIDUAL>
-__global__ __launch_bounds__(256) void finish_ln_kernel(const float* __restrict__ P, int KS, int M,
-                                                        const float* __restrict__ bias,
-                                                        const float* __restrict__ g, const float* __restrict__ be,
-                                                        const float* __restrict__ res, long ldres,
-                                                        float* __restrict__ out, long ldo, int col_off)
+struct LnProb {
+    const float* P;     // [KS][M][256] split-K slabs of the preceding linear
+    const float* bias;  // [256]
+    const float* g;     // LayerNorm weight
+    const float* be;    // LayerNorm bias
+    const float* x;     // [M][256] block input (copied into cat / added as residual)
+    float* out;         // CONCAT: cat [M][512];  else: block output [M][256]
+};
+struct LnArgs {
+    LnProb p[2];
+    int KS, M;
+};
+
+// LayerNorm(256, eps 1e-5, biased variance) of (sum_ks P + bias);
+// CONCAT: out[row] = [x[row], y]   (attention.py:255-256)   else: out[row] = x[row] + y   (:257-258)
+template <bool CONCAT>
+__global__ __launch_bounds__(256) void ln_kernel(const LnArgs a)
 {
+    const LnProb pr = a.p[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    f32x4 x = *reinterpret_cast<const f32x4*>(bias + 4 * lane);
-    for (int ks = 0; ks < KS; ++ks) x += *reinterpret_cast<const f32x4*>(P + ((long)ks * M + row) * 256 + 4 * lane);
-    const float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / 256.0f);
-    const f32x4 d = x - mean;
+    if (row >= a.M) return;
+    f32x4 t = *reinterpret_cast<const f32x4*>(pr.bias + 4 * lane);
+    for (int ks = 0; ks < a.KS; ++ks) t += *reinterpret_cast<const f32x4*>(pr.P + ((long)ks * a.M + row) * 256 + 4 * lane);
+    const f32x4 xin = *reinterpret_cast<const f32x4*>(pr.x + (long)row * 256 + 4 * lane);
+    const float mean = wave_sum(t[0] + t[1] + t[2] + t[3]) * (1.0f / 256.0f);
+    const f32x4 d = t - mean;
     const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * lane);
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 4 * lane);
-    f32x4 y = d * rstd * gg + bb;
-    if (RESIDUAL) y += *reinterpret_cast<const f32x4*>(res + (long)row * ldres + 4 * lane);
-    *reinterpret_cast<f32x4*>(out + (long)row * ldo + col_off + 4 * lane) = y;
-}
-
-// GEGLU (transformer/attention.py:81-88): h = sum_ks P[ks][row][0:2H] + bias; out = h[:H] * gelu(h[H:]), exact erf.
-__global__ __launch_bounds__(256) void finish_geglu_kernel(const float* __restrict__ P, int KS, int M, int H,
-                                                           const float* __restrict__ bias, float* __restrict__ out)
-{
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
-    const long total = (long)M * (H / 4);
-    if (i >= total) return;
-    const long row = i / (H / 4);
-    const int c = (int)(i - row * (H / 4)) * 4;
-    f32x4 a = *reinterpret_cast<const f32x4*>(bias + c);
-    f32x4 gt = *reinterpret_cast<const f32x4*>(bias + H + c);
-    for (int ks = 0; ks < KS; ++ks) {
-        const float* p = P + ((long)ks * M + row) * (2 * H);
-        a += *reinterpret_cast<const f32x4*>(p + c);
-        gt += *reinterpret_cast<const f32x4*>(p + H + c);
+    const f32x4 y = d * rstd * *reinterpret_cast<const f32x4*>(pr.g + 4 * lane) + *reinterpret_cast<const f32x4*>(pr.be + 4 * lane);
+    if (CONCAT) {
+        *reinterpret_cast<f32x4*>(pr.out + (long)row * 512 + 4 * lane) = xin;
+        *reinterpret_cast<f32x4*>(pr.out + (long)row * 512 + 256 + 4 * lane) = y;
+    } else {
+        *reinterpret_cast<f32x4*>(pr.out + (long)row * 256 + 4 * lane) = xin + y;
     }
-    f32x4 y;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = a[e] * (0.5f * gt[e] * (1.0f + erff(gt[e] * 0.70710678118654752f)));
-    *reinterpret_cast<f32x4*>(out + row * H + c) = y;
-}
-
-// copy x into the first half of the concat buffer: cat[row][0:256] = x[row]
-__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
-                                                        long ldo, int M)
-{
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    *reinterpret_cast<f32x4*>(out + (long)row * ldo + 4 * lane) = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + 4 * lane);
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-static hipError_t launch_linear(const float* X, long ldx, const float* W, long ldw, float* P, int M, int N, int K,
-                                int KS, hipStream_t s)
+struct LinSpec {
+    const float* X;
+    const float* W;
+    float* P;
+    const float* bias;
+    int N;
+};
+
+static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
+                                hipStream_t s)
 {
-    const int Kc = K / KS;
     const size_t lds = sizeof(float) * 4 * 64 * kLinLdx;
     static thread_local int attr_dev = -1;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (attr_dev != dev) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_partial_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_partial_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_dev = dev;
     }
-    if (N % 32 == 0 && N >= 1024)
-        hipLaunchKernelGGL(linear_partial_kernel<2>, dim3(N / 32, KS, M / 64), dim3(256), lds, s, X, ldx, W, ldw, P, M, N, Kc);
-    else
-        hipLaunchKernelGGL(linear_partial_kernel<1>, dim3(N / 16, KS, M / 64), dim3(256), lds, s, X, ldx, W, ldw, P, M, N, Kc);
+    const bool wide = specs[0].N >= 1024;  // 32 columns per workgroup for the big FF projection
+    const int cols = wide ? 32 : 16;
+    LinArgs a;
+    a.nprob = nprob; a.M = M; a.Kc = K / KS; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
+    int tiles = 0;
+    for (int i = 0; i < kMaxProb; ++i) {
+        const LinSpec& sp = specs[i < nprob ? i : 0];
+        a.p[i] = LinProb{sp.X, sp.W, sp.P, sp.bias, sp.N, tiles};
+        if (i < nprob) tiles += sp.N / cols;
+    }
+    const dim3 grid(tiles, KS, M / 64);
+    if (wide) hipLaunchKernelGGL(linear_kernel<2>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(linear_kernel<1>, grid, dim3(256), lds, s, a);
     return hipGetLastError();
-}
-
-// split-K factor: keep the per-wave K slice <= 128 and a multiple of 16, and get >= ~64 workgroups
-static int pick_ks(int N, int K)
-{
-    int ks = 1;
-    while (K / ks / 4 > kLinMaxKw) ks *= 2;
-    while ((N / 16) * ks < 64 && K / (ks * 2) / 4 >= 16 && (K / (ks * 2)) % 64 == 0) ks *= 2;
-    return ks;
 }
 
 size_t transformer_workspace_floats(int B)
 {
     const size_t M = (size_t)64 * (size_t)(B > 0 ? B : 0);
-    // qkv 768 + kv 768 + attn 256 + cat 512 + gate 2048 + split-K slabs (max N*KS over the linears = 4096)
-    // + two ping-pong token buffers
-    return M * (768 + 768 + 256 + 512 + 2048 + 4096 + 2 * 256) + 64;
+    // per stream: qkv 768 + kv 512 + attn 256 + cat 512 + split-K slabs 4096 + ping-pong tokens 256; two streams
+    return 2 * M * (768 + 512 + 256 + 512 + 4096 + 256) + 64;
 }
 
-static int run_block(const ahv_block_weights* w, const float* x, const float* ctx, int self_attn, float* out, int M,
-                     float* ws, hipStream_t s, const char** what)
+struct StreamWs {
+    float *qkv, *kv, *att, *cat, *part, *tmp;
+};
+
+static StreamWs carve(float* ws, int M, int which)
+{
+    float* base = ws + (size_t)which * M * (768 + 512 + 256 + 512 + 4096 + 256);
+    StreamWs w;
+    w.qkv = base;
+    w.kv = w.qkv + (size_t)M * 768;
+    w.att = w.kv + (size_t)M * 512;
+    w.cat = w.att + (size_t)M * 256;
+    w.part = w.cat + (size_t)M * 512;
+    w.tmp = w.part + (size_t)M * 4096;
+    return w;
+}
+
+// One BasicTransformerBlock on EACH stream in the same launches: stream s uses weights w[s], input x[s],
+// attention context ctx[s] (== x[s] for self-attention) and writes out[s].
+static int run_block_pair(const ahv_block_weights* const w[2], const float* const x[2], const float* const ctx[2],
+                          bool self_attn, float* const out[2], int M, const StreamWs ws[2], hipStream_t s,
+                          const char** what)
 {
     const int B = M / 64;
-    float* qkv = ws;                       // [M][768]  (self: q|k|v of x;  cross: q of x in cols 0..255)
-    float* kv = qkv + (size_t)M * 768;     // [M][768]  (cross: k|v of ctx in cols 256..767)
-    float* att = kv + (size_t)M * 768;     // [M][256]
-    float* cat = att + (size_t)M * 256;    // [M][512]
-    float* gate = cat + (size_t)M * 512;   // [M][2048]
-    float* part = gate + (size_t)M * 2048; // split-K slabs
     hipError_t e;
 #define AHV_TRY(call, name) do { e = (call); if (e != hipSuccess) { *what = name; return (int)e; } } while (0)
-    const float *Q, *Kp, *Vp;
-    long ldq, ldkv;
+    AttnArgs at;
+    at.B = B;
+    at.scale = 0.125f;  // dim_head ** -0.5
     if (self_attn) {
-        AHV_TRY(launch_linear(x, 256, w->w_qkv, 256, qkv, M, 768, 256, 1, s), "qkv projection");
-        Q = qkv; Kp = qkv + 256; Vp = qkv + 512; ldq = 768; ldkv = 768;
+        LinSpec sp[2];
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{x[i], w[i]->w_qkv, ws[i].qkv, nullptr, 768};
+        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 1, 0, s), "qkv projection");
+        for (int i = 0; i < 2; ++i) at.p[i] = AttnProb{ws[i].qkv, ws[i].qkv + 256, ws[i].qkv + 512, ws[i].att, 768, 768};
     } else {
-        AHV_TRY(launch_linear(x, 256, w->w_qkv, 256, qkv, M, 256, 256, 1, s), "q projection");
-        AHV_TRY(launch_linear(ctx, 256, w->w_qkv + 256 * 256, 256, kv, M, 512, 256, 1, s), "kv projection");
-        Q = qkv; Kp = kv; Vp = kv + 256; ldq = 256; ldkv = 512;
+        LinSpec sq[2], skv[2];
+        for (int i = 0; i < 2; ++i) {
+            sq[i] = LinSpec{x[i], w[i]->w_qkv, ws[i].qkv, nullptr, 256};
+            skv[i] = LinSpec{ctx[i], w[i]->w_qkv + 256 * 256, ws[i].kv, nullptr, 512};
+        }
+        LinSpec sp[4] = {sq[0], sq[1], skv[0], skv[1]};
+        AHV_TRY(launch_linear(sp, 4, 256, 256, M, 256, 1, 0, s), "q / kv projections");
+        for (int i = 0; i < 2; ++i) at.p[i] = AttnProb{ws[i].qkv, ws[i].kv, ws[i].kv + 256, ws[i].att, 256, 512};
     }
-    hipLaunchKernelGGL(attention_kernel, dim3(B), dim3(256), 0, s, Q, ldq, Kp, ldkv, Vp, ldkv, att, 256L, 4, 0.125f);
+    hipLaunchKernelGGL(attention_kernel, dim3(2 * B, 4), dim3(256), 0, s, at);
     AHV_TRY(hipGetLastError(), "attention");
-    int ks = pick_ks(256, 256);
-    AHV_TRY(launch_linear(att, 256, w->w_out, 256, part, M, 256, 256, ks, s), "out projection");
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, 256L, cat, 512L, M);
-    hipLaunchKernelGGL(finish_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, part, ks, M, w->b_out, w->ln1_g,
-                       w->ln1_b, (const float*)nullptr, 0L, cat, 512L, 256);
-    AHV_TRY(hipGetLastError(), "norm1");
-    AHV_TRY(launch_linear(cat, 512, w->w_ff1, 512, part, M, 4096, 512, 1, s), "ff in");
-    hipLaunchKernelGGL(finish_geglu_kernel, dim3((unsigned)(((long)M * 512 + 255) / 256)), dim3(256), 0, s, part, 1, M,
-                       2048, w->b_ff1, gate);
-    AHV_TRY(hipGetLastError(), "geglu");
-    ks = pick_ks(256, 2048);
-    AHV_TRY(launch_linear(gate, 2048, w->w_ff2, 2048, part, M, 256, 2048, ks, s), "ff out");
-    hipLaunchKernelGGL(finish_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, part, ks, M, w->b_ff2, w->ln2_g,
-                       w->ln2_b, x, 256L, out, 256L, 0);
-    AHV_TRY(hipGetLastError(), "norm2");
+    {
+        LinSpec sp[2];
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].att, w[i]->w_out, ws[i].part, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 2, 0, s), "out projection");
+        LnArgs ln;
+        ln.KS = 2; ln.M = M;
+        for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].part, w[i]->b_out, w[i]->ln1_g, w[i]->ln1_b, x[i], ws[i].cat};
+        hipLaunchKernelGGL(ln_kernel<true>, dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_TRY(hipGetLastError(), "norm1 + concat");
+    }
+    {
+        LinSpec sp[2];
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].cat, w[i]->w_ff1, ws[i].part, nullptr, 4096};
+        AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 0, s), "ff in");
+        // FF out reads the GEGLU of that slab on the fly; its own slabs go behind it in `part`
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, w[i]->b_ff1, 256};
+        // 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
+        AHV_TRY(launch_linear(sp, 2, 4096, 2048, M, 2048, 4, 2048, s), "ff out");
+        LnArgs ln;
+        ln.KS = 4; ln.M = M;
+        for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
+        hipLaunchKernelGGL(ln_kernel<false>, dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_TRY(hipGetLastError(), "norm2 + residual");
+    }
 #undef AHV_TRY
     return 0;
 }
@@ -357,18 +411,23 @@ int transformer_blocks(const ahv_block_weights* blocks, int depth, float* x_src,
                        hipStream_t s, const char** what)
 {
     const int M = 64 * B;
-    // the two ping-pong token buffers live at the end of the workspace
-    float* tmp_src = ws + (size_t)M * (768 + 768 + 256 + 512 + 2048 + 4096);
-    float* tmp_tgt = tmp_src + (size_t)M * 256;
+    const StreamWs w2[2] = {carve(ws, M, 0), carve(ws, M, 1)};
     for (int d = 0; d < depth; ++d) {
         const ahv_block_weights* w = blocks + 4 * d;  // order: attn_self_1, attn_self_2, attn_cross_1, attn_cross_2
         int rc;
-        // x = self_1(x); ctx = self_2(ctx)
-        if ((rc = run_block(w + 0, x_src, x_src, 1, tmp_src, M, ws, s, what))) return rc;
-        if ((rc = run_block(w + 1, x_tgt, x_tgt, 1, tmp_tgt, M, ws, s, what))) return rc;
-        // x_out = cross_1(x, ctx); ctx_out = cross_2(ctx, x)  -- both read the post-self tensors
-        if ((rc = run_block(w + 2, tmp_src, tmp_tgt, 0, x_src, M, ws, s, what))) return rc;
-        if ((rc = run_block(w + 3, tmp_tgt, tmp_src, 0, x_tgt, M, ws, s, what))) return rc;
+        {   // x = self_1(x); ctx = self_2(ctx)
+            const ahv_block_weights* const ww[2] = {w + 0, w + 1};
+            const float* const xin[2] = {x_src, x_tgt};
+            float* const out[2] = {w2[0].tmp, w2[1].tmp};
+            if ((rc = run_block_pair(ww, xin, xin, true, out, M, w2, s, what))) return rc;
+        }
+        {   // x_out = cross_1(x, ctx); ctx_out = cross_2(ctx, x): both read the post-self tensors
+            const ahv_block_weights* const ww[2] = {w + 2, w + 3};
+            const float* const xin[2] = {w2[0].tmp, w2[1].tmp};
+            const float* const cin[2] = {w2[1].tmp, w2[0].tmp};
+            float* const out[2] = {x_src, x_tgt};
+            if ((rc = run_block_pair(ww, xin, cin, false, out, M, w2, s, what))) return rc;
+        }
     }
     return 0;
 }
