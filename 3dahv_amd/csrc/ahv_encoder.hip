@@ -44,20 +44,18 @@ struct LinArgs {
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
 
 // -------------------------------------------------------------------------------------------------
-// Skinny linear.  grid = (sum of n-tiles, KS, M / 64); 256 threads.  The workgroup owns 64 rows x 16*NT
-// columns and the K range [ks*Kc, (ks+1)*Kc); its 4 waves split that range (each streams its own part
-// of the W rows exactly once), stage their X slice in LDS and meet in LDS at the end.  All W operands of a
-// wave (<= 8 float4 per n-tile) are requested up front, so HBM latency is paid once, not per k-step.
-// k ordering inside a 16-wide step: MFMA k-step s, lane group kq <-> column k0 + 4*kq + s, so that both
-// operands are one aligned float4 per lane.
+// Skinny linear.  grid = (sum of n-tiles, KS, M / 64); 512 threads.  The workgroup owns 64 rows x 16*NT
+// columns and the K range [ks*Kc, (ks+1)*Kc); its 8 waves split that range (KW columns each, every W row
+// segment is streamed exactly once).  Both MFMA operands go straight from memory to registers: with the
+// k ordering "MFMA k-step s, lane group kq <-> column k0 + 4*kq + s" a lane needs exactly one aligned
+// float4 of its X row and one of its W row per 16-wide step, and nobody else needs them.  ALL loads of a
+// wave are issued before its first MFMA (sched_barrier keeps hipcc from sinking them to their uses), so
+// the memory latency is paid once.  The 8 partial tiles meet in LDS.
 // -------------------------------------------------------------------------------------------------
-constexpr int kLinMaxKw = 128;          // K columns per wave
-constexpr int kLinLdx = kLinMaxKw + 4;  // +4 floats: ds_read_b128 of 16 rows hits 16 distinct slots
-
-template <int NT>
-__global__ __launch_bounds__(256) void linear_kernel(const LinArgs a)
+template <int NT, int KW, bool GEGLU>
+__global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16 * NT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pi = 0;
@@ -68,67 +66,51 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a)
     const int n0 = ((int)blockIdx.x - pr.tile0) * 16 * NT;
     const int ks = blockIdx.y;
     const int m0 = blockIdx.z * 64;
-    const int Kw = a.Kc >> 2;
-    const int kbase = ks * a.Kc + wave * Kw;
+    const int kbase = ks * a.Kc + wave * KW;
     const int r16 = lane & 15, kq = lane >> 4;
+    constexpr int STEPS = KW / 16;
 
-    // request every W operand of this wave now
-    f32x4 b[8][NT];
+    f32x4 w[STEPS][NT], x[STEPS][4], g[GEGLU ? STEPS : 1][4], bv[GEGLU ? STEPS : 1], bg[GEGLU ? STEPS : 1];
+    const float* xrow = pr.X + (long)(m0 + r16) * a.ldx + kbase + 4 * kq;
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
+    for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            if (it * 16 < Kw)
-                b[it][nt] = *reinterpret_cast<const f32x4*>(pr.W + (long)(n0 + nt * 16 + r16) * a.ldw + kbase + 16 * it + 4 * kq);
-
-    // stage X[m0..m0+63][kbase..kbase+Kw) -> Xs[row][k]
-    float* Xs = lds + wave * (64 * kLinLdx);
-    {
-        const int q4 = Kw >> 2;  // float4 per row
-        const int H = a.geglu_h;
-        for (int i = lane; i < 64 * q4; i += 64) {
-            const int r = i / q4, c = i - r * q4;
-            const float* src = pr.X + (long)(m0 + r) * a.ldx + kbase + 4 * c;
-            f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            if (H > 0) {
-                f32x4 g = *reinterpret_cast<const f32x4*>(src + H);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(pr.bias + kbase + 4 * c);
-                const f32x4 bg = *reinterpret_cast<const f32x4*>(pr.bias + H + kbase + 4 * c);
-                v += bv;
-                g += bg;
+            w[st][nt] = *reinterpret_cast<const f32x4*>(pr.W + (long)(n0 + nt * 16 + r16) * a.ldw + kbase + 16 * st + 4 * kq);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf(g[e]);
-            }
-            *reinterpret_cast<f32x4*>(Xs + r * kLinLdx + 4 * c) = v;
+        for (int rt = 0; rt < 4; ++rt) x[st][rt] = *reinterpret_cast<const f32x4*>(xrow + (long)(16 * rt) * a.ldx + 16 * st);
+        if (GEGLU) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+                g[st][rt] = *reinterpret_cast<const f32x4*>(xrow + (long)(16 * rt) * a.ldx + 16 * st + a.geglu_h);
+            bv[st] = *reinterpret_cast<const f32x4*>(pr.bias + kbase + 16 * st + 4 * kq);
+            bg[st] = *reinterpret_cast<const f32x4*>(pr.bias + a.geglu_h + kbase + 16 * st + 4 * kq);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    asm volatile("" ::: "memory");
-
+    __builtin_amdgcn_sched_barrier(0);
+    if (GEGLU) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[st][rt][e] = (x[st][rt][e] + bv[st][e]) * gelu_erf(g[st][rt][e] + bg[st][e]);
+    }
     f32x4 acc[4][NT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        if (it * 16 < Kw) {
-            f32x4 x[4];
+    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
-                x[rt] = *reinterpret_cast<const f32x4*>(Xs + (rt * 16 + r16) * kLinLdx + 16 * it + 4 * kq);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], b[it][nt][s], acc[rt][nt], 0, 0, 0);
-        }
-    }
-    // cross-wave reduction through LDS (re-using the X staging area), then one coalesced store
-    __syncthreads();
-    float* red = lds;  // [4 waves][64 rows][16*NT]
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[st][rt][s4], w[st][nt][s4], acc[rt][nt], 0, 0, 0);
+    // cross-wave reduction through LDS, then one coalesced store
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -138,9 +120,11 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a)
                 red[(wave * 64 + rt * 16 + 4 * kq + r) * (16 * NT) + nt * 16 + r16] = acc[rt][nt][r];
     __syncthreads();
     float* out = pr.P + ((long)ks * a.M + m0) * pr.N + n0;
-    for (int i = tid; i < 64 * 16 * NT; i += 256) {
+    for (int i = tid; i < 64 * 16 * NT; i += 512) {
         const int r = i / (16 * NT), c = i - r * (16 * NT);
-        const float v = red[i] + red[i + 64 * 16 * NT] + red[i + 2 * 64 * 16 * NT] + red[i + 3 * 64 * 16 * NT];
+        float v = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) v += red[i + wv * 64 * 16 * NT];
         out[(long)r * pr.N + c] = v;
     }
 }
@@ -298,20 +282,9 @@ struct LinSpec {
 static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
                                 hipStream_t s)
 {
-    const size_t lds = sizeof(float) * 4 * 64 * kLinLdx;
-    static thread_local int attr_dev = -1;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (attr_dev != dev) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
     const bool wide = specs[0].N >= 1024;  // 32 columns per workgroup for the big FF projection
     const int cols = wide ? 32 : 16;
+    const int Kw = K / KS / 8;
     LinArgs a;
     a.nprob = nprob; a.M = M; a.Kc = K / KS; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
     int tiles = 0;
@@ -321,8 +294,11 @@ static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long 
         if (i < nprob) tiles += sp.N / cols;
     }
     const dim3 grid(tiles, KS, M / 64);
-    if (wide) hipLaunchKernelGGL(linear_kernel<2>, grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(linear_kernel<1>, grid, dim3(256), lds, s, a);
+    if (wide && Kw == 64 && !geglu_h) hipLaunchKernelGGL((linear_kernel<2, 64, false>), grid, dim3(512), 0, s, a);
+    else if (!wide && Kw == 64 && geglu_h) hipLaunchKernelGGL((linear_kernel<1, 64, true>), grid, dim3(512), 0, s, a);
+    else if (!wide && Kw == 32 && !geglu_h) hipLaunchKernelGGL((linear_kernel<1, 32, false>), grid, dim3(512), 0, s, a);
+    else if (!wide && Kw == 16 && !geglu_h) hipLaunchKernelGGL((linear_kernel<1, 16, false>), grid, dim3(512), 0, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
