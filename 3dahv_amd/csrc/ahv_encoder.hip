@@ -7,7 +7,7 @@
 // separate "problems": 7 launches per half layer, 56 for the whole depth-4 encoder.
 //
 //   linear_kernel       P[ks][M][N] = X[M][K-slice ks] . W[N][K-slice]^T   fp32 MFMA 16x16x4, split-K,
-//                       up to 4 problems per launch; the X staging can apply GEGLU on the fly
+//                       up to 4 problems per launch; optional fused bias + GEGLU epilogue
 //   attention_kernel    softmax(Q K^T / 8) V, one wave per (sample, head, 16 queries); scores are kept
 //                       transposed so that softmax runs down registers and P feeds the 2nd MFMA in place
 //   ln1_concat_kernel   cat[row] = [x[row], LayerNorm(sum_ks P + bias)]          (attention.py:255-256)
@@ -29,7 +29,7 @@ struct LinProb {
     const float* X;     // [M][ldx]  (GEGLU mode: the [M][2H] slab of the previous linear)
     const float* W;     // [N][ldw]
     float* P;           // [KS][M][N]
-    const float* bias;  // GEGLU mode: bias of the previous linear [2H]
+    const float* bias;  // GEGLU_OUT: bias of this projection [2H]
     int N;
     int tile0;          // first n-tile (of 16*NT columns) of this problem in blockIdx.x
 };
@@ -38,7 +38,7 @@ struct LinArgs {
     LinProb p[kMaxProb];
     int nprob, M, Kc;
     long ldx, ldw;
-    int geglu_h;  // 0: plain X;  H > 0: X[r][k] = (h[r][k] + b[k]) * gelu(h[r][H + k] + b[H + k])
+    int geglu_h;  // H > 0: GEGLU epilogue, W has 2H rows (value rows, then gate rows), output [M][H]
 };
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
@@ -52,7 +52,10 @@ __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + e
 // wave are issued before its first MFMA (sched_barrier keeps hipcc from sinking them to their uses), so
 // the memory latency is paid once.  The 8 partial tiles meet in LDS.
 // -------------------------------------------------------------------------------------------------
-template <int NT, int KW, bool GEGLU>
+// GEGLU_OUT (NT = 2, KS = 1): the two n-tiles of the workgroup are the VALUE columns [16t, 16t+16) and the GATE
+// columns [H+16t, H+16t+16) of the GEGLU projection, and the epilogue writes
+// out[r][16t+c] = (value + b[16t+c]) * gelu(gate + b[H+16t+c]) straight into a [M][H] buffer (attention.py:81-88).
+template <int NT, int KW, bool GEGLU_OUT>
 __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 {
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16 * NT];
@@ -63,39 +66,26 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
     for (int i = 1; i < kMaxProb; ++i)
         if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile0) pi = i;
     const LinProb pr = a.p[pi];
-    const int n0 = ((int)blockIdx.x - pr.tile0) * 16 * NT;
+    const int tile = (int)blockIdx.x - pr.tile0;
+    const int n0 = GEGLU_OUT ? tile * 16 : tile * 16 * NT;
+    const int nstep = GEGLU_OUT ? a.geglu_h : 16;  // distance between the workgroup's n-tiles
     const int ks = blockIdx.y;
     const int m0 = blockIdx.z * 64;
     const int kbase = ks * a.Kc + wave * KW;
     const int r16 = lane & 15, kq = lane >> 4;
     constexpr int STEPS = KW / 16;
 
-    f32x4 w[STEPS][NT], x[STEPS][4], g[GEGLU ? STEPS : 1][4], bv[GEGLU ? STEPS : 1], bg[GEGLU ? STEPS : 1];
+    f32x4 w[STEPS][NT], x[STEPS][4];
     const float* xrow = pr.X + (long)(m0 + r16) * a.ldx + kbase + 4 * kq;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            w[st][nt] = *reinterpret_cast<const f32x4*>(pr.W + (long)(n0 + nt * 16 + r16) * a.ldw + kbase + 16 * st + 4 * kq);
+            w[st][nt] = *reinterpret_cast<const f32x4*>(pr.W + (long)(n0 + nt * nstep + r16) * a.ldw + kbase + 16 * st + 4 * kq);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) x[st][rt] = *reinterpret_cast<const f32x4*>(xrow + (long)(16 * rt) * a.ldx + 16 * st);
-        if (GEGLU) {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-                g[st][rt] = *reinterpret_cast<const f32x4*>(xrow + (long)(16 * rt) * a.ldx + 16 * st + a.geglu_h);
-            bv[st] = *reinterpret_cast<const f32x4*>(pr.bias + kbase + 16 * st + 4 * kq);
-            bg[st] = *reinterpret_cast<const f32x4*>(pr.bias + a.geglu_h + kbase + 16 * st + 4 * kq);
-        }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (GEGLU) {
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st)
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[st][rt][e] = (x[st][rt][e] + bv[st][e]) * gelu_erf(g[st][rt][e] + bg[st][e]);
-    }
     f32x4 acc[4][NT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -119,13 +109,27 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
             for (int r = 0; r < 4; ++r)
                 red[(wave * 64 + rt * 16 + 4 * kq + r) * (16 * NT) + nt * 16 + r16] = acc[rt][nt][r];
     __syncthreads();
-    float* out = pr.P + ((long)ks * a.M + m0) * pr.N + n0;
-    for (int i = tid; i < 64 * 16 * NT; i += 512) {
-        const int r = i / (16 * NT), c = i - r * (16 * NT);
-        float v = 0.0f;
+    if (GEGLU_OUT) {
+        float* out = pr.P + (long)m0 * a.geglu_h + n0;
+        for (int i = tid; i < 64 * 16; i += 512) {
+            const int r = i >> 4, c = i & 15;
+            float v = pr.bias[n0 + c], gt = pr.bias[a.geglu_h + n0 + c];
 #pragma unroll
-        for (int wv = 0; wv < 8; ++wv) v += red[i + wv * 64 * 16 * NT];
-        out[(long)r * pr.N + c] = v;
+            for (int wv = 0; wv < 8; ++wv) {
+                v += red[(wv * 64 + r) * 32 + c];
+                gt += red[(wv * 64 + r) * 32 + 16 + c];
+            }
+            out[(long)r * a.geglu_h + c] = v * gelu_erf(gt);
+        }
+    } else {
+        float* out = pr.P + ((long)ks * a.M + m0) * pr.N + n0;
+        for (int i = tid; i < 64 * 16 * NT; i += 512) {
+            const int r = i / (16 * NT), c = i - r * (16 * NT);
+            float v = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) v += red[i + wv * 64 * 16 * NT];
+            out[(long)r * pr.N + c] = v;
+        }
     }
 }
 
@@ -282,7 +286,7 @@ struct LinSpec {
 static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
                                 hipStream_t s)
 {
-    const bool wide = specs[0].N >= 1024;  // 32 columns per workgroup for the big FF projection
+    const bool wide = geglu_h > 0;  // the GEGLU projection: value tile + gate tile per workgroup
     const int cols = wide ? 32 : 16;
     const int Kw = K / KS / 8;
     LinArgs a;
@@ -294,8 +298,8 @@ static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long 
         if (i < nprob) tiles += sp.N / cols;
     }
     const dim3 grid(tiles, KS, M / 64);
-    if (wide && Kw == 64 && !geglu_h) hipLaunchKernelGGL((linear_kernel<2, 64, false>), grid, dim3(512), 0, s, a);
-    else if (!wide && Kw == 64 && geglu_h) hipLaunchKernelGGL((linear_kernel<1, 64, true>), grid, dim3(512), 0, s, a);
+    if (wide && Kw == 64 && KS == 1) hipLaunchKernelGGL((linear_kernel<2, 64, true>), grid, dim3(512), 0, s, a);
+    else if (!wide && Kw == 64) hipLaunchKernelGGL((linear_kernel<1, 64, false>), grid, dim3(512), 0, s, a);
     else if (!wide && Kw == 32 && !geglu_h) hipLaunchKernelGGL((linear_kernel<1, 32, false>), grid, dim3(512), 0, s, a);
     else if (!wide && Kw == 16 && !geglu_h) hipLaunchKernelGGL((linear_kernel<1, 16, false>), grid, dim3(512), 0, s, a);
     else return hipErrorInvalidValue;
@@ -367,12 +371,12 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
     }
     {
         LinSpec sp[2];
-        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].cat, w[i]->w_ff1, ws[i].part, nullptr, 4096};
-        AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 0, s), "ff in");
-        // FF out reads the GEGLU of that slab on the fly; its own slabs go behind it in `part`
-        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, w[i]->b_ff1, 256};
-        // 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
-        AHV_TRY(launch_linear(sp, 2, 4096, 2048, M, 2048, 4, 2048, s), "ff out");
+        // FF in + GEGLU: writes the gated activations [M][2048] into `part`
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].cat, w[i]->w_ff1, ws[i].part, w[i]->b_ff1, 4096};
+        AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 2048, s), "ff in + geglu");
+        // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
         LnArgs ln;
         ln.KS = 4; ln.M = M;
         for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
