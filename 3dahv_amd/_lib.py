@@ -43,6 +43,16 @@ class BlockWeights(ctypes.Structure):
                                    "ln2_g", "ln2_b")]
 
 
+class AlignerWeights(ctypes.Structure):
+    """Mirror of ``ahv_aligner_weights`` (include/ahv.h)."""
+    _fields_ = ([(n, _vp) for n in ("w_emb", "w_conv1", "w_conv2", "posemb", "gn_g", "gn_b")] +
+                [("w_in", _vp * 2), ("b_in", _vp * 2), ("w_out", _vp * 2), ("b_out", _vp * 2),
+                 ("w3d_1", _vp), ("w3d_2", _vp), ("blocks", ctypes.POINTER(BlockWeights)), ("depth", _int)])
+
+
+SIGNATURES["ahv_forward_2d3d_workspace_bytes"] = (ctypes.c_size_t, [_int])
+SIGNATURES["ahv_forward_2d3d_f32"] = (_int, [ctypes.POINTER(AlignerWeights), _vp, _vp, _int, _vp, ctypes.c_size_t, _vp,
+                                             _vp, _vp])
 SIGNATURES["ahv_transformer_workspace_bytes"] = (ctypes.c_size_t, [_int])
 SIGNATURES["ahv_transformer_blocks_f32"] = (_int, [ctypes.POINTER(BlockWeights), _int, _vp, _vp, _int, _vp,
                                                    ctypes.c_size_t, _vp])

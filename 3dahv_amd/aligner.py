@@ -238,6 +238,8 @@ class Feature_Aligner(nn.Module):
         self.feature_embedding_3d = _ResBlock(mid_channel // 8, 16, three_d=True)
         self.feature_embedding_2d = nn.Sequential(nn.Conv2d(3 * 8 * 16, out_channel, 1, bias=False),
                                                   nn.ReLU(inplace=True), nn.Conv2d(out_channel, out_channel, 1))
+        self.use_hip_encoder = True  # forward_2d3d on the HIP kernels when the inputs are on the GPU
+        self.register_load_state_dict_post_hook(lambda module, incompatible: _PACKED.pop(module, None))
 
     def posemb_sincos_2d(self, patches, channel=128, temperature=10000, dtype=torch.float32):
         """cat(sin x, cos x, sin y, cos y) with channel/4 frequencies 1/T^(k/(channel/4-1))
@@ -251,9 +253,76 @@ class Feature_Aligner(nn.Module):
         ay, ax = ys[None] * omega[:, None, None], xs[None] * omega[:, None, None]
         return torch.cat((ax.sin(), ax.cos(), ay.sin(), ay.cos()), dim=0).type(dtype)
 
+    # ---- whole forward_2d3d on the HIP kernels (csrc/ahv_encoder.hip) -----------------------------
+    def _hip_2d3d_eligible(self, x):
+        return (self.use_hip_encoder and x.is_cuda and x.dtype == torch.float32 and self.in_channel == 768
+                and self.mid_channel == 256 and tuple(x.shape[1:]) == (768, 8, 8) and not torch.is_grad_enabled()
+                and self.att.n_heads == 4)
+
+    def _pack_aligner(self, device):
+        from . import _lib
+        blocks, keep_b, _ = self.att._pack(device)
+        rb2, rb3 = self.feature_embedding[1], self.feature_embedding_3d
+        c1 = rb3.conv1.weight.permute(0, 2, 3, 4, 1).reshape(16, 27, 32)
+        w3d_1 = torch.zeros(32, 32, 32, dtype=torch.float32, device=c1.device)  # [row][tap padded to 32][ci]
+        w3d_1[:16, :27] = c1
+        w3d_1[16:, 13] = rb3.downsample[0].weight.reshape(16, 32)  # centre tap (1,1,1) = 1*9 + 1*3 + 1
+        w3d_2 = torch.zeros(16, 32, 16, dtype=torch.float32, device=c1.device)
+        w3d_2[:, :27] = rb3.conv2.weight.permute(0, 2, 3, 4, 1).reshape(16, 27, 16)
+        pe = self.posemb_sincos_2d(torch.empty(1, 1, 8, 8, device=c1.device), channel=self.mid_channel)
+        tensors = dict(
+            w_emb=self.feature_embedding[0].weight.reshape(256, 768),
+            w_conv1=rb2.conv1.weight.permute(0, 2, 3, 1).reshape(256, 2304),
+            w_conv2=rb2.conv2.weight.permute(0, 2, 3, 1).reshape(256, 2304),
+            posemb=pe.reshape(256, 64).t(), gn_g=self.att.norm.weight, gn_b=self.att.norm.bias,
+            w3d_1=w3d_1.reshape(32, 1024), w3d_2=w3d_2.reshape(16, 512))
+        pairs = dict(w_in=(self.att.proj_in.weight, self.att.proj_context_in.weight),
+                     b_in=(self.att.proj_in.bias, self.att.proj_context_in.bias),
+                     w_out=(self.att.proj_out.weight, self.att.proj_context_out.weight),
+                     b_out=(self.att.proj_out.bias, self.att.proj_context_out.bias))
+        aw, keep = _lib.AlignerWeights(), [keep_b]
+        conv = lambda t: t.detach().to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous() \
+            if t.dim() > 1 else t.detach().to(device=device, dtype=torch.float32).contiguous()
+        for name, t in tensors.items():
+            t = conv(t)
+            keep.append(t)
+            setattr(aw, name, t.data_ptr())
+        for name, (a, b) in pairs.items():
+            ta, tb = conv(a), conv(b)
+            keep += [ta, tb]
+            arr = getattr(aw, name)
+            arr[0], arr[1] = ta.data_ptr(), tb.data_ptr()
+        aw.blocks, aw.depth = blocks, len(self.att.transformer_blocks)
+        _PACKED[self] = (aw, keep, device)
+        return _PACKED[self]
+
+    def _hip_forward_2d3d(self, src, tgt):
+        from . import _lib
+        packed = _PACKED.get(self)
+        if packed is None or packed[2] != src.device or _PACKED.get(self.att) is None:
+            packed = self._pack_aligner(src.device)
+        B = src.shape[0]
+        lib = _lib.load()
+        nbytes = lib.ahv_forward_2d3d_workspace_bytes(B)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=src.device)
+        vol_src = torch.empty((B, 16, 8, 8, 8), dtype=torch.float32, device=src.device)
+        vol_tgt = torch.empty_like(vol_src)
+        import ctypes
+        _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed[0]), src.contiguous().data_ptr(),
+                                            tgt.contiguous().data_ptr(), B, ws.data_ptr(), nbytes, vol_src.data_ptr(),
+                                            vol_tgt.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "ahv_forward_2d3d_f32")
+        return vol_src, vol_tgt
+
     def forward_2d3d(self, img_feat_src, img_feat_tgt, random_mask=True, mask_ratio=0.25):
         """(B,in,8,8) x2 -> (B,16,8,8,8) x2 (modules/modules.py:86-110)."""
         bs = img_feat_src.shape[0]
+        if self._hip_2d3d_eligible(img_feat_src):
+            src, tgt = self._hip_forward_2d3d(img_feat_src, img_feat_tgt)
+            if random_mask is True:
+                src = src * random_masking(src, mask_ratio).reshape(-1, 1, 8, 8, 8)
+                tgt = tgt * random_masking(tgt, mask_ratio).reshape(-1, 1, 8, 8, 8)
+            return src, tgt
         src, tgt = self.feature_embedding(img_feat_src), self.feature_embedding(img_feat_tgt)
         pe = self.posemb_sincos_2d(src, channel=self.mid_channel)[None]
         src, tgt = self.att(src + pe, tgt + pe)

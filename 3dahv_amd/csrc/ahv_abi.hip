@@ -25,6 +25,9 @@ hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_
 extern int g_score_variant;
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
+size_t forward_2d3d_workspace_floats(int B);
+int forward_2d3d(const ahv_aligner_weights*, const float*, const float*, int, float*, float*, float*, hipStream_t,
+                 const char**);
 }  // namespace ahv
 
 namespace {
@@ -217,6 +220,31 @@ int ahv_transformer_blocks_f32(const ahv_block_weights* blocks, int depth, float
     const int rc = ahv::transformer_blocks(blocks, depth, x_src, x_tgt, B, static_cast<float*>(workspace),
                                            static_cast<hipStream_t>(stream), &what);
     if (rc != 0) return fail(AHV_ELAUNCH, "transformer_blocks: %s: %s", what, hipGetErrorString((hipError_t)rc));
+    return AHV_OK;
+}
+
+size_t ahv_forward_2d3d_workspace_bytes(int B) { return sizeof(float) * ahv::forward_2d3d_workspace_floats(B); }
+
+int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, const float* layer4_tgt, int B,
+                         void* workspace, size_t workspace_bytes, float* vol_src, float* vol_tgt, void* stream)
+{
+    if (B < 0) return fail(AHV_EINVAL, "forward_2d3d: negative B");
+    if (B == 0) return AHV_OK;
+    if (!w || !layer4_src || !layer4_tgt || !workspace || !vol_src || !vol_tgt)
+        return fail(AHV_EINVAL, "forward_2d3d: null pointer");
+    if (!w->w_emb || !w->w_conv1 || !w->w_conv2 || !w->posemb || !w->gn_g || !w->gn_b || !w->w_in[0] || !w->w_in[1] ||
+        !w->b_in[0] || !w->b_in[1] || !w->w_out[0] || !w->w_out[1] || !w->b_out[0] || !w->b_out[1] || !w->w3d_1 ||
+        !w->w3d_2 || (w->depth > 0 && !w->blocks))
+        return fail(AHV_EINVAL, "forward_2d3d: null weight pointer");
+    if (w->depth < 0) return fail(AHV_EINVAL, "forward_2d3d: negative depth");
+    if (workspace_bytes < ahv_forward_2d3d_workspace_bytes(B))
+        return fail(AHV_EINVAL, "forward_2d3d: workspace of %zu bytes, need %zu", workspace_bytes,
+                    ahv_forward_2d3d_workspace_bytes(B));
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(AHV_EINVAL, "forward_2d3d: workspace must be 16-byte aligned");
+    const char* what = "";
+    const int rc = ahv::forward_2d3d(w, layer4_src, layer4_tgt, B, static_cast<float*>(workspace), vol_src, vol_tgt,
+                                     static_cast<hipStream_t>(stream), &what);
+    if (rc != 0) return fail(AHV_ELAUNCH, "forward_2d3d: %s: %s", what, hipGetErrorString((hipError_t)rc));
     return AHV_OK;
 }
 

@@ -43,6 +43,13 @@ struct LinArgs {
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
 
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
+    return x;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Skinny linear.  grid = (sum of n-tiles, KS, M / 64); 512 threads.  The workgroup owns 64 rows x 16*NT
 // columns and the K range [ks*Kc, (ks+1)*Kc); its 8 waves split that range (KW columns each, every W row
@@ -55,7 +62,11 @@ __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + e
 // GEGLU_OUT (NT = 2, KS = 1): the two n-tiles of the workgroup are the VALUE columns [16t, 16t+16) and the GATE
 // columns [H+16t, H+16t+16) of the GEGLU projection, and the epilogue writes
 // out[r][16t+c] = (value + b[16t+c]) * gelu(gate + b[H+16t+c]) straight into a [M][H] buffer (attention.py:81-88).
-template <int NT, int KW, bool GEGLU_OUT>
+// MODE 1 / 2: implicit GEMM of a 3x3 convolution over 8x8 tokens (C = 256 channels) / a 3x3x3 convolution over
+// the 8^3 voxels of a channel-last volume (C = KW channels): the K axis is (tap, channel) with one tap (or a
+// part of one) per wave, so the row a lane reads is its own row shifted by the tap, or zero outside the image
+// (zero padding).  Taps >= 27 (3-D) are K padding: their weights are zero and nothing is loaded.
+template <int NT, int KW, bool GEGLU_OUT, int MODE = 0>
 __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 {
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16 * NT];
@@ -76,14 +87,37 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
     constexpr int STEPS = KW / 16;
 
     f32x4 w[STEPS][NT], x[STEPS][4];
-    const float* xrow = pr.X + (long)(m0 + r16) * a.ldx + kbase + 4 * kq;
+    const float* xsrc[4];
+    bool xok[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int p = rt * 16 + r16;  // row of this lane inside the 64-row tile
+        if (MODE == 0) {
+            xsrc[rt] = pr.X + (long)(m0 + p) * a.ldx + kbase + 4 * kq;
+            xok[rt] = true;
+        } else if (MODE == 1) {
+            const int tap = kbase >> 8, ci0 = kbase & 255;
+            const int ny = (p >> 3) + tap / 3 - 1, nx = (p & 7) + tap % 3 - 1;
+            xok[rt] = (unsigned)ny < 8u && (unsigned)nx < 8u;
+            xsrc[rt] = pr.X + (long)(m0 + (xok[rt] ? ny * 8 + nx : p)) * 256 + ci0 + 4 * kq;
+        } else {
+            const int tap = kbase / KW;
+            const int v = (m0 & 511) + p;  // voxel inside the sample
+            const int nd = (v >> 6) + tap / 9 - 1, nh = ((v >> 3) & 7) + (tap / 3) % 3 - 1, nw = (v & 7) + tap % 3 - 1;
+            xok[rt] = tap < 27 && (unsigned)nd < 8u && (unsigned)nh < 8u && (unsigned)nw < 8u;
+            xsrc[rt] = pr.X + (long)((m0 - (m0 & 511)) + (xok[rt] ? nd * 64 + nh * 8 + nw : v)) * KW + 4 * kq;
+        }
+    }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             w[st][nt] = *reinterpret_cast<const f32x4*>(pr.W + (long)(n0 + nt * nstep + r16) * a.ldw + kbase + 16 * st + 4 * kq);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) x[st][rt] = *reinterpret_cast<const f32x4*>(xrow + (long)(16 * rt) * a.ldx + 16 * st);
+        for (int rt = 0; rt < 4; ++rt) {
+            x[st][rt] = *reinterpret_cast<const f32x4*>(xsrc[rt] + 16 * st);
+            if (MODE != 0 && !xok[rt]) x[st][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4][NT];
@@ -229,13 +263,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
 // -------------------------------------------------------------------------------------------------
 // Row kernels (one wave per 256-wide row; blockIdx.y = problem).
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float x)
-{
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
-    return x;
-}
-
 struct LnProb {
     const float* P;     // [KS][M][256] split-K slabs of the preceding linear
     const float* bias;  // [256]
@@ -274,6 +301,106 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnArgs a)
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Kernels around the token stage (Feature_Aligner.forward_2d3d, modules/modules.py:86-101).
+// Activations live token-major [M = 64*B][C] ("channel-last"); blockIdx.y = stream.
+// -------------------------------------------------------------------------------------------------
+struct Nchw2TokArgs {
+    const float* in[2];  // [B][C][64]
+    float* out[2];       // [B*64][C]
+    int C, B;
+};
+
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const Nchw2TokArgs a)
+{
+    __shared__ float tile[64][65];
+    const float* in = a.in[blockIdx.z];
+    float* out = a.out[blockIdx.z];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, m = i & 63;
+        tile[c][m] = in[((long)b * a.C + c0 + c) * 64 + m];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int m = i >> 6, c = i & 63;
+        out[((long)b * 64 + m) * a.C + c0 + c] = tile[c][m];
+    }
+}
+
+// GroupNorm(32 groups, eps 1e-6, biased variance) over (8 channels x 64 tokens) of one sample
+// (transformer/attention.py:120-121,378,383): one wave per (sample, group), lane = token.
+struct GnArgs {
+    const float* x[2];
+    float* y[2];
+    const float *g, *be;
+    int B;
+};
+
+__global__ __launch_bounds__(256) void groupnorm_kernel(const GnArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0..31
+    const int b = blockIdx.y;
+    const float* x = a.x[blockIdx.z] + ((long)b * 64 + lane) * 256 + grp * 8;
+    float* y = a.y[blockIdx.z] + ((long)b * 64 + lane) * 256 + grp * 8;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(x), v = *reinterpret_cast<const f32x4*>(x + 4);
+    const float mean = wave_sum(u[0] + u[1] + u[2] + u[3] + v[0] + v[1] + v[2] + v[3]) * (1.0f / 512.0f);
+    const f32x4 du = u - mean, dv = v - mean;
+    const float var = wave_sum(du[0] * du[0] + du[1] * du[1] + du[2] * du[2] + du[3] * du[3] + dv[0] * dv[0] +
+                               dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.0f / 512.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.g + grp * 8), g1 = *reinterpret_cast<const f32x4*>(a.g + grp * 8 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.be + grp * 8), b1 = *reinterpret_cast<const f32x4*>(a.be + grp * 8 + 4);
+    *reinterpret_cast<f32x4*>(y) = du * rstd * g0 + b0;
+    *reinterpret_cast<f32x4*>(y + 4) = dv * rstd * g1 + b1;
+}
+
+// Generic finish: v = sum_ks P[ks][m][n] (+ bias[n]); relu on columns < relu_cols; + res[m][n]; + pe[m % 64][n];
+// stored as  layout 0: out[m][ldo] token-major
+//            layout 1: channel-last volume from tokens, out[b][d][h][w][c'] with token m = (b, h*8+w), n = c'*8 + d
+//                      (the reshape(bs, 32, 8, 8, 8) of modules/modules.py:97)
+//            layout 2: NCDHW, out[b][n][voxel] with row m = (b, voxel)            (the scorer's volume layout)
+struct FinProb {
+    const float* P;
+    const float* bias;
+    const float* res;
+    float* out;
+};
+struct FinArgs {
+    FinProb p[2];
+    const float* pe;
+    int KS, M, N, ldp, col0;  // P slabs are [KS][M][ldp]; columns col0 .. col0+N-1 are used
+    int relu_cols, ldres, ldo, layout;
+};
+
+__global__ __launch_bounds__(256) void finish_kernel(const FinArgs a)
+{
+    const FinProb pr = a.p[blockIdx.y];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = a.N >> 2;
+    if (i >= (long)a.M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    f32x4 v = pr.bias ? *reinterpret_cast<const f32x4*>(pr.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < a.KS; ++ks) v += *reinterpret_cast<const f32x4*>(pr.P + ((long)ks * a.M + m) * a.ldp + a.col0 + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (n + e < a.relu_cols) v[e] = fmaxf(v[e], 0.0f);
+    if (pr.res) v += *reinterpret_cast<const f32x4*>(pr.res + (long)m * a.ldres + n);
+    if (a.pe) v += *reinterpret_cast<const f32x4*>(a.pe + (long)(m & 63) * a.N + n);
+    if (a.layout == 0) {
+        *reinterpret_cast<f32x4*>(pr.out + (long)m * a.ldo + n) = v;
+    } else if (a.layout == 1) {
+        const int b = m >> 6, hw = m & 63, cp = n >> 3, d0 = n & 7;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pr.out[(((long)b * 8 + d0 + e) * 64 + hw) * 32 + cp] = v[e];
+    } else {
+        const int b = m >> 9, vox = m & 511;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pr.out[((long)b * a.N + n + e) * 512 + vox] = v[e];
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 struct LinSpec {
     const float* X;
@@ -284,7 +411,7 @@ struct LinSpec {
 };
 
 static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
-                                hipStream_t s)
+                                hipStream_t s, int mode = 0)
 {
     const bool wide = geglu_h > 0;  // the GEGLU projection: value tile + gate tile per workgroup
     const int cols = wide ? 32 : 16;
@@ -298,7 +425,11 @@ static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long 
         if (i < nprob) tiles += sp.N / cols;
     }
     const dim3 grid(tiles, KS, M / 64);
-    if (wide && Kw == 64 && KS == 1) hipLaunchKernelGGL((linear_kernel<2, 64, true>), grid, dim3(512), 0, s, a);
+    if (mode == 1 && Kw == 32) hipLaunchKernelGGL((linear_kernel<1, 32, false, 1>), grid, dim3(512), 0, s, a);
+    else if (mode == 2 && Kw == 32) hipLaunchKernelGGL((linear_kernel<1, 32, false, 2>), grid, dim3(512), 0, s, a);
+    else if (mode == 2 && Kw == 16) hipLaunchKernelGGL((linear_kernel<1, 16, false, 2>), grid, dim3(512), 0, s, a);
+    else if (mode != 0) return hipErrorInvalidValue;
+    else if (wide && Kw == 64 && KS == 1) hipLaunchKernelGGL((linear_kernel<2, 64, true>), grid, dim3(512), 0, s, a);
     else if (!wide && Kw == 64) hipLaunchKernelGGL((linear_kernel<1, 64, false>), grid, dim3(512), 0, s, a);
     else if (!wide && Kw == 32 && !geglu_h) hipLaunchKernelGGL((linear_kernel<1, 32, false>), grid, dim3(512), 0, s, a);
     else if (!wide && Kw == 16 && !geglu_h) hipLaunchKernelGGL((linear_kernel<1, 16, false>), grid, dim3(512), 0, s, a);
@@ -409,6 +540,123 @@ int transformer_blocks(const ahv_block_weights* blocks, int depth, float* x_src,
             if ((rc = run_block_pair(ww, xin, cin, false, out, M, w2, s, what))) return rc;
         }
     }
+    return 0;
+}
+
+// ---- whole forward_2d3d (modules/modules.py:86-101, inference form) --------------------------------------
+static const size_t kRowFloats = 768 + 2304 + 6 * 256 + 128 + 128;  // per token row and stream
+
+size_t forward_2d3d_workspace_floats(int B)
+{
+    const size_t M = (size_t)64 * (size_t)(B > 0 ? B : 0);
+    return 2 * M * kRowFloats + transformer_workspace_floats(B) + 64;
+}
+
+struct EncWs {
+    float *T0, *S, *E0, *H1, *Xin, *Gn, *Xs, *Vol0, *H3, *Skip;
+};
+
+static EncWs carve_enc(float* ws, size_t M, int which)
+{
+    float* b = ws + (size_t)which * M * kRowFloats;
+    EncWs w;
+    w.T0 = b;                 b += M * 768;
+    w.S = b;                  b += M * 2304;
+    w.E0 = b;                 b += M * 256;
+    w.H1 = b;                 b += M * 256;
+    w.Xin = b;                b += M * 256;
+    w.Gn = b;                 b += M * 256;
+    w.Xs = b;                 b += M * 256;
+    w.Vol0 = b;               b += M * 256;
+    w.H3 = b;                 b += M * 128;
+    w.Skip = b;
+    return w;
+}
+
+static hipError_t launch_finish(const float* const P[2], const float* const bias[2], const float* const res[2],
+                                float* const out[2], const float* pe, int KS, int M, int N, int ldp, int col0,
+                                int relu_cols, int ldres, int ldo, int layout, hipStream_t s)
+{
+    FinArgs a;
+    for (int i = 0; i < 2; ++i) a.p[i] = FinProb{P[i], bias ? bias[i] : nullptr, res ? res[i] : nullptr, out[i]};
+    a.pe = pe; a.KS = KS; a.M = M; a.N = N; a.ldp = ldp; a.col0 = col0;
+    a.relu_cols = relu_cols; a.ldres = ldres; a.ldo = ldo; a.layout = layout;
+    const long n = (long)M * (N / 4);
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+int forward_2d3d(const ahv_aligner_weights* w, const float* l4_src, const float* l4_tgt, int B, float* ws,
+                 float* vol_src, float* vol_tgt, hipStream_t s, const char** what)
+{
+    const int M = 64 * B, MV = 512 * B;
+    const EncWs e[2] = {carve_enc(ws, M, 0), carve_enc(ws, M, 1)};
+    float* tws = ws + 2 * (size_t)M * kRowFloats;
+    hipError_t err;
+#define AHV_TRY(call, name) do { err = (call); if (err != hipSuccess) { *what = name; return (int)err; } } while (0)
+#define PAIR(T, name, a0, a1) T const name[2] = {a0, a1}
+    {   // (B,768,8,8) -> tokens [M][768]
+        Nchw2TokArgs a;
+        a.in[0] = l4_src; a.in[1] = l4_tgt; a.out[0] = e[0].T0; a.out[1] = e[1].T0; a.C = 768; a.B = B;
+        hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(768 / 64, B, 2), dim3(256), 0, s, a);
+        AHV_TRY(hipGetLastError(), "layout");
+    }
+    PAIR(const float*, S, e[0].S, e[1].S);
+    PAIR(float*, E0, e[0].E0, e[1].E0);
+    PAIR(float*, H1, e[0].H1, e[1].H1);
+    PAIR(float*, Xin, e[0].Xin, e[1].Xin);
+    PAIR(float*, Xs, e[0].Xs, e[1].Xs);
+    PAIR(float*, Vol0, e[0].Vol0, e[1].Vol0);
+    PAIR(float*, H3, e[0].H3, e[1].H3);
+    PAIR(float*, Skip, e[0].Skip, e[1].Skip);
+    {   // feature_embedding: conv1x1 768->256, then res-block (conv3x3, relu, conv3x3, + skip), then + pos-emb
+        LinSpec sp[2];
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].T0, w->w_emb, e[i].S, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 768, 768, M, 768, 3, 0, s), "embedding conv1x1");
+        AHV_TRY(launch_finish(S, nullptr, nullptr, E0, nullptr, 3, M, 256, 256, 0, 0, 0, 256, 0, s), "embedding sum");
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].E0, w->w_conv1, e[i].S, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 256, 2304, M, 2304, 9, 0, s, 1), "res-block conv1");
+        AHV_TRY(launch_finish(S, nullptr, nullptr, H1, nullptr, 9, M, 256, 256, 0, 256, 0, 256, 0, s), "res-block relu");
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].H1, w->w_conv2, e[i].S, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 256, 2304, M, 2304, 9, 0, s, 1), "res-block conv2");
+        PAIR(const float*, resE0, e[0].E0, e[1].E0);
+        AHV_TRY(launch_finish(S, nullptr, resE0, Xin, w->posemb, 9, M, 256, 256, 0, 0, 256, 256, 0, s), "res-block skip + posemb");
+    }
+    {   // BidirectionTransformer: shared GroupNorm, per-stream proj_in, blocks, per-stream proj_out + residual
+        GnArgs g;
+        g.x[0] = e[0].Xin; g.x[1] = e[1].Xin; g.y[0] = e[0].Gn; g.y[1] = e[1].Gn; g.g = w->gn_g; g.be = w->gn_b; g.B = B;
+        hipLaunchKernelGGL(groupnorm_kernel, dim3(8, B, 2), dim3(256), 0, s, g);
+        AHV_TRY(hipGetLastError(), "groupnorm");
+        LinSpec sp[2];
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Gn, w->w_in[i], e[i].S, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 1, 0, s), "proj_in");
+        PAIR(const float*, bin, w->b_in[0], w->b_in[1]);
+        AHV_TRY(launch_finish(S, bin, nullptr, Xs, nullptr, 1, M, 256, 256, 0, 0, 0, 256, 0, s), "proj_in bias");
+        const int rc = transformer_blocks(w->blocks, w->depth, e[0].Xs, e[1].Xs, B, tws, s, what);
+        if (rc) return rc;
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Xs, w->w_out[i], e[i].S, nullptr, 256};
+        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 1, 0, s), "proj_out");
+        PAIR(const float*, bout, w->b_out[0], w->b_out[1]);
+        PAIR(const float*, resX, e[0].Xin, e[1].Xin);
+        // + bias + x_in, written as the channel-last volume [B][8][8][8][32] (channel 256 = c' * 8 + d)
+        AHV_TRY(launch_finish(S, bout, resX, Vol0, nullptr, 1, M, 256, 256, 0, 0, 256, 0, 1, s), "proj_out + residual");
+    }
+    {   // feature_embedding_3d: conv3d 32->16, relu, conv3d 16->16, + 1x1x1 skip (folded into conv1 as columns 16..31)
+        LinSpec sp[2];
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Vol0, w->w3d_1, e[i].S, nullptr, 32};
+        AHV_TRY(launch_linear(sp, 2, 32, 1024, MV, 1024, 4, 0, s, 2), "conv3d 1 + skip");
+        AHV_TRY(launch_finish(S, nullptr, nullptr, H3, nullptr, 4, MV, 16, 32, 0, 16, 0, 16, 0, s), "conv3d relu");
+        AHV_TRY(launch_finish(S, nullptr, nullptr, Skip, nullptr, 4, MV, 16, 32, 16, 0, 0, 16, 0, s), "conv3d skip");
+        PAIR(float*, S2, e[0].S + (size_t)MV * 32 * 4, e[1].S + (size_t)MV * 32 * 4);
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].H3, w->w3d_2, S2[i], nullptr, 16};
+        AHV_TRY(launch_linear(sp, 2, 16, 512, MV, 512, 4, 0, s, 2), "conv3d 2");
+        PAIR(const float*, S2c, S2[0], S2[1]);
+        PAIR(const float*, resS, e[0].Skip, e[1].Skip);
+        PAIR(float*, vout, vol_src, vol_tgt);
+        AHV_TRY(launch_finish(S2c, nullptr, resS, vout, nullptr, 4, MV, 16, 16, 0, 0, 16, 0, 2, s), "volume");
+    }
+#undef PAIR
+#undef AHV_TRY
     return 0;
 }
 

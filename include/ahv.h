@@ -194,6 +194,43 @@ size_t ahv_transformer_workspace_bytes(int B);
 int ahv_transformer_blocks_f32(const ahv_block_weights* blocks, int depth, float* x_src, float* x_tgt, int B,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * All weights of Feature_Aligner.forward_2d3d (modules/modules.py:49-110), device pointers, fp32.
+ * Convolution weights are repacked tap-major so that a convolution is an implicit GEMM over K = (tap, ci):
+ *   w_conv1/2 [256][2304] = feature_embedding.1.conv{1,2}.weight.permute(0,2,3,1)          k = (ky*3+kx)*256 + ci
+ *   w3d_1     [32][1024]  rows 0..15  = feature_embedding_3d.conv1.weight.permute(0,2,3,4,1), 27 taps padded to 32
+ *                         rows 16..31 = feature_embedding_3d.downsample.0.weight at tap 13 (the centre), else 0
+ *   w3d_2     [16][512]   = feature_embedding_3d.conv2.weight.permute(0,2,3,4,1), 27 taps padded to 32
+ * (bn_down exists in the reference state dict but is never applied, modules/modules.py:28-47.)
+ */
+typedef struct ahv_aligner_weights {
+    const float* w_emb;     /* [256][768]  feature_embedding.0.weight (1x1, no bias) */
+    const float* w_conv1;
+    const float* w_conv2;
+    const float* posemb;    /* [64][256]   posemb_sincos_2d(channel=256) token-major: [h*8+w][c] */
+    const float* gn_g;      /* [256] att.norm.weight  (one GroupNorm shared by both streams) */
+    const float* gn_b;      /* [256] att.norm.bias */
+    const float* w_in[2];   /* [256][256] att.proj_in.weight, att.proj_context_in.weight */
+    const float* b_in[2];   /* [256] */
+    const float* w_out[2];  /* [256][256] att.proj_out.weight, att.proj_context_out.weight */
+    const float* b_out[2];  /* [256] */
+    const float* w3d_1;
+    const float* w3d_2;
+    const ahv_block_weights* blocks; /* HOST array of 4*depth entries (see ahv_transformer_blocks_f32) */
+    int depth;
+} ahv_aligner_weights;
+
+size_t ahv_forward_2d3d_workspace_bytes(int B);
+
+/*
+ * Feature_Aligner.forward_2d3d(img_feat_src, img_feat_tgt, random_mask=False) (modules/modules.py:86-101):
+ * layer_4 features [B][768][8][8] x2 -> volumes [B][16][8][8][8] x2 (conv embedding + res-block, sin/cos
+ * position code, GroupNorm + proj_in, `depth` bidirectional transformer blocks, proj_out + residual, the
+ * reshape to (32,8,8,8), 3-D res-block).  Built for the reference's only configuration (768 -> 256, 4 heads).
+ */
+int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, const float* layer4_tgt, int B,
+                         void* workspace, size_t workspace_bytes, float* vol_src, float* vol_tgt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,16 +45,22 @@ def test_single_block_and_attention_against_modules(ahv, fa):
     assert torch.equal(xs, xs.clone())  # inputs untouched (the kernels work on copies)
 
 
-def test_forward_2d3d_hip_vs_torch_and_graph(fa):
-    g = torch.Generator().manual_seed(4)
-    a, b = torch.randn(1, 768, 8, 8, generator=g).cuda(), torch.randn(1, 768, 8, 8, generator=g).cuda()
+@pytest.mark.parametrize("B", [1, 2])
+def test_forward_2d3d_hip_vs_torch_and_graph(fa, B):
+    g = torch.Generator().manual_seed(4 + B)
+    a, b = torch.randn(B, 768, 8, 8, generator=g).cuda(), torch.randn(B, 768, 8, 8, generator=g).cuda()
     with torch.no_grad():
-        fa.att.use_hip = False
-        ref = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+        fa.use_hip_encoder = fa.att.use_hip = False
+        ref = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)   # stock torch operators
         fa.att.use_hip = True
-        got = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
-    for x, y in zip(got, ref):
-        assert rel(x, y) < 2e-5
+        mid = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)   # HIP token stage only
+        fa.use_hip_encoder = True
+        got = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)   # everything on the HIP kernels
+    for x, y, z in zip(got, ref, mid):
+        assert x.shape == (B, 16, 8, 8, 8)
+        assert rel(z, y) < 2e-5 and rel(x, y) < 2e-5
+    if B != 1:
+        return
     run = fa.graphed_forward_2d3d(batch=1)  # the HIP launches are captured into the hipGraph too
     out = run(a, b)
     for x, y in zip(out, ref):
