@@ -26,6 +26,113 @@ from . import ops
 _PACKED = weakref.WeakKeyDictionary()
 
 
+
+# ----------------------------------------------------------------------------- weight packing for the C ABI
+# These work on ANY module tree with the reference's attribute names (this file's mirror or the reference's
+# own Feature_Aligner / BidirectionTransformer), which is what lets patch.install() rebind forward_2d3d.
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_transformer(att, device):
+    """ahv_block_weights table: per layer attn_self_1, attn_self_2, attn_cross_1, attn_cross_2; q|k|v weights
+    concatenated to one [768][256] matrix (one GEMM for self-attention, row slices for cross-attention)."""
+    from . import _lib
+    keep, table = [], (_lib.BlockWeights * (4 * len(att.transformer_blocks)))()
+    i = 0
+    for layer in att.transformer_blocks:
+        for blk in (layer.attn_self_1, layer.attn_self_2, layer.attn_cross_1, layer.attn_cross_2):
+            a, ff = blk.attn, blk.ff
+            tensors = dict(
+                w_qkv=torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dim=0),
+                w_out=a.to_out[0].weight, b_out=a.to_out[0].bias, ln1_g=blk.norm1.weight, ln1_b=blk.norm1.bias,
+                w_ff1=ff.net[0].proj.weight, b_ff1=ff.net[0].proj.bias, w_ff2=ff.net[2].weight,
+                b_ff2=ff.net[2].bias, ln2_g=blk.norm2.weight, ln2_b=blk.norm2.bias)
+            for name, t in tensors.items():
+                t = _f32(t, device)
+                keep.append(t)
+                setattr(table[i], name, t.data_ptr())
+            i += 1
+    _PACKED[att] = (table, keep, device)
+    return _PACKED[att]
+
+
+def posemb_sincos_2d_tokens(channel: int, device, temperature: float = 10000.0) -> torch.Tensor:
+    """modules/modules.py:72-84 evaluated on the 8x8 grid, token-major [h*8+w][channel]."""
+    n = channel // 4
+    omega = 1.0 / (temperature ** (torch.arange(n, device=device) / (n - 1)))
+    ys, xs = torch.meshgrid(torch.arange(8, device=device), torch.arange(8, device=device), indexing="ij")
+    ay, ax = ys[None] * omega[:, None, None], xs[None] * omega[:, None, None]
+    pe = torch.cat((ax.sin(), ax.cos(), ay.sin(), ay.cos()), dim=0).type(torch.float32)
+    return pe.reshape(channel, 64).t().contiguous()
+
+
+def pack_aligner(fa, device):
+    """ahv_aligner_weights (include/ahv.h): conv weights repacked tap-major, the 1x1x1 skip of the 3-D
+    res-block folded into its first convolution as 16 extra output rows."""
+    from . import _lib
+    blocks, keep_b, _ = pack_transformer(fa.att, device)
+    rb2, rb3 = fa.feature_embedding[1], fa.feature_embedding_3d
+    dev0 = rb3.conv1.weight.device
+    w3d_1 = torch.zeros(32, 32, 32, dtype=torch.float32, device=dev0)  # [row][tap padded to 32][ci]
+    w3d_1[:16, :27] = rb3.conv1.weight.detach().permute(0, 2, 3, 4, 1).reshape(16, 27, 32)
+    w3d_1[16:, 13] = rb3.downsample[0].weight.detach().reshape(16, 32)  # centre tap (1,1,1) = 1*9 + 1*3 + 1
+    w3d_2 = torch.zeros(16, 32, 16, dtype=torch.float32, device=dev0)
+    w3d_2[:, :27] = rb3.conv2.weight.detach().permute(0, 2, 3, 4, 1).reshape(16, 27, 16)
+    tensors = dict(
+        w_emb=fa.feature_embedding[0].weight.reshape(256, 768),
+        w_conv1=rb2.conv1.weight.permute(0, 2, 3, 1).reshape(256, 2304),
+        w_conv2=rb2.conv2.weight.permute(0, 2, 3, 1).reshape(256, 2304),
+        posemb=posemb_sincos_2d_tokens(256, dev0), gn_g=fa.att.norm.weight, gn_b=fa.att.norm.bias,
+        w3d_1=w3d_1.reshape(32, 1024), w3d_2=w3d_2.reshape(16, 512))
+    pairs = dict(w_in=(fa.att.proj_in.weight.reshape(256, 256), fa.att.proj_context_in.weight.reshape(256, 256)),
+                 b_in=(fa.att.proj_in.bias, fa.att.proj_context_in.bias),
+                 w_out=(fa.att.proj_out.weight.reshape(256, 256), fa.att.proj_context_out.weight.reshape(256, 256)),
+                 b_out=(fa.att.proj_out.bias, fa.att.proj_context_out.bias))
+    aw, keep = _lib.AlignerWeights(), [keep_b]
+    for name, t in tensors.items():
+        t = _f32(t, device)
+        keep.append(t)
+        setattr(aw, name, t.data_ptr())
+    for name, (a, b) in pairs.items():
+        ta, tb = _f32(a, device), _f32(b, device)
+        keep += [ta, tb]
+        arr = getattr(aw, name)
+        arr[0], arr[1] = ta.data_ptr(), tb.data_ptr()
+    aw.blocks, aw.depth = blocks, len(fa.att.transformer_blocks)
+    _PACKED[fa] = (aw, keep, device)
+    return _PACKED[fa]
+
+
+@torch.no_grad()
+def hip_forward_2d3d(fa, src, tgt):
+    """forward_2d3d(random_mask=False) of `fa` (mirror or reference module) through ahv_forward_2d3d_f32."""
+    import ctypes
+    from . import _lib
+    packed = _PACKED.get(fa)
+    if packed is None or packed[2] != src.device or _PACKED.get(fa.att) is None:
+        packed = pack_aligner(fa, src.device)
+    B = src.shape[0]
+    lib = _lib.load()
+    nbytes = lib.ahv_forward_2d3d_workspace_bytes(B)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=src.device)
+    vol_src = torch.empty((B, 16, 8, 8, 8), dtype=torch.float32, device=src.device)
+    vol_tgt = torch.empty_like(vol_src)
+    _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed[0]), src.detach().contiguous().data_ptr(),
+                                        tgt.detach().contiguous().data_ptr(), B, ws.data_ptr(), nbytes,
+                                        vol_src.data_ptr(), vol_tgt.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "ahv_forward_2d3d_f32")
+    return vol_src, vol_tgt
+
+
+def invalidate_packed(module):
+    """Forget the packed weight tables of `module` (after its parameters changed)."""
+    _PACKED.pop(module, None)
+    att = getattr(module, "att", None)
+    if att is not None:
+        _PACKED.pop(att, None)
+
+
 # ----------------------------------------------------------------------------- encoder pieces
 class _GatedProj(nn.Module):
     """GEGLU input projection (transformer/attention.py:81-88): Linear -> (x, gate) -> x * gelu(gate)."""
@@ -138,26 +245,7 @@ class BidirectionTransformer(nn.Module):
                 and self.n_heads == 4 and self.d_head == 64 and xs.shape[1] == 64 and not torch.is_grad_enabled())
 
     def _pack(self, device):
-        """ahv_block_weights table: per layer attn_self_1, attn_self_2, attn_cross_1, attn_cross_2; q|k|v
-        weights concatenated to one [768][256] matrix (one GEMM for self-attention, row slices for cross)."""
-        from . import _lib
-        keep, table = [], (_lib.BlockWeights * (4 * len(self.transformer_blocks)))()
-        i = 0
-        for layer in self.transformer_blocks:
-            for blk in (layer.attn_self_1, layer.attn_self_2, layer.attn_cross_1, layer.attn_cross_2):
-                a, ff = blk.attn, blk.ff
-                tensors = dict(
-                    w_qkv=torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dim=0),
-                    w_out=a.to_out[0].weight, b_out=a.to_out[0].bias, ln1_g=blk.norm1.weight, ln1_b=blk.norm1.bias,
-                    w_ff1=ff.net[0].proj.weight, b_ff1=ff.net[0].proj.bias, w_ff2=ff.net[2].weight,
-                    b_ff2=ff.net[2].bias, ln2_g=blk.norm2.weight, ln2_b=blk.norm2.bias)
-                for name, t in tensors.items():
-                    t = t.detach().to(device=device, dtype=torch.float32).contiguous()
-                    keep.append(t)
-                    setattr(table[i], name, t.data_ptr())
-                i += 1
-        _PACKED[self] = (table, keep, device)
-        return _PACKED[self]
+        return pack_transformer(self, device)
 
     def _hip_blocks(self, xs, cs):
         from . import _lib
@@ -260,59 +348,10 @@ class Feature_Aligner(nn.Module):
                 and self.att.n_heads == 4)
 
     def _pack_aligner(self, device):
-        from . import _lib
-        blocks, keep_b, _ = self.att._pack(device)
-        rb2, rb3 = self.feature_embedding[1], self.feature_embedding_3d
-        c1 = rb3.conv1.weight.permute(0, 2, 3, 4, 1).reshape(16, 27, 32)
-        w3d_1 = torch.zeros(32, 32, 32, dtype=torch.float32, device=c1.device)  # [row][tap padded to 32][ci]
-        w3d_1[:16, :27] = c1
-        w3d_1[16:, 13] = rb3.downsample[0].weight.reshape(16, 32)  # centre tap (1,1,1) = 1*9 + 1*3 + 1
-        w3d_2 = torch.zeros(16, 32, 16, dtype=torch.float32, device=c1.device)
-        w3d_2[:, :27] = rb3.conv2.weight.permute(0, 2, 3, 4, 1).reshape(16, 27, 16)
-        pe = self.posemb_sincos_2d(torch.empty(1, 1, 8, 8, device=c1.device), channel=self.mid_channel)
-        tensors = dict(
-            w_emb=self.feature_embedding[0].weight.reshape(256, 768),
-            w_conv1=rb2.conv1.weight.permute(0, 2, 3, 1).reshape(256, 2304),
-            w_conv2=rb2.conv2.weight.permute(0, 2, 3, 1).reshape(256, 2304),
-            posemb=pe.reshape(256, 64).t(), gn_g=self.att.norm.weight, gn_b=self.att.norm.bias,
-            w3d_1=w3d_1.reshape(32, 1024), w3d_2=w3d_2.reshape(16, 512))
-        pairs = dict(w_in=(self.att.proj_in.weight, self.att.proj_context_in.weight),
-                     b_in=(self.att.proj_in.bias, self.att.proj_context_in.bias),
-                     w_out=(self.att.proj_out.weight, self.att.proj_context_out.weight),
-                     b_out=(self.att.proj_out.bias, self.att.proj_context_out.bias))
-        aw, keep = _lib.AlignerWeights(), [keep_b]
-        conv = lambda t: t.detach().to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous() \
-            if t.dim() > 1 else t.detach().to(device=device, dtype=torch.float32).contiguous()
-        for name, t in tensors.items():
-            t = conv(t)
-            keep.append(t)
-            setattr(aw, name, t.data_ptr())
-        for name, (a, b) in pairs.items():
-            ta, tb = conv(a), conv(b)
-            keep += [ta, tb]
-            arr = getattr(aw, name)
-            arr[0], arr[1] = ta.data_ptr(), tb.data_ptr()
-        aw.blocks, aw.depth = blocks, len(self.att.transformer_blocks)
-        _PACKED[self] = (aw, keep, device)
-        return _PACKED[self]
+        return pack_aligner(self, device)
 
     def _hip_forward_2d3d(self, src, tgt):
-        from . import _lib
-        packed = _PACKED.get(self)
-        if packed is None or packed[2] != src.device or _PACKED.get(self.att) is None:
-            packed = self._pack_aligner(src.device)
-        B = src.shape[0]
-        lib = _lib.load()
-        nbytes = lib.ahv_forward_2d3d_workspace_bytes(B)
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=src.device)
-        vol_src = torch.empty((B, 16, 8, 8, 8), dtype=torch.float32, device=src.device)
-        vol_tgt = torch.empty_like(vol_src)
-        import ctypes
-        _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed[0]), src.contiguous().data_ptr(),
-                                            tgt.contiguous().data_ptr(), B, ws.data_ptr(), nbytes, vol_src.data_ptr(),
-                                            vol_tgt.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                   "ahv_forward_2d3d_f32")
-        return vol_src, vol_tgt
+        return hip_forward_2d3d(self, src, tgt)
 
     def forward_2d3d(self, img_feat_src, img_feat_tgt, random_mask=True, mask_ratio=0.25):
         """(B,in,8,8) x2 -> (B,16,8,8,8) x2 (modules/modules.py:86-110)."""

@@ -3,6 +3,7 @@ path (option A):
 
     utils.rotate_volume                          -> 3dahv_amd.ops.rotate_volume        (utils.py:113-131)
     modules.modules.Feature_Aligner.forward_3d2d -> HIP head kernel                    (modules/modules.py:112-124)
+    modules.modules.Feature_Aligner.forward_2d3d -> HIP encoder (inference calls only) (modules/modules.py:86-110)
 
 Usage from the reference's checkout, before the script's own imports bind the names:
 
@@ -26,6 +27,18 @@ def _hip_forward_3d2d(self, img_feat):
     return ops.forward_3d2d(img_feat, c1.weight, c2.weight, c2.bias)
 
 
+def _hip_forward_2d3d(self, img_feat_src, img_feat_tgt, random_mask=True, mask_ratio=0.25):
+    """The reference module's own weights, packed once for the C ABI; training-style calls (autograd on,
+    or random_mask=True) fall through to the reference implementation."""
+    import torch
+    from .aligner import hip_forward_2d3d
+    ok = (img_feat_src.is_cuda and not torch.is_grad_enabled() and random_mask is not True
+          and tuple(img_feat_src.shape[1:]) == (768, 8, 8) and getattr(self, "mid_channel", 0) == 256)
+    if not ok:
+        return _saved["forward_2d3d"][1](self, img_feat_src, img_feat_tgt, random_mask, mask_ratio)
+    return hip_forward_2d3d(self, img_feat_src, img_feat_tgt)
+
+
 def install(utils_module=None, modules_module=None):
     """Patch the reference's modules (already imported, importable from sys.path, or passed in)."""
     if utils_module is None:
@@ -35,8 +48,12 @@ def install(utils_module=None, modules_module=None):
     if "rotate_volume" not in _saved:
         _saved["rotate_volume"] = (utils_module, utils_module.rotate_volume)
         _saved["forward_3d2d"] = (modules_module.Feature_Aligner, modules_module.Feature_Aligner.forward_3d2d)
+        if hasattr(modules_module.Feature_Aligner, "forward_2d3d"):
+            _saved["forward_2d3d"] = (modules_module.Feature_Aligner, modules_module.Feature_Aligner.forward_2d3d)
     utils_module.rotate_volume = ops.rotate_volume
     modules_module.Feature_Aligner.forward_3d2d = _hip_forward_3d2d
+    if "forward_2d3d" in _saved:
+        modules_module.Feature_Aligner.forward_2d3d = _hip_forward_2d3d
     # scripts that did `from utils import *` / `from utils import rotate_volume` earlier hold their own binding
     for mod in list(sys.modules.values()):
         if mod is not None and getattr(mod, "rotate_volume", None) is _saved["rotate_volume"][1]:
@@ -54,3 +71,6 @@ def uninstall():
     um.rotate_volume = f
     cls, g = _saved.pop("forward_3d2d")
     cls.forward_3d2d = g
+    if "forward_2d3d" in _saved:
+        cls2, h = _saved.pop("forward_2d3d")
+        cls2.forward_2d3d = h

@@ -79,3 +79,35 @@ def test_state_dict_reload_invalidates_packed_weights(fa):
         m.att.use_hip = False
         y2, _ = m.att(x, x)
     assert rel(y1, y2) < 2e-5 and rel(y0, y2) > 1e-4
+
+
+def test_patch_rebinds_forward_2d3d_of_a_reference_shaped_module(ahv, fa):
+    """patch.install() on a stand-in `modules.modules`: a class with the reference's attribute names whose own
+    forward_2d3d runs stock torch operators; after patching, inference calls go through ahv_forward_2d3d_f32."""
+    import copy
+    import types
+
+    class RefAligner(ahv.aligner.Feature_Aligner):  # torch-operator forward, like the reference's class
+        def forward_2d3d(self, a, b, random_mask=True, mask_ratio=0.25):
+            self.use_hip_encoder = self.att.use_hip = False
+            return super().forward_2d3d(a, b, random_mask, mask_ratio)
+
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+    mm.Feature_Aligner = RefAligner
+    ref = RefAligner(768, 256, 32, 4, 4).cuda().eval()
+    ref.load_state_dict(fa.state_dict())
+    g = torch.Generator().manual_seed(11)
+    a, b = torch.randn(1, 768, 8, 8, generator=g).cuda(), torch.randn(1, 768, 8, 8, generator=g).cuda()
+    with torch.no_grad():
+        want = ref.forward_2d3d(a, b, random_mask=False, mask_ratio=0)
+        ahv.patch.install(um, mm)
+        try:
+            assert RefAligner.forward_2d3d is ahv.patch._hip_forward_2d3d
+            got = ref.forward_2d3d(a, b, random_mask=False, mask_ratio=0)
+            masked = ref.forward_2d3d(a, b)  # training-style call falls through to the original
+        finally:
+            ahv.patch.uninstall()
+    for x, y in zip(got, want):
+        assert rel(x, y) < 2e-5
+    assert masked[0].shape == (1, 16, 8, 8, 8)
