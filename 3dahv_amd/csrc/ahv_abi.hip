@@ -22,6 +22,7 @@ hipError_t launch_compose_rotations(const uint64_t*, const float*, int64_t, int6
                                     int, float*, hipStream_t);
 hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*,
                                   int64_t*, hipStream_t);
+hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 extern int g_score_variant;
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
@@ -245,6 +246,16 @@ int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, 
     const int rc = ahv::forward_2d3d(w, layer4_src, layer4_tgt, B, static_cast<float*>(workspace), vol_src, vol_tgt,
                                      static_cast<hipStream_t>(stream), &what);
     if (rc != 0) return fail(AHV_ELAUNCH, "forward_2d3d: %s: %s", what, hipGetErrorString((hipError_t)rc));
+    return AHV_OK;
+}
+
+int ahv_random_rotations_f32(uint64_t seed, uint64_t offset, int64_t N, float* out, void* stream)
+{
+    if (N < 0) return fail(AHV_EINVAL, "random_rotations: negative N");
+    if (N == 0) return AHV_OK;
+    if (!out) return fail(AHV_EINVAL, "random_rotations: null pointer");
+    hipError_t e = ahv::launch_random_rotations(seed, offset, N, out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("random_rotations: launch", e);
     return AHV_OK;
 }
 

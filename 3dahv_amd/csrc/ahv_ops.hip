@@ -378,6 +378,49 @@ __global__ void select_rotation_kernel(const unsigned long long* __restrict__ be
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Haar-uniform rotation hypotheses generated on the device (replaces the host call
+// pytorch3d.transforms.random_rotations(N), test_co3d.py:106 / modules/model.py:184; only the
+// distribution matters -- hypotheses are inputs of the hot path).  Counter-based: rotation n
+// depends on (seed, offset + n) alone, so any shard of the set can be generated anywhere,
+// reproducibly, and the call is graph-capturable.  Philox-4x32-10 -> 4 uniforms -> Box-Muller
+// -> normalised Gaussian quaternion -> matrix.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void random_rotations_kernel(unsigned long long seed, unsigned long long offset, long N,
+                                                               float* __restrict__ out)
+{
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const unsigned long long ctr = offset + (unsigned long long)n;
+    unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0x3D4148u, 0u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    // uniforms in (0,1]: never log(0)
+    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530717958647692f * u1, &s0, &c0);
+    sincosf(6.28318530717958647692f * u3, &s1, &c1);
+    const float qr = r0 * c0, qi = r0 * s0, qj = r1 * c1, qk = r1 * s1;
+    const float t = 2.0f / fmaxf(qr * qr + qi * qi + qj * qj + qk * qk, 1e-30f);
+    float* o = out + n * 9;
+    o[0] = 1.0f - t * (qj * qj + qk * qk); o[1] = t * (qi * qj - qk * qr);        o[2] = t * (qi * qk + qj * qr);
+    o[3] = t * (qi * qj + qk * qr);        o[4] = 1.0f - t * (qi * qi + qk * qk); o[5] = t * (qj * qk - qi * qr);
+    o[6] = t * (qi * qk - qj * qr);        o[7] = t * (qj * qk + qi * qr);        o[8] = 1.0f - t * (qi * qi + qj * qj);
+}
+
 // ---- launchers ----------------------------------------------------------------------
 hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C,
                                 int D, int H, int W, float* out, int num_cu, hipStream_t stream)
@@ -453,6 +496,13 @@ hipError_t launch_select_rotation(const uint64_t* best_key, const float* R, int6
     hipLaunchKernelGGL(select_rotation_kernel, dim3((B + 63) / 64), dim3(64), 0, stream,
                        reinterpret_cast<const unsigned long long*>(best_key), R, (long)r_batch_stride,
                        (long)n_offset, (long)N, B, R_out, best_score, reinterpret_cast<long*>(best_idx));
+    return hipGetLastError();
+}
+
+hipError_t launch_random_rotations(uint64_t seed, uint64_t offset, int64_t N, float* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(random_rotations_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream,
+                       (unsigned long long)seed, (unsigned long long)offset, (long)N, out);
     return hipGetLastError();
 }
 

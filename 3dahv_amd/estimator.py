@@ -66,6 +66,7 @@ class _EstimatorBase(nn.Module):
         self.gt_dis = []
         self.pred_Rs = []
         self.logged = {}  # stands in for Lightning's self.log
+        self._proposal_draws = 0
 
     # -- reference: modules/model_co3d.py:37-39, modules/model.py:39-41
     def feature_extraction(self, img):
@@ -80,6 +81,14 @@ class _EstimatorBase(nn.Module):
     def forward_features(self, layer4_src, layer4_tgt):
         """Everything after the backbone: (B,768,8,8) x2 -> volumes (B,16,8,8,8) x2."""
         return self.feature_aligner.forward_2d3d(layer4_src, layer4_tgt, random_mask=False, mask_ratio=0.0)
+
+    def fresh_proposals(self, device):
+        """`random_rotations(self.num_rota)` of the reference steps (modules/model.py:184): a fresh Haar set per
+        call, generated on the GPU (counter-based, seeded by torch's global seed and a draw counter)."""
+        self._proposal_draws += 1
+        if torch.device(device).type == "cuda":
+            return ops.random_rotations(self.num_rota, seed=torch.initial_seed() + self._proposal_draws, device=device)
+        return random_rotations(self.num_rota, device=device)
 
     def log(self, name, value, **_):
         self.logged.setdefault(name, []).append(float(value))
@@ -145,7 +154,7 @@ class EstimatorObjaverse(_EstimatorBase):
         vol_src, vol_tgt = self.forward(img_src, mask_src, img_tgt, mask_tgt)
         gt_src_2_tgt_R = torch.bmm(R_tgt, torch.inverse(R_src))
         if proposals is None:
-            proposals = random_rotations(self.num_rota, device=img_src.device)
+            proposals = self.fresh_proposals(img_src.device)
         _, _, _, pred_R = self.verify(vol_src, vol_tgt, proposals)
         geo_dis = geodesic_deg(pred_R, gt_src_2_tgt_R)
         gt_dis = geodesic_deg(R_src, R_tgt)
@@ -164,7 +173,7 @@ class EstimatorObjaverse(_EstimatorBase):
         vol_src, vol_tgt = self.forward(img_src, mask_src, img_tgt, mask_tgt)
         gt_src_2_tgt_R = torch.bmm(R_tgt, torch.inverse(R_src))
         if proposals is None:
-            proposals = random_rotations(self.num_rota, device=img_src.device)
+            proposals = self.fresh_proposals(img_src.device)
         _, pred_sim, _, pred_R = self.verify(vol_src, vol_tgt, proposals)
         # gt_sim: each sample's own GT rotation = per-sample R with N = 1 (modules/model.py:137-143)
         f_tgt = self.feature_aligner.forward_3d2d(vol_tgt)

@@ -222,3 +222,18 @@ def compose_rotations(best_key: torch.Tensor, R: torch.Tensor, D: torch.Tensor, 
     _lib.check(lib.ahv_compose_rotations_f32(best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, Dc.data_ptr(),
                                              N2, B, out.data_ptr(), _stream()), "ahv_compose_rotations_f32")
     return out
+
+
+@torch.no_grad()
+def random_rotations(n: int, seed: int = 0, offset: int = 0, device=None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Drop-in for ``pytorch3d.transforms.random_rotations(n)`` generated on the GPU: Haar-uniform (n,3,3) fp32.
+    Rotation i depends only on ``(seed, offset + i)``: ``random_rotations(n, s)[a:b]`` equals
+    ``random_rotations(b - a, s, offset=a)``, so every rank can generate its own shard."""
+    if out is None:
+        out = torch.empty((n, 3, 3), dtype=torch.float32, device=device if device is not None else "cuda")
+    if not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * 9:
+        raise RuntimeError("out must be a contiguous float32 GPU tensor of n*9 elements")
+    lib = _lib.load()
+    _lib.check(lib.ahv_random_rotations_f32(seed & (2**64 - 1), offset, n, out.data_ptr(), _stream()),
+               "ahv_random_rotations_f32")
+    return out

@@ -161,6 +161,14 @@ int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t 
                               int64_t N, const float* D, int64_t N2, int B, float* out, void* stream);
 
 /*
+ * N Haar-uniform rotation matrices out [N][3][3], generated on the device; replaces the host call
+ * pytorch3d.transforms.random_rotations(N) (test_co3d.py:106, modules/model.py:184).  Counter-based
+ * (Philox-4x32-10): rotation n is a function of (seed, offset + n) only, so shards of one hypothesis set can
+ * be generated independently on different GPUs (offset = first global index of the shard).
+ */
+int ahv_random_rotations_f32(uint64_t seed, uint64_t offset, int64_t N, float* out, void* stream);
+
+/*
  * Weights of one BasicTransformerBlock of the reference's encoder (transformer/attention.py:240-258),
  * device pointers, fp32, torch layouts (Linear weight = [out][in]).  State-dict names in comments.
  */

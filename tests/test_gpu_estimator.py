@@ -157,3 +157,12 @@ def test_graphed_encoder_matches_eager(ahv, dev):
         got = run(a, b)
         for x, y in zip(got, ref):
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-5)
+
+
+def test_test_step_default_proposals_are_device_haar(ahv, model_obj, dev):
+    b = batch(dev, 2, seed=9)
+    n0 = len(model_obj.step_outputs)
+    geo = model_obj.test_step(b, 0)  # no proposals given: fresh Haar set generated on the GPU
+    assert geo.shape == (2,) and len(model_obj.step_outputs) == n0 + 1
+    P1, P2 = model_obj.fresh_proposals(dev), model_obj.fresh_proposals(dev)
+    assert P1.shape == (model_obj.num_rota, 3, 3) and P1.is_cuda and not torch.equal(P1, P2)

@@ -333,3 +333,21 @@ def test_fused_kernel_variants_agree(ops, ahv, G, g128, variant):
         assert score_relerr(s2.cpu().numpy(), g["scores_per"]) < SCORE_RTOL
     finally:
         lib.ahv_set_option(b"score_variant", prev)
+
+
+def test_device_haar_sampler(ops, dev):
+    R = ops.random_rotations(200000, seed=7, device=dev)
+    Rd = R.double()
+    eye = torch.eye(3, dtype=torch.float64, device=dev)
+    assert (Rd @ Rd.transpose(1, 2) - eye).abs().max().item() < 5e-6       # orthonormal
+    assert (torch.linalg.det(Rd) - 1).abs().max().item() < 5e-6            # proper rotations
+    tr = Rd.diagonal(dim1=1, dim2=2).sum(-1)
+    ang = torch.arccos(((tr - 1) / 2).clamp(-1, 1))
+    assert abs(tr.mean().item()) < 0.01                                    # Haar: E[trace] = 0
+    assert abs(ang.mean().item() - (np.pi / 2 + 2 / np.pi)) < 0.01        # Haar: E[angle] = pi/2 + 2/pi
+    for col in range(3):                                                   # columns uniform on the sphere
+        assert Rd[:, :, col].mean(0).abs().max().item() < 0.01
+    # counter-based: shards reproduce slices of the whole set; other seeds differ
+    assert torch.equal(ops.random_rotations(1000, seed=7, offset=50000, device=dev), R[50000:51000])
+    assert not torch.equal(ops.random_rotations(1000, seed=8, device=dev), R[:1000])
+    assert ops.random_rotations(0, device=dev).shape == (0, 3, 3)
