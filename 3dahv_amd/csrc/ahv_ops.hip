@@ -3,6 +3,7 @@
 // (rotate_volume -> forward_3d2d -> mul/sum/mean -> max) runs unchanged on HIP.
 // These are the HBM-bound siblings of the fused scorer (ahv_score.hip).
 #include "ahv_device.h"
+#include "ahv_dual.h"
 
 namespace ahv {
 
@@ -171,6 +172,74 @@ __global__ __launch_bounds__(kF32Threads, 1) void forward_3d2d_kernel(
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             const float nrm = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize clamp_min(eps)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16] = v[m2][t][r] / nrm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward_3d2d, throughput path: the "dual" structure of the fused scorer (ahv_dual.h): 512 threads = two
+// waves per SIMD, one item per wave, W1 as an LDS fragment table, one 8-KiB quarter image per wave filled
+// straight from HBM (next quarter's loads are in flight while the current one is contracted).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
+    const float* __restrict__ vol, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, long M, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
+    __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* buf = lds_q + wave * kQuarterFloats;
+    stage_w1_table(lds_w1, W1, tid, 512);
+    DualFrags f;
+    load_dual_frags(f, W2, b2, lane);
+    __syncthreads();
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int i2 = 2 * lane, sa0 = i2 >> 6, sb = (i2 >> 3) & 7, se = i2 & 7;
+    const int o0 = qoff(sa0, sb, se), o1 = qoff(sa0, sb, se + 1);
+    for (long m = (long)wave * gridDim.x + blockIdx.x; m < M; m += (long)gridDim.x * 8) {
+        const float* V = vol + m * (16 * 512) + i2;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 cur[16], nxt[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cur[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(V + c * 512));
+#define AHV_F3_QUARTER(Q)                                                                                   \
+        if (Q < 3) {                                                                                        \
+            _Pragma("unroll") for (int c = 0; c < 16; ++c)                                                  \
+                nxt[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(V + c * 512 + (Q + 1) * 128)); \
+        }                                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 16; ++c) { buf[c * 128 + o0] = cur[c][0]; buf[c * 128 + o1] = cur[c][1]; } \
+        wave_lds_fence();                                                                                   \
+        gemm1_quarter_lds<Q>(acc, lds_w1, buf, lane);                                                       \
+        wave_lds_fence();                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 16; ++c) cur[c] = nxt[c];
+        AHV_F3_QUARTER(0)
+        AHV_F3_QUARTER(1)
+        AHV_F3_QUARTER(2)
+        AHV_F3_QUARTER(3)
+#undef AHV_F3_QUARTER
+        f32x4 v[2][4];
+        gemm2_dual(v, acc, f);
+        float* o = out + m * (32 * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss += v[m2][t][r] * v[m2][t][r];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
@@ -458,6 +527,13 @@ hipError_t launch_forward_3d2d(const float* vol, const float* W1, const float* W
     }
     if (M <= 64) {  // latency path: one workgroup per item, quarters split over its 4 waves
         hipLaunchKernelGGL(forward_3d2d_small_kernel, dim3((unsigned)M), dim3(256), 0, stream, vol, W1, W2, b2, out);
+        return hipGetLastError();
+    }
+    if (M >= 4096) {  // throughput path
+        long blocks = (M + 7) / 8;
+        if (blocks > num_cu) blocks = num_cu;
+        hipLaunchKernelGGL(forward_3d2d_dual_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, vol, W1, W2, b2,
+                           (long)M, out);
         return hipGetLastError();
     }
     long blocks = (M + 3) / 4;

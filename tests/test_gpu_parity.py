@@ -351,3 +351,16 @@ def test_device_haar_sampler(ops, dev):
     assert torch.equal(ops.random_rotations(1000, seed=7, offset=50000, device=dev), R[50000:51000])
     assert not torch.equal(ops.random_rotations(1000, seed=8, device=dev), R[:1000])
     assert ops.random_rotations(0, device=dev).shape == (0, 3, 3)
+
+
+def test_forward_3d2d_throughput_path_matches_small_paths(ops, oracle, G, g128, ahv, dev):
+    """M >= 4096 takes the two-waves-per-SIMD kernel; same results as the oracle and as the other paths."""
+    R = to_dev(ahv.rotations.haar_rotations_np(5000, 77), dev)
+    rot = ops.rotate_volume(G["vol_src"][0][None].expand(5000, -1, -1, -1, -1), R)
+    big = ops.forward_3d2d(rot, G["W1"], G["W2"], G["b2"])            # dual kernel
+    mid = ops.forward_3d2d(rot[:1000], G["W1"], G["W2"], G["b2"])     # register-resident W1 kernel
+    small = ops.forward_3d2d(rot[:8], G["W1"], G["W2"], G["b2"])      # latency kernel
+    assert tensor_relerr(big[:1000].cpu().numpy(), mid.cpu().numpy()) < 1e-6
+    assert tensor_relerr(big[:8].cpu().numpy(), small.cpu().numpy()) < 1e-6
+    ref = oracle.forward_3d2d(rot[4990:].cpu().numpy(), g128["W1"], g128["W2"], g128["b2"])
+    assert tensor_relerr(big[4990:].cpu().numpy(), ref) < TENSOR_RTOL
