@@ -175,6 +175,67 @@ __device__ __forceinline__ void tri_blend(float (&out)[16], const float* srcT, c
     }
 }
 
+// Byte-offset form of the same coefficients: the corner rows come out as LDS pointers (no index -> byte
+// conversion per corner, one integer multiply per axis neighbour).
+struct TriCoefP {
+    float w[8];
+    const float* p[8];
+};
+
+__device__ __forceinline__ void axis_coef_bytes(float g, float& w0, float& w1, int& o0, int& o1, int scale_bytes)
+{
+    float i = ((g + 1.0f) * 8.0f - 1.0f) * 0.5f;
+    i = fminf(fmaxf(i, -2.0f), 9.0f);
+    const float fl = floorf(i);
+    const float t = i - fl;
+    const int i0 = (int)fl;
+    const int i1 = i0 + 1;
+    w0 = ((unsigned)i0 < 8u) ? 1.0f - t : 0.0f;
+    w1 = ((unsigned)i1 < 8u) ? t : 0.0f;
+    o0 = min(max(i0, 0), 7) * scale_bytes;
+    o1 = min(max(i1, 0), 7) * scale_bytes;
+}
+
+__device__ __forceinline__ void tri_coef_ptr(TriCoefP& k, const float* srcT, const float* Rm, float x, float y, float z)
+{
+    const float gx = Rm[0] * x + Rm[1] * y + Rm[2] * z;
+    const float gy = Rm[3] * x + Rm[4] * y + Rm[5] * z;
+    const float gz = Rm[6] * x + Rm[7] * y + Rm[8] * z;
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+    int ox0, ox1, oy0, oy1, oz0, oz1;
+    axis_coef_bytes(gx, wx0, wx1, ox0, ox1, 4 * kSrcStride);
+    axis_coef_bytes(gy, wy0, wy1, oy0, oy1, 4 * 8 * kSrcStride);
+    axis_coef_bytes(gz, wz0, wz1, oz0, oz1, 4 * kSrcPlaneRows * kSrcStride);
+    const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
+    k.w[0] = w00 * wx0; k.w[1] = w00 * wx1; k.w[2] = w01 * wx0; k.w[3] = w01 * wx1;
+    k.w[4] = w10 * wx0; k.w[5] = w10 * wx1; k.w[6] = w11 * wx0; k.w[7] = w11 * wx1;
+    const char* base = reinterpret_cast<const char*>(srcT);
+    const char* z0 = base + oz0;
+    const char* z1 = base + oz1;
+    const char* a00 = z0 + oy0; const char* a01 = z0 + oy1; const char* a10 = z1 + oy0; const char* a11 = z1 + oy1;
+    k.p[0] = reinterpret_cast<const float*>(a00 + ox0); k.p[1] = reinterpret_cast<const float*>(a00 + ox1);
+    k.p[2] = reinterpret_cast<const float*>(a01 + ox0); k.p[3] = reinterpret_cast<const float*>(a01 + ox1);
+    k.p[4] = reinterpret_cast<const float*>(a10 + ox0); k.p[5] = reinterpret_cast<const float*>(a10 + ox1);
+    k.p[6] = reinterpret_cast<const float*>(a11 + ox0); k.p[7] = reinterpret_cast<const float*>(a11 + ox1);
+}
+
+__device__ __forceinline__ void tri_blend_ptr(float (&out)[16], const TriCoefP& k)
+{
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(k.p[n]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = row[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n == 0) out[4 * j + e] = k.w[n] * v[e];
+                else out[4 * j + e] += k.w[n] * v[e];
+            }
+        }
+    }
+}
+
 // Produce quarter Q (d in {2Q, 2Q+1}) of the rotated volume into `buf` (swizzled planes).
 // Two passes of 64 voxels; lane -> (w = l&7, d0 = (l>>3)&1, h = 4p + 2*((l>>5)&1) + ((l>>4)&1)),
 // a mapping whose ds_write_b32 hits 32 distinct banks per half-wave.
@@ -188,10 +249,10 @@ __device__ __forceinline__ void tri_quarter(float* buf, const float* srcT, const
     for (int p = 0; p < 2; ++p) {
         const int b = 4 * p + 2 * b1 + b0;
         const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
-        TriCoef k;
-        tri_coef(k, Rm, x, y, z);
+        TriCoefP k;
+        tri_coef_ptr(k, srcT, Rm, x, y, z);
         float o[16];
-        tri_blend(o, srcT, k);
+        tri_blend_ptr(o, k);
         float* dst = buf + qoff(a0, b, e);
 #pragma unroll
         for (int c = 0; c < 16; ++c) dst[c * 128] = o[c];

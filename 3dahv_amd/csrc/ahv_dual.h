@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm2_dual(f32x4 (&v)[2][4], const f32x4 (&acc)[
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float u = fmaxf(acc[m][t][r], 0.0f);
+                const float u = __builtin_amdgcn_fmed3f(acc[m][t][r], 0.0f, __builtin_inff());  // relu, one instruction
                 v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][0], u, v[0][t], 0, 0, 0);
                 v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][1], u, v[1][t], 0, 0, 0);
             }

@@ -92,3 +92,16 @@ if not only or "enc" in only:
     ms_graph = timeit(lambda: run(a, b), 100)
     print(json.dumps({"config": "encoder forward_2d3d B=1", "eager_us": ms_eager * 1e3, "hipgraph_us": ms_graph * 1e3,
                       "weights_MB": sum(p.numel() for p in fa.parameters()) * 4 / 1e6}))
+    for B in (1, 32):  # HIP kernels vs the stock PyTorch-ROCm operator path of the same module
+        a, b = torch.randn(B, 768, 8, 8, device=dev), torch.randn(B, 768, 8, 8, device=dev)
+        with torch.no_grad():
+            fa.use_hip_encoder = fa.att.use_hip = True
+            ms_hip = timeit(lambda: fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0), 20)
+            ref_hip = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+            fa.use_hip_encoder = fa.att.use_hip = False
+            ms_torch = timeit(lambda: fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0), 10)
+            ref_t = fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+            fa.use_hip_encoder = fa.att.use_hip = True
+        rel = max(((x - y).abs().max() / y.abs().max()).item() for x, y in zip(ref_hip, ref_t))
+        print(json.dumps({"config": "encoder forward_2d3d", "B": B, "hip_us": ms_hip * 1e3, "torch_ops_us": ms_torch * 1e3,
+                          "max_rel_diff": rel}))
