@@ -114,11 +114,29 @@ class _EstimatorBase(nn.Module):
         _ckpt.load_into(model, sd, strict=strict)
         return model
 
-    def training_step(self, batch, batch_idx):
-        raise NotImplementedError("training (infoNCE_loss backward through the rotation/projection path) is the "
-                                  "next row of SURVEY.md section 8(f); this build covers inference")
+    @torch.no_grad()
+    def infoNCE_loss(self, img_feat_1, img_feat_2, sampled_R, gt_delta_R, reduce_mean: Optional[bool] = None):
+        """Forward value of the reference's InfoNCE loss (modules/model_co3d.py:41-61, modules/model.py:43-63):
+        per-sample hypothesis sets ``sampled_R (B,N,3,3)``, positives = hypotheses within ``DATA.ACC_THR`` degrees
+        of ``gt_delta_R``, ``-log(sum_pos exp(s/0.1) / sum_all exp(s/0.1))``.  The (B,N) similarities come from ONE
+        fused HIP launch with per-sample rotations.  No autograd graph: the backward of the rotate/projection
+        path is not built yet, so this serves validation / monitoring.
+        ``reduce_mean`` defaults to the variant's behaviour: mean (model_co3d.py:59) or per-sample (model.py:61)."""
+        import math
+        bs = gt_delta_R.shape[0]
+        gt_sim = (torch.sum(sampled_R.flatten(2) * gt_delta_R.reshape(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+        positive = 180 * (torch.arccos(gt_sim) / math.pi) <= self.cfg["DATA"]["ACC_THR"]          # (B, N)
+        f_tgt = self.feature_aligner.forward_3d2d(img_feat_2)
+        sim, _ = ops.score_hypotheses(img_feat_1, f_tgt, sampled_R.contiguous(), *self.feature_aligner.head_weights())
+        e = torch.exp(sim / 0.1)
+        loss = -torch.log((e * positive).sum(dim=-1) / e.sum(dim=-1).clamp(min=1e-8))
+        if reduce_mean is None:
+            reduce_mean = isinstance(self, EstimatorCo3d)
+        return loss.mean() if reduce_mean else loss
 
-    infoNCE_loss = training_step
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("training (the backward of infoNCE_loss through the rotation/projection path) is "
+                                  "the next row of SURVEY.md section 8(f); this build covers inference")
 
 
 class EstimatorCo3d(_EstimatorBase):

@@ -166,3 +166,35 @@ def test_test_step_default_proposals_are_device_haar(ahv, model_obj, dev):
     assert geo.shape == (2,) and len(model_obj.step_outputs) == n0 + 1
     P1, P2 = model_obj.fresh_proposals(dev), model_obj.fresh_proposals(dev)
     assert P1.shape == (model_obj.num_rota, 3, 3) and P1.is_cuda and not torch.equal(P1, P2)
+
+
+def test_infonce_forward_matches_torch_op_sequence(ahv, model_obj, dev):
+    """Forward value of infoNCE_loss (modules/model.py:43-63) with per-sample hypothesis sets."""
+    from oracle import torch_ref
+    import math
+    c = cfg(64)
+    c["DATA"]["ACC_THR"] = 30
+    torch.manual_seed(1)
+    m = ahv.estimator.EstimatorObjaverse(c).to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    l4 = torch.randn(2, 2, 768, 8, 8, generator=g).to(dev)
+    with torch.no_grad():
+        vs, vt = m.forward_features(l4[0], l4[1])
+    gt = ahv.rotations.random_rotations(2, generator=g).to(dev)
+    R = ahv.rotations.random_rotations(2 * 63, generator=g).to(dev).reshape(2, 63, 3, 3)
+    R = torch.cat([gt[:, None], R], dim=1)  # GT at index 0, as in training_step (modules/model.py:102-103)
+    loss = m.infoNCE_loss(vs, vt, R, gt)
+    assert loss.shape == (2,)
+    W1, W2, b2 = m.feature_aligner.head_weights()
+    with torch.no_grad():
+        ref = []
+        for i in range(2):
+            s, _, _ = torch_ref.score_hypotheses(vs[i:i + 1], vt[i:i + 1], R[i], W1, W2, b2)
+            gs = (torch.sum(R[i].flatten(1) * gt[i].reshape(1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+            pos = 180 * torch.arccos(gs) / math.pi <= 30
+            e = torch.exp(s[0] / 0.1)
+            ref.append(-torch.log(e[pos].sum() / e.sum().clamp(min=1e-8)))
+    assert torch.allclose(loss, torch.stack(ref), rtol=1e-4, atol=1e-5)
+    mc = ahv.estimator.EstimatorCo3d(c).to(dev).eval()
+    mc.load_state_dict(m.state_dict())
+    assert torch.allclose(mc.infoNCE_loss(vs, vt, R, gt), loss.mean(), rtol=1e-5)
