@@ -364,3 +364,24 @@ def test_forward_3d2d_throughput_path_matches_small_paths(ops, oracle, G, g128, 
     assert tensor_relerr(big[:8].cpu().numpy(), small.cpu().numpy()) < 1e-6
     ref = oracle.forward_3d2d(rot[4990:].cpu().numpy(), g128["W1"], g128["W2"], g128["b2"])
     assert tensor_relerr(big[4990:].cpu().numpy(), ref) < TENSOR_RTOL
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3])
+def test_fused_many_samples_few_hypotheses(ops, ahv, oracle, g128, dev, variant):
+    """B larger than the number of CUs (each workgroup loops over several samples) and N smaller than a workgroup."""
+    lib = ahv._lib.load()
+    prev = lib.ahv_set_option(b"score_variant", variant)
+    try:
+        rng = np.random.RandomState(3)
+        B, N = 300, 5
+        vs = (rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32)
+        vt = (rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32)
+        R = ahv.rotations.haar_rotations_np(N, 12)
+        ft = ops.forward_3d2d(to_dev(vt, dev), to_dev(g128["W1"], dev), to_dev(g128["W2"], dev), to_dev(g128["b2"], dev))
+        s, key = ops.score_hypotheses(to_dev(vs, dev), ft, to_dev(R, dev), to_dev(g128["W1"], dev), to_dev(g128["W2"], dev),
+                                      to_dev(g128["b2"], dev))
+        ref, _, ref_idx = oracle.score_hypotheses(vs, vt, R, g128["W1"], g128["W2"], g128["b2"])
+        assert score_relerr(s.cpu().numpy(), ref) < SCORE_RTOL
+        assert ops.unpack_best(key)[1].cpu().tolist() == ref_idx.tolist()
+    finally:
+        lib.ahv_set_option(b"score_variant", prev)
