@@ -76,7 +76,7 @@ const char* ahv_last_error(void) { return g_err; }
 int ahv_set_option(const char* name, int value)
 {
     if (name && std::strcmp(name, "score_variant") == 0) {
-        if (value < 0 || value > 3) return fail(AHV_EINVAL, "set_option: score_variant must be 0..3");
+        if (value < 0 || value > 4) return fail(AHV_EINVAL, "set_option: score_variant must be 0..4");
         const int prev = ahv::g_score_variant;
         ahv::g_score_variant = value;
         return prev;

@@ -13,6 +13,7 @@
 #include "ahv_pipeline.h"
 #include "ahv_wide.h"
 #include "ahv_dual.h"
+#include "ahv_split.h"
 
 namespace ahv {
 
@@ -45,6 +46,40 @@ __device__ __forceinline__ float hyp_score(const f32x4 (&v)[2][4], const f32x4 (
 #pragma unroll
     for (int s = 8; s >= 1; s >>= 1) tot += __shfl_xor(tot, s, 64);
     return tot * (1.0f / 64.0f);
+}
+
+// Same score with a reduce-scatter instead of four all-reduces: after two exchange steps lane (col, kq)
+// owns the complete sums of ONE position (tile t = kq, column col), so the normalisation runs once per
+// lane instead of four times and 6 cross-lane moves replace 20.  Result uniform (read from lane 63).
+__device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x4 (&tg)[4][2], int lane)
+{
+    float ss[4], dt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ss[t] = 0.0f;
+        dt[t] = 0.0f;
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = v[m2][t][r];
+                ss[t] += x * x;
+                dt[t] += x * tg[t][m2][r];
+            }
+    }
+    const bool up = (lane & 32) != 0;  // upper half keeps tiles 2,3 and hands over 0,1
+    float s2[2], d2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        s2[i] = (up ? ss[2 + i] : ss[i]) + __shfl_xor(up ? ss[i] : ss[2 + i], 32, 64);
+        d2[i] = (up ? dt[2 + i] : dt[i]) + __shfl_xor(up ? dt[i] : dt[2 + i], 32, 64);
+    }
+    const bool odd = (lane & 16) != 0;  // odd rows keep the second tile of their pair
+    const float s1 = (odd ? s2[1] : s2[0]) + __shfl_xor(odd ? s2[0] : s2[1], 16, 64);
+    const float d1 = (odd ? d2[1] : d2[0]) + __shfl_xor(odd ? d2[0] : d2[1], 16, 64);
+    const float c = d1 / fmaxf(sqrtf(s1), 1e-12f);
+    const float tot = wave_sum_dpp(c);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63)) * (1.0f / 64.0f);
 }
 
 __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_kernel(
@@ -359,6 +394,8 @@ __global__ __launch_bounds__(kScoreThreads, 1) void score_hypotheses_wide_kernel
 // ---------------------------------------------------------------------------------------
 constexpr int kDualThreads = 512;
 
+// SPLIT = true: GEMM1 on the f16 matrix pipe with hi/lo split operands (ahv_split.h, score_variant 4).
+template <bool SPLIT>
 __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
     long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
@@ -374,24 +411,36 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const float* srcT = lds_src;
     float* buf = lds_q + wave * kQuarterFloats;
 
-    stage_w1_table(lds_w1, W1, tid, kDualThreads);
+    static_assert(kSplitTableBytes == sizeof(float) * kW1TableFloats && kSplitImageBytes == sizeof(float) * kQuarterFloats, "LDS budget");
+    if (SPLIT) stage_w1_split(reinterpret_cast<f16x8*>(lds_w1), W1, tid, kDualThreads);
+    else stage_w1_table(lds_w1, W1, tid, kDualThreads);
     DualFrags f;
     load_dual_frags(f, W2, b2, lane);
-    const int n16 = lane & 15, kq = lane >> 4;
-    const long hstep = (long)gridDim.x * 8;
+    if (SPLIT) {  // the operand prescale 2^12 comes back out through the GEMM2 A operand (exact)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f.a2[m][r][0] *= kSplitUnscale;
+                f.a2[m][r][1] *= kSplitUnscale;
+            }
+    }
+        const long hstep = (long)gridDim.x * 8;
 
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
-        f32x4 tg[4][2];
+        if (SPLIT) stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+        else stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+        // Target features as the per-lane fragments the score needs, parked in the 16-byte pad of source
+        // rows 0..511 (row (2t + m2)*64 + lane): 32 registers less per wave, and the 80-byte row stride
+        // makes the eight ds_read_b128 of the epilogue conflict-free.
         {
             const float* ft = feat_tgt + (long)b * (32 * 64);
+            const int l = tid & 63, t = tid >> 7, m2 = (tid >> 6) & 1;
+            f32x4 x;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tg[t][m2][r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16];
+            for (int r = 0; r < 4; ++r) x[r] = ft[(16 * m2 + 4 * (l >> 4) + r) * 64 + 16 * t + (l & 15)];
+            *reinterpret_cast<f32x4*>(lds_src + tid * kSrcStride + 16) = x;
         }
         __syncthreads();
 
@@ -437,35 +486,49 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #define AHV_TS(i)
 #endif
             AHV_TS(0)
-            tri_quarter<0>(buf, srcT, Rm, lane);
+            if (SPLIT) tri_quarter_split<0>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
+            else tri_quarter<0>(buf, srcT, Rm, lane);
             wave_lds_fence();
             AHV_TS(1)
-            gemm1_quarter_lds<0>(acc, lds_w1, buf, lane);
+            if (SPLIT) gemm1_quarter_split<0>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
+            else gemm1_quarter_lds<0>(acc, lds_w1, buf, lane);
             wave_lds_fence();
             AHV_TS(2)
-            tri_quarter<1>(buf, srcT, Rm, lane);
+            if (SPLIT) tri_quarter_split<1>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
+            else tri_quarter<1>(buf, srcT, Rm, lane);
             wave_lds_fence();
             AHV_TS(3)
-            gemm1_quarter_lds<1>(acc, lds_w1, buf, lane);
+            if (SPLIT) gemm1_quarter_split<1>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
+            else gemm1_quarter_lds<1>(acc, lds_w1, buf, lane);
             wave_lds_fence();
             AHV_TS(4)
-            tri_quarter<2>(buf, srcT, Rm, lane);
+            if (SPLIT) tri_quarter_split<2>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
+            else tri_quarter<2>(buf, srcT, Rm, lane);
             wave_lds_fence();
             AHV_TS(5)
-            gemm1_quarter_lds<2>(acc, lds_w1, buf, lane);
+            if (SPLIT) gemm1_quarter_split<2>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
+            else gemm1_quarter_lds<2>(acc, lds_w1, buf, lane);
             wave_lds_fence();
             AHV_TS(6)
-            tri_quarter<3>(buf, srcT, Rm, lane);
+            if (SPLIT) tri_quarter_split<3>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
+            else tri_quarter<3>(buf, srcT, Rm, lane);
             wave_lds_fence();
             AHV_TS(7)
-            gemm1_quarter_lds<3>(acc, lds_w1, buf, lane);
+            if (SPLIT) gemm1_quarter_split<3>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
+            else gemm1_quarter_lds<3>(acc, lds_w1, buf, lane);
             wave_lds_fence();
             AHV_TS(8)
 
             f32x4 v[2][4];
             gemm2_dual(v, acc, f);
             AHV_TS(9)
-            const float s = hyp_score(v, tg);
+            f32x4 tg[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+                    tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
+            const float s = hyp_score_rs(v, tg, lane);
             if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
             const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
             best = key > best ? key : best;
@@ -537,16 +600,17 @@ hipError_t launch_score_hypotheses(const float* vol_src, const float* feat_tgt, 
     const int64_t need = (N + 3) / 4;  // workgroups that can get at least one hypothesis per wave
     if (gx > need) gx = (int)need;
     if (gx < 1) gx = 1;
-    const int waves_per_wg = (g_score_variant == 3) ? 8 : 4;
+    const int waves_per_wg = (g_score_variant >= 3) ? 8 : 4;
     const int64_t need_w = (N + waves_per_wg - 1) / waves_per_wg;
-    if (g_score_variant == 3 && gx > need_w) gx = (int)(need_w < 1 ? 1 : need_w);
+    if (g_score_variant >= 3 && gx > need_w) gx = (int)(need_w < 1 ? 1 : need_w);
     const dim3 grid(gx, gy);
 #define AHV_LAUNCH(K, L, T) \
     launch_score_kernel(K, L, grid, T, stream, vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key)
     switch (g_score_variant) {
         case 0: return AHV_LAUNCH(score_hypotheses_kernel, lds, kScoreThreads);
         case 1: return AHV_LAUNCH(score_hypotheses_pipelined_kernel, 0, kScoreThreads);
-        case 3: return AHV_LAUNCH(score_hypotheses_dual_kernel, 0, kDualThreads);
+        case 3: return AHV_LAUNCH(score_hypotheses_dual_kernel<false>, 0, kDualThreads);
+        case 4: return AHV_LAUNCH(score_hypotheses_dual_kernel<true>, 0, kDualThreads);
         default: return AHV_LAUNCH(score_hypotheses_wide_kernel, 0, kScoreThreads);
     }
 #undef AHV_LAUNCH
