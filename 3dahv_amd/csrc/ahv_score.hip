@@ -412,25 +412,35 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     float* buf = lds_q + wave * kQuarterFloats;
 
     static_assert(kSplitTableBytes == sizeof(float) * kW1TableFloats && kSplitImageBytes == sizeof(float) * kQuarterFloats, "LDS budget");
-    if (SPLIT) stage_w1_split(reinterpret_cast<f16x8*>(lds_w1), W1, tid, kDualThreads);
-    else stage_w1_table(lds_w1, W1, tid, kDualThreads);
-    DualFrags f;
-    load_dual_frags(f, W2, b2, lane);
-    if (SPLIT) {  // the operand prescale 2^12 comes back out through the GEMM2 A operand (exact)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                f.a2[m][r][0] *= kSplitUnscale;
-                f.a2[m][r][1] *= kSplitUnscale;
-            }
+    int w1_exp = 0;
+    if (SPLIT) {
+        float m = 0.0f;
+        for (int i = tid; i < 32 * 384; i += kDualThreads) m = fmaxf(m, fabsf(W1[i]));
+        w1_exp = split_prescale_exp(block_absmax(m, lds_q, tid));
+        stage_w1_split(reinterpret_cast<f16x8*>(lds_w1), W1, ldexpf(1.0f, w1_exp), tid, kDualThreads);
+    } else {
+        stage_w1_table(lds_w1, W1, tid, kDualThreads);
     }
-        const long hstep = (long)gridDim.x * 8;
+    DualFrags f0;
+    load_dual_frags(f0, W2, b2, lane);
+    const long hstep = (long)gridDim.x * 8;
 
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        if (SPLIT) stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
-        else stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+        DualFrags f = f0;
+        if (SPLIT) {
+            const int v_exp = stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid);
+            const float unscale = ldexpf(1.0f, -(w1_exp + v_exp));  // exact; relu commutes with it
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f.a2[m][r][0] *= unscale;
+                    f.a2[m][r][1] *= unscale;
+                }
+        } else {
+            stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+        }
         // Target features as the per-lane fragments the score needs, parked in the 16-byte pad of source
         // rows 0..511 (row (2t + m2)*64 + lane): 32 registers less per wave, and the 80-byte row stride
         // makes the eight ds_read_b128 of the epilogue conflict-free.

@@ -7,8 +7,8 @@
 // to f16; the three products hi*hi + hi*lo + lo*hi are accumulated in fp32 by v_mfma_f32_16x16x32_f16
 // (hi*hi is exact in fp32, the dropped lo*lo term is 2^-22 relative).  Measured against the fp32
 // oracle the scores agree to ~1e-6, two orders inside the 1e-4 parity bar (tests/test_gpu_split.py), but
-// the arithmetic is NOT IEEE fp32 -- hence opt-in.  Operand range: |V| < 4094, |W1| < 255 (prescaled by
-// 2^4 and 2^8 so that lo stays a normal f16 for ordinary magnitudes; the 2^-12 is folded into W2).
+// the arithmetic is NOT IEEE fp32 -- hence opt-in.  Operands are prescaled by powers of two taken from their
+// largest magnitude (split_prescale_exp), so any finite fp32 range works.
 //
 // K order inside a slab is (spatial index, channel) with the channel fastest: a lane's own 16 blended
 // channels are then two complete B fragments, the gather stores them with four ds_write_b128 and ONE
@@ -25,9 +25,32 @@ namespace ahv {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kSplitSrcScale = 16.0f;    // applied while staging the source volume
-constexpr float kSplitW1Scale = 256.0f;    // applied while building the W1 table
-constexpr float kSplitUnscale = 1.0f / (kSplitSrcScale * kSplitW1Scale);  // folded into the GEMM2 A operand
+// Both operands are prescaled by a power of two chosen from their largest magnitude (per launch for W1,
+// per sample for the source volume) so that max |x| * 2^e lies in [2^13, 2^14): hi never overflows f16 and
+// lo stays a normal f16 for everything within 2^-13 of the maximum.  The exact 2^-(eW+eV) comes back out
+// through the GEMM2 A operand.
+__device__ __forceinline__ int split_prescale_exp(float amax)
+{
+    if (!(amax > 0.0f) || amax > 3.0e38f) return 0;  // all-zero, NaN or inf operands: nothing to gain
+    int ex;
+    (void)frexpf(amax, &ex);  // amax = m * 2^ex, m in [0.5, 1)
+    const int e = 14 - ex;
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+
+// max over the workgroup; `scratch` = 8 floats of LDS nobody else is using right now
+__device__ __forceinline__ float block_absmax(float x, float* scratch, int tid)
+{
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) x = fmaxf(x, __shfl_xor(x, sft, 64));
+    if ((tid & 63) == 0) scratch[tid >> 6] = x;
+    __syncthreads();
+    float m = scratch[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, scratch[i]);
+    __syncthreads();
+    return m;
+}
 constexpr int kSplitTableFrags = 48;       // 12 groups (slab, k-step) x {m0 hi, m0 lo, m1 hi, m1 lo}
 constexpr int kSplitTableBytes = kSplitTableFrags * 64 * 16;  // 48 KiB
 constexpr int kSplitImageBytes = 128 * 64;  // per wave: 128 voxels x (16 hi + 16 lo halfs)
@@ -37,7 +60,7 @@ constexpr int kSplitImageBytes = 128 * 64;  // per wave: 128 voxels x (16 hi + 1
 // (4*G + i)*64 + lane.  Lane (row, kq), half j holds
 //   W1[16m + row][128 s + c*8 + idx],  idx = 2 ks + (kq >> 1),  c = 8 (kq & 1) + j
 // i.e. k = idx*16 + c inside the slab; for the z slab idx = a, so k-step ks = the quarter.
-__device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __restrict__ W1, int tid, int nthreads)
+__device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __restrict__ W1, float scale, int tid, int nthreads)
 {
     for (int i = tid; i < kSplitTableFrags * 64; i += nthreads) {
         const int lane = i & 63, frag = i >> 6;
@@ -48,7 +71,7 @@ __device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __rest
         f16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float x = w[(8 * (kq & 1) + j) * 8] * kSplitW1Scale;
+            const float x = w[(8 * (kq & 1) + j) * 8] * scale;
             const _Float16 hi = (_Float16)x;
             v[j] = part ? (_Float16)(x - (float)hi) : hi;
         }
@@ -56,12 +79,24 @@ __device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __rest
     }
 }
 
-__device__ __forceinline__ void stage_src_volume_scaled(float* srcT, const float* __restrict__ vol, int tid, int nthreads)
+// Source volume -> LDS, prescaled per sample; returns the exponent used (512 threads, 16 values each).
+__device__ __forceinline__ int stage_src_volume_scaled(float* srcT, const float* __restrict__ vol, float* scratch, int tid)
 {
-    for (int i = tid; i < 16 * 512; i += nthreads) {
-        const int c = i >> 9, v = i & 511;
-        srcT[((v >> 6) * kSrcPlaneRows + (v & 63)) * kSrcStride + c] = vol[i] * kSplitSrcScale;
+    float x[16];
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        x[k] = vol[tid + 512 * k];
+        m = fmaxf(m, fabsf(x[k]));
     }
+    const int e = split_prescale_exp(block_absmax(m, scratch, tid));
+    const float scale = ldexpf(1.0f, e);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid + 512 * k, c = i >> 9, v = i & 511;
+        srcT[((v >> 6) * kSrcPlaneRows + (v & 63)) * kSrcStride + c] = x[k] * scale;
+    }
+    return e;
 }
 
 // ---- rotated quarter image ---------------------------------------------------------------

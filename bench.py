@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--score-variant", type=int, default=3, help="fused-kernel variant to time (3 = all-fp32 dual, "
+                    "the default and the headline; 4 = split-f16 GEMM1, opt-in, reported beside it)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -98,7 +100,8 @@ def main():
 
     ahv = importlib.import_module("3dahv_amd")
     ops, adist = ahv.ops, ahv.dist
-    ahv._lib.load()  # fails loudly without the HIP library
+    lib = ahv._lib.load()  # fails loudly without the HIP library
+    lib.ahv_set_option(b"score_variant", args.score_variant)
 
     vol_src, vol_tgt, W1, W2, b2, R = synth_inputs(ahv, dev, rank)
     n_offset = rank * N_HYP
@@ -197,6 +200,30 @@ def main():
                          "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
                          "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP},
         }
+        if args.score_variant != 3:
+            res["roofline"]["kernel"] = "score_variant %d" % args.score_variant
+        if args.score_variant == 4:  # opt-in kernel: priced against the f16 matrix peak (16 x the fp32 one)
+            res["dtype"] = "f16 hi/lo split products, f32 accumulate"
+            res["roofline"].update(peak=16 * PEAK_F32_MFMA_TFLOPS, frac=achieved / (16 * PEAK_F32_MFMA_TFLOPS),
+                                   note="GEMM1 runs 3 f16 MFMA products per algorithmic MAC; the kernel is bound by "
+                                        "LDS bandwidth (trilinear gather), not by the matrix pipe")
+        if world == 1 and args.score_variant == 3:
+            # The opt-in split-f16 kernel on the same inputs, reported beside the fp32 headline (never as `value`).
+            lib.ahv_set_option(b"score_variant", 4)
+            s4, k4 = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+            for a, b in ev:
+                a.record()
+                ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=keys[0], reset_best=True)
+                b.record()
+            torch.cuda.synchronize()
+            lib.ahv_set_option(b"score_variant", 3)
+            ms4 = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            res["split_f16_kernel"] = {
+                "note": "score_variant 4 (opt-in): GEMM1 as 3 f16 MFMA products of hi/lo split operands, f32 accumulate",
+                "kernel_ms": ms4, "hypotheses_per_s_kernel_only": N_HYP / (ms4 * 1e-3),
+                "max_abs_score_diff_vs_f32_kernel": float((s4 - scores).abs().max().item()),
+                "same_argmax": bool(torch.equal(ops.unpack_best(k4)[1], ops.unpack_best(key)[1]))}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_scores = cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R)
             res["cpu_baseline"] = cb

@@ -317,7 +317,7 @@ def test_fused_argument_errors(ops, ahv, G):
         ahv._lib.check(rc, "ahv_score_hypotheses_f32")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_fused_kernel_variants_agree(ops, ahv, G, g128, variant):
     """All fused-kernel variants (diagnostic knob) meet the same parity bar."""
     lib = ahv._lib.load()
@@ -366,7 +366,7 @@ def test_forward_3d2d_throughput_path_matches_small_paths(ops, oracle, G, g128, 
     assert tensor_relerr(big[4990:].cpu().numpy(), ref) < TENSOR_RTOL
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4])
 def test_fused_many_samples_few_hypotheses(ops, ahv, oracle, g128, dev, variant):
     """B larger than the number of CUs (each workgroup loops over several samples) and N smaller than a workgroup."""
     lib = ahv._lib.load()

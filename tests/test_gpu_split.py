@@ -1,0 +1,124 @@
+"""score_variant 4 ("split"): GEMM1 on the f16 matrix pipe with hi/lo split operands, fp32 accumulation.
+
+Opt-in (the default kernel is all-fp32).  These tests pin what makes it usable as an fp32 stand-in:
+the same parity bar as the fp32 kernels against the golden vectors, an error against an fp64 evaluation
+of the reference's op sequence that is of the order of the fp32 kernel's own, and indifference to the
+magnitude of the operands (power-of-two prescaling chosen on the device).
+"""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(ahv):
+    ahv._lib.load()
+    return ahv.ops
+
+
+@pytest.fixture()
+def variant(ahv):
+    lib = ahv._lib.load()
+
+    def use(v):
+        return lib.ahv_set_option(b"score_variant", v)
+    prev = use(4)
+    yield use
+    use(prev)
+
+
+def scores_with(ops, use, v, vs, vt, R, W1, W2, b2):
+    use(v)
+    ft = ops.forward_3d2d(vt, W1, W2, b2)
+    s, key = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    return s, ops.unpack_best(key)[1]
+
+
+def f64_truth(vs, vt, R, W1, W2, b2):
+    from oracle import torch_ref
+    d = lambda t: t.double()
+    return torch_ref.score_hypotheses(d(vs), d(vt), d(R), d(W1), d(W2), d(b2), chunk=512)[0]
+
+
+def test_split_error_is_of_fp32_order(ops, ahv, variant, dev):
+    g = load_golden("score_n4096")
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    vs, vt, R = t(g128["vol_src"]), t(g128["vol_tgt"]), t(g["R"])
+    W1, W2, b2 = t(g128["W1"]), t(g128["W2"]), t(g128["b2"])
+    truth = f64_truth(vs, vt, R, W1, W2, b2)
+    s32, i32 = scores_with(ops, variant, 3, vs, vt, R, W1, W2, b2)
+    s4, i4 = scores_with(ops, variant, 4, vs, vt, R, W1, W2, b2)
+    e32 = (s32.double() - truth).abs().max().item()
+    e4 = (s4.double() - truth).abs().max().item()
+    print(f"max |score - f64|: fp32 kernel {e32:.2e}, split kernel {e4:.2e}")
+    assert e32 < 5e-7 and e4 < 5e-7           # scores are cosines in [-1, 1]; fp32 epsilon is 6e-8
+    assert e4 < 4 * e32 + 1e-7
+    assert torch.equal(i4, i32) and i4.item() == int(truth.argmax(dim=1).item())
+
+
+@pytest.mark.parametrize("vscale,wscale", [(1e-6, 1.0), (1.0, 1e-4), (3e4, 1.0), (1.0, 700.0), (1e8, 1e-8), (1e-12, 1e9)])
+def test_split_is_scale_free(ops, ahv, variant, dev, vscale, wscale):
+    """Operand magnitudes far outside the f16 range: the device picks power-of-two prescales per launch (W1)
+    and per sample (volume), so accuracy does not depend on them."""
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R = t(ahv.rotations.haar_rotations_np(700, 4))
+    vs = t(g128["vol_src"]) * vscale
+    vs = torch.cat([vs, vs * 37.0])                    # two samples of different magnitude in one launch
+    vt = torch.cat([t(g128["vol_tgt"])] * 2)
+    W1, W2, b2 = t(g128["W1"]) * wscale, t(g128["W2"]) / (vscale * wscale), t(g128["b2"])
+    truth = f64_truth(vs, vt, R, W1, W2, b2)
+    s4, i4 = scores_with(ops, variant, 4, vs, vt, R, W1, W2, b2)
+    s32, i32 = scores_with(ops, variant, 3, vs, vt, R, W1, W2, b2)
+    assert (s4.double() - truth).abs().max().item() < 1e-6
+    assert (s32.double() - truth).abs().max().item() < 1e-6
+    assert torch.equal(i4, truth.argmax(dim=1))
+
+
+def test_split_zero_and_nonfinite_operands(ops, ahv, variant, dev):
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R = t(g128["R"])
+    W1, W2, b2 = t(g128["W1"]), t(g128["W2"]), t(g128["b2"])
+    vt = t(g128["vol_tgt"])
+    zero = torch.zeros_like(vt)
+    s4, _ = scores_with(ops, variant, 4, zero, vt, R, W1, W2, b2)     # all-zero volume: prescale exponent 0
+    s32, _ = scores_with(ops, variant, 3, zero, vt, R, W1, W2, b2)
+    assert torch.allclose(s4, s32, atol=1e-7, rtol=0)
+    bad = t(g128["vol_src"]).clone()
+    bad[0, 3, 4, 4, 4] = float("inf")                                 # non-finite input: no prescale, no hang
+    s4, _ = scores_with(ops, variant, 4, bad, vt, R, W1, W2, b2)
+    assert s4.shape == (1, R.shape[0])
+
+
+def test_split_soak_against_fp32_kernel(ops, ahv, variant, dev):
+    rng = np.random.RandomState(11)
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    W2, b2 = t(g128["W2"]), t(g128["b2"])
+    for trial in range(10):
+        B = int(rng.choice([1, 2, 5]))
+        N = int(rng.choice([1, 7, 8, 9, 511, 2048, 2049, 5000]))
+        vs = t((rng.standard_normal((B, 16, 8, 8, 8)) * rng.uniform(0.1, 5)).astype(np.float32))
+        vt = t(rng.standard_normal((B, 16, 8, 8, 8)).astype(np.float32))
+        W1 = t((rng.standard_normal((32, 384)) * rng.uniform(0.01, 0.3)).astype(np.float32))
+        per_sample = bool(rng.randint(2))
+        R = ahv.rotations.haar_rotations_np(N * (B if per_sample else 1), 100 + trial)
+        R = t(R.reshape(B, N, 3, 3) if per_sample else R)
+        s4, i4 = scores_with(ops, variant, 4, vs, vt, R, W1, W2, b2)
+        s32, i32 = scores_with(ops, variant, 3, vs, vt, R, W1, W2, b2)
+        assert (s4 - s32).abs().max().item() < 5e-7, (trial, B, N)
+        top2 = torch.topk(s32, min(2, N), dim=1).values
+        clear = (top2[:, 0] - top2[:, -1] > 2e-6) | (N == 1)
+        assert torch.equal(i4[clear], i32[clear])
