@@ -250,52 +250,66 @@ __global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
 
 // ---------------------------------------------------------------------------------
 // forward_3d2d for a handful of items (the per-pair target feature, test_co3d.py:141): latency matters,
-// not throughput.  One workgroup per item; wave q contracts quarter q with only the W1 fragments that
-// quarter needs, the four partial accumulators meet in LDS, wave 0 runs ReLU/GEMM2/normalise.
+// not throughput.  One 512-thread workgroup per item.  W1 is copied once, coalesced, into LDS with a
+// 386-float row stride (the fragment reads W1[row][k0 + kq] of a half-wave then hit 32 different banks); wave
+// (q, kh) contracts quarter q with the x slab + half of the z slab (kh = 0) or the y slab + the other half
+// (kh = 1); the eight partial accumulators meet in LDS and waves 0-3 each finish one position tile
+// (ReLU, GEMM2, bias, normalise).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void forward_3d2d_small_kernel(
+constexpr int kW1PadStride = 386;  // bank = (2 row + k) mod 32: 16 rows x 2 k-groups of a half-wave hit 32 banks
+
+__global__ __launch_bounds__(512) void forward_3d2d_small_kernel(
     const float* __restrict__ vol, const float* __restrict__ W1, const float* __restrict__ W2,
     const float* __restrict__ b2, float* __restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) float qbuf[4][kQuarterFloats];
-    __shared__ __attribute__((aligned(16))) float part[4][8][64][4];
+    __shared__ __attribute__((aligned(16))) float part[8][8][64][4];
+    __shared__ float w1s[32 * kW1PadStride];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wave & 3, kh = wave >> 2;
     const int n = lane & 15, kq = lane >> 4, i0 = n >> 3, j = n & 7, row = lane & 15;
     const float* V = vol + (long)blockIdx.x * (16 * 512);
-    float* buf = qbuf[q];
-    {   // quarter q of channel c = 128 contiguous floats at c*512 + q*128
+    for (int i = tid; i < 32 * 96; i += 512) {  // 96 float4 per W1 row
+        const int r = i / 96, k4 = i - r * 96;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + r * 384 + 4 * k4);
+        float* d = w1s + r * kW1PadStride + 4 * k4;
+        d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+    }
+    {   // quarter q of channel c = 128 contiguous floats at c*512 + q*128; the two waves of a quarter take 8 channels each
+        float* buf = qbuf[q];
         const int i = 2 * lane, a0 = i >> 6, bb = (i >> 3) & 7, e = i & 7;
         const int o0 = qoff(a0, bb, e), o1 = qoff(a0, bb, e + 1);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int cc = 0; cc < 8; ++cc) {
+            const int c = 8 * kh + cc;
             const float2 v = *reinterpret_cast<const float2*>(V + c * 512 + q * 128 + i);
             buf[c * 128 + o0] = v.x;
             buf[c * 128 + o1] = v.y;
         }
     }
-    wave_lds_fence();
+    __syncthreads();
+    const float* buf = qbuf[q];
     f32x4 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* w0 = W1 + row * 384;
-    const float* w1 = W1 + (16 + row) * 384;
-    // x / y slabs land in n-tile q; which tile that is must be a compile-time register index
-#define AHV_XY(T)                                                                                         \
-    _Pragma("unroll") for (int c = 0; c < 16; ++c) _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {       \
-        const float bx = buf[c * 128 + qoff(i0, j, 4 * hh + kq)];                                         \
-        acc[0][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c * 8 + 4 * hh + kq], bx, acc[0][T], 0, 0, 0); \
-        acc[1][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c * 8 + 4 * hh + kq], bx, acc[1][T], 0, 0, 0); \
-        const float by = buf[c * 128 + qoff(i0, 4 * hh + kq, j)];                                         \
-        acc[0][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[128 + c * 8 + 4 * hh + kq], by, acc[0][T], 0, 0, 0); \
-        acc[1][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[128 + c * 8 + 4 * hh + kq], by, acc[1][T], 0, 0, 0); \
+    const float* w0 = w1s + row * kW1PadStride;
+    const float* w1 = w1s + (16 + row) * kW1PadStride;
+    // the x / y slab lands in n-tile q; which tile that is must be a compile-time register index
+#define AHV_XY(T)                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < 16; ++c) _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {        \
+        const int k = 128 * kh + c * 8 + 4 * hh + kq;                                                      \
+        const float bv = kh ? buf[c * 128 + qoff(i0, 4 * hh + kq, j)] : buf[c * 128 + qoff(i0, j, 4 * hh + kq)]; \
+        acc[0][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], bv, acc[0][T], 0, 0, 0);                    \
+        acc[1][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], bv, acc[1][T], 0, 0, 0);                    \
     }
     if (q == 0) { AHV_XY(0) } else if (q == 1) { AHV_XY(1) } else if (q == 2) { AHV_XY(2) } else { AHV_XY(3) }
 #undef AHV_XY
 #pragma unroll
-    for (int cp = 0; cp < 8; ++cp) {
+    for (int cc = 0; cc < 4; ++cc) {
+        const int cp = 4 * kh + cc;
         const int kz = 256 + (2 * cp + (kq >> 1)) * 8 + 2 * q + (kq & 1);
         const float a0 = w0[kz], a1 = w1[kz];
 #pragma unroll
@@ -308,52 +322,44 @@ __global__ __launch_bounds__(256) void forward_3d2d_small_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part[q][m * 4 + t][lane]) = acc[m][t];
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part[wave][m * 4 + t][lane]) = acc[m][t];
     __syncthreads();
-    if (q != 0) return;
+    if (wave >= 4) return;
+    const int t = wave;  // this wave finishes positions 16t .. 16t+15
+    f32x4 u[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        u[m] = *reinterpret_cast<const f32x4*>(part[0][m * 4 + t][lane]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int w = 1; w < 4; ++w) acc[m][t] += *reinterpret_cast<const f32x4*>(part[w][m * 4 + t][lane]);
-    f32x4 v[2][4];
-#pragma unroll
-    for (int m2 = 0; m2 < 2; ++m2) {
-        f32x4 bias;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = b2[16 * m2 + 4 * kq + r];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[m2][t] = bias;
+        for (int w = 1; w < 8; ++w) u[m] += *reinterpret_cast<const f32x4*>(part[w][m * 4 + t][lane]);
     }
+    f32x4 v[2];
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m2][r] = b2[16 * m2 + 4 * kq + r];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float a20 = W2[row * 32 + 16 * m + 4 * kq + r], a21 = W2[(16 + row) * 32 + 16 * m + 4 * kq + r];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float u = fmaxf(acc[m][t][r], 0.0f);
-                v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, u, v[0][t], 0, 0, 0);
-                v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, u, v[1][t], 0, 0, 0);
-            }
+            const float x = fmaxf(u[m][r], 0.0f);
+            v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, x, v[0], 0, 0, 0);
+            v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, x, v[1], 0, 0, 0);
         }
+    float ss = 0.0f;
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss += v[m2][r] * v[m2][r];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
     float* o = out + (long)blockIdx.x * (32 * 64);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float ss = 0.0f;
+    for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ss += v[m2][t][r] * v[m2][t][r];
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n] = v[m2][t][r] / nrm;
-    }
+        for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n] = v[m2][r] / nrm;
 }
 
 // ---------------------------------------------------------------------------------
@@ -525,8 +531,8 @@ hipError_t launch_forward_3d2d(const float* vol, const float* W1, const float* W
         if (e != hipSuccess) return e;
         attr_dev = dev;
     }
-    if (M <= 64) {  // latency path: one workgroup per item, quarters split over its 4 waves
-        hipLaunchKernelGGL(forward_3d2d_small_kernel, dim3((unsigned)M), dim3(256), 0, stream, vol, W1, W2, b2, out);
+    if (M <= 64) {  // latency path: one workgroup per item, quarters and slabs split over its 8 waves
+        hipLaunchKernelGGL(forward_3d2d_small_kernel, dim3((unsigned)M), dim3(512), 0, stream, vol, W1, W2, b2, out);
         return hipGetLastError();
     }
     if (M >= 4096) {  // throughput path

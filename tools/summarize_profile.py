@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Condense a tools/profile_bench.sh output directory into the small files kept under profiles/.
-Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> [kernel-substring]"""
+Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> [kernel-substring [summary-suffix]]"""
 import collections, csv, glob, json, os, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 kern = sys.argv[3] if len(sys.argv) > 3 else "score_hypotheses"
+suffix = sys.argv[4] if len(sys.argv) > 4 else ""
 out = {}
 for d in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"]:
     files = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
@@ -29,5 +30,5 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     f, w = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
     summary["hbm_bytes_per_launch"] = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
                                        "value": (2 * f + w) * 1024, "fetch_kb": f, "write_kb": w}
-json.dump(summary, open(os.path.join("profiles", tag + "_pmc_summary.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join("profiles", tag + suffix + "_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
