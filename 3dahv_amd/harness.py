@@ -72,6 +72,9 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
     errors, details = [], []
     for meta in sequences:
         key_frames = np.random.choice(meta["n"], num_frames, replace=False)
+        if "get_data" in meta:  # lazy source (co3d.Co3dSequences): decode only the key frames (test_co3d.py:112)
+            meta = dict(meta, **meta["get_data"](key_frames))
+            key_frames = np.arange(num_frames)
         rot = meta["R"][key_frames][permutations].to(device)               # (P, 2, 3, 3)
         R_gt = torch.bmm(rot[:, 0].transpose(1, 2), rot[:, 1])
         feats = meta["layer4"] if "layer4" in meta else meta["image"]
