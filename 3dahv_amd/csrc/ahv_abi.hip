@@ -23,6 +23,9 @@ hipError_t launch_compose_rotations(const uint64_t*, const float*, int64_t, int6
 hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*,
                                   int64_t*, hipStream_t);
 hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStream_t);
+hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
+                                 const float*, int, int64_t, const float*, float*, float*, float*, float*, float*,
+                                 float*, int, hipStream_t);
 extern int g_score_variant;
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
@@ -246,6 +249,42 @@ int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, 
     const int rc = ahv::forward_2d3d(w, layer4_src, layer4_tgt, B, static_cast<float*>(workspace), vol_src, vol_tgt,
                                      static_cast<hipStream_t>(stream), &what);
     if (rc != 0) return fail(AHV_ELAUNCH, "forward_2d3d: %s: %s", what, hipGetErrorString((hipError_t)rc));
+    return AHV_OK;
+}
+
+size_t ahv_score_hypotheses_backward_workspace_bytes(int B, int64_t N)
+{
+    if (B <= 0 || N <= 0) return 0;
+    return sizeof(float) * 2048 * (size_t)B * (size_t)N;
+}
+
+int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                                      int64_t r_batch_stride, const float* W1, const float* W2, const float* b2,
+                                      int B, int64_t N, const float* grad_scores, void* workspace,
+                                      size_t workspace_bytes, float* grad_vol_src, float* grad_feat_tgt,
+                                      float* grad_W1, float* grad_W2, float* grad_b2, void* stream)
+{
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "score_backward: negative size");
+    if (B > 65535) return fail(AHV_EINVAL, "score_backward: B > 65535");
+    if (!grad_W1 || !grad_W2 || !grad_b2) return fail(AHV_EINVAL, "score_backward: null weight-gradient pointer");
+    if (B > 0 && (!grad_vol_src || !grad_feat_tgt)) return fail(AHV_EINVAL, "score_backward: null gradient pointer");
+    if (B > 0 && N > 0) {
+        if (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2 || !grad_scores || !workspace)
+            return fail(AHV_EINVAL, "score_backward: null pointer");
+        if (r_batch_stride != 0 && r_batch_stride != N * 9)
+            return fail(AHV_EINVAL, "score_backward: r_batch_stride must be 0 or N*9");
+        if (workspace_bytes < ahv_score_hypotheses_backward_workspace_bytes(B, N))
+            return fail(AHV_EINVAL, "score_backward: workspace of %zu bytes, need %zu", workspace_bytes,
+                        ahv_score_hypotheses_backward_workspace_bytes(B, N));
+        if (reinterpret_cast<uintptr_t>(workspace) & 15)
+            return fail(AHV_EINVAL, "score_backward: workspace must be 16-byte aligned");
+    }
+    const int cu = cu_count();
+    if (cu <= 0) return fail(AHV_EDEVICE, "score_backward: no usable HIP device");
+    hipError_t e = ahv::launch_score_backward(vol_src, feat_tgt, R, r_batch_stride, W1, W2, b2, B, N, grad_scores,
+                                              static_cast<float*>(workspace), grad_vol_src, grad_feat_tgt, grad_W1,
+                                              grad_W2, grad_b2, cu, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("score_backward: launch", e);
     return AHV_OK;
 }
 

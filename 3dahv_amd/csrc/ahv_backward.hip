@@ -1,0 +1,459 @@
+// ahv_backward.hip -- backward of the fused scorer (what Estimator.infoNCE_loss,
+// modules/model_co3d.py:41-61, needs from autograd): given dL/dscore[b][n], the gradients w.r.t. the source
+// volume, the target feature and the head weights.  No gradient flows to the rotations (they are sampled).
+//
+//   scores[b][n] = 1/64 sum_pos <normalize(W2 relu(W1 slabs(rot(V_b, R_n))) + b2)[:, pos], tg_b[:, pos]>
+//
+// Two launches, nothing of the 32 KiB-per-hypothesis rotated volumes or 96 KiB slab tensors ever reaches HBM:
+//   1. score_backward_head_kernel   recomputes the forward of each hypothesis (same code as the forward
+//      kernel), back-propagates through the score, the normalisation, GEMM2 and the ReLU and leaves
+//      du = dL/du (32 x 64 floats per hypothesis) in the caller's workspace; accumulates d feat_tgt, d W2, d b2.
+//   2. score_backward_volume_kernel re-gathers each quarter of the rotated volume, accumulates
+//      dW1 += du X^T in registers, forms dX = W1^T du and scatters it through the trilinear weights into a
+//      per-workgroup LDS image of dV that is flushed once per sample.
+// All contractions are fp32 MFMA 16x16x4 (one float per lane and operand, so any LDS layout can feed them).
+// Accumulation across waves/workgroups uses float atomics: gradients are reproducible to rounding, not bitwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ahv_device.h"
+#include "ahv_dual.h"
+
+namespace ahv {
+
+constexpr int kBwdThreads = 256;  // 4 waves, one per SIMD: 512 registers per wave
+
+// du image in LDS: du[o][pos] at o*64 + (pos ^ ((o & 7) << 2)).  The XOR keeps aligned groups of four
+// positions together (float4 fills) and spreads rows over banks for the transposed reads (k = pos).
+__device__ __forceinline__ int dimg(int o, int pos) { return o * 64 + (pos ^ ((o & 7) << 2)); }
+
+__device__ __forceinline__ void lds_add(float* p, float v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void global_add(float* p, float v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel 1: forward recompute + backward through score / normalise / GEMM2 / ReLU.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
+    long r_batch_stride, const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ b2,
+    int B, long N, const float* __restrict__ grad_scores, float* __restrict__ du_ws,
+    float* __restrict__ grad_feat_tgt, float* __restrict__ grad_W2, float* __restrict__ grad_b2)
+{
+    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
+    __shared__ __attribute__((aligned(16))) float lds_q[4 * kQuarterFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4, row = lane & 15;
+    float* buf = lds_q + wave * kQuarterFloats;
+
+    stage_w1_table(lds_w1, W1, tid, kBwdThreads);
+    DualFrags f;
+    load_dual_frags(f, W2, b2, lane);
+    float a2t[2][4][2];  // dr = W2^T dv: A[row = o][k = o2]: [m2][r2][m] = W2[16 m2 + 4 kq + r2][16 m + row]
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a2t[m2][r2][m] = W2[(16 * m2 + 4 * kq + r2) * 32 + 16 * m + row];
+
+    f32x4 dW2[2][2];   // [mt][nt][r]: dW2[16 mt + 4 kq + r][16 nt + n]
+    float db2p[2][4];  // [m2][r]: partial over this lane's columns of db2[16 m2 + 4 kq + r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db2p[i][r] = 0.0f;
+
+    const long hstep = (long)gridDim.x * 4;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kBwdThreads);
+        __syncthreads();
+        f32x4 tg[4][2], dtg[4][2];
+        {
+            const float* ft = feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tg[t][m2][r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n];
+                        dtg[t][m2][r] = 0.0f;
+                    }
+        }
+        const float* Rb = R + (long)b * r_batch_stride;
+        for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
+            float Rm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tri_quarter<0>(buf, lds_src, Rm, lane); wave_lds_fence();
+            gemm1_quarter_lds<0>(acc, lds_w1, buf, lane); wave_lds_fence();
+            tri_quarter<1>(buf, lds_src, Rm, lane); wave_lds_fence();
+            gemm1_quarter_lds<1>(acc, lds_w1, buf, lane); wave_lds_fence();
+            tri_quarter<2>(buf, lds_src, Rm, lane); wave_lds_fence();
+            gemm1_quarter_lds<2>(acc, lds_w1, buf, lane); wave_lds_fence();
+            tri_quarter<3>(buf, lds_src, Rm, lane); wave_lds_fence();
+            gemm1_quarter_lds<3>(acc, lds_w1, buf, lane); wave_lds_fence();
+            f32x4 v[2][4];
+            gemm2_dual(v, acc, f);
+
+            // score = 1/64 sum_pos <v / max(|v|, eps), tg>; F.normalize's clamp passes no gradient to the norm
+            // when it is below eps
+            const float g = grad_scores[(long)b * N + h] * (1.0f / 64.0f);
+            f32x4 dv[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float ss = 0.0f, dt = 0.0f;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ss += v[m2][t][r] * v[m2][t][r];
+                        dt += v[m2][t][r] * tg[t][m2][r];
+                    }
+                ss += __shfl_xor(ss, 16, 64); dt += __shfl_xor(dt, 16, 64);
+                ss += __shfl_xor(ss, 32, 64); dt += __shfl_xor(dt, 32, 64);
+                const float nrm = sqrtf(ss);
+                const bool clamped = nrm < 1e-12f;
+                const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+                const float c3 = clamped ? 0.0f : dt * inv * inv * inv;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dv[m2][t][r] = g * (tg[t][m2][r] * inv - c3 * v[m2][t][r]);
+                        dtg[t][m2][r] += g * inv * v[m2][t][r];
+                    }
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) db2p[m2][r] += dv[m2][0][r] + dv[m2][1][r] + dv[m2][2][r] + dv[m2][3][r];
+
+            // dr = W2^T dv (accumulator registers of dv are the B operand), du = dr where u > 0
+            f32x4 du[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) du[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        du[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][0], dv[m2][t][r2], du[0][t], 0, 0, 0);
+                        du[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][1], dv[m2][t][r2], du[1][t], 0, 0, 0);
+                    }
+            float* dst = du_ws + ((long)b * N + h) * 2048;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(16 * m + 4 * kq + r) * 64 + 16 * t + n] = acc[m][t][r] > 0.0f ? du[m][t][r] : 0.0f;
+
+            // dW2 += dv relu(u)^T: the contraction runs over positions, so both operands go through the
+            // wave's LDS image once (dv as A, relu(u) as B).
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) buf[dimg(16 * m2 + 4 * kq + r, 16 * t + n)] = dv[m2][t][r];
+            wave_lds_fence();
+            float av[2][16];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) av[mt][s] = buf[dimg(16 * mt + row, 4 * s + kq)];
+            wave_lds_fence();
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) buf[dimg(16 * m + 4 * kq + r, 16 * t + n)] = fmaxf(acc[m][t][r], 0.0f);
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float bv = buf[dimg(16 * nt + n, 4 * s + kq)];
+                    dW2[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][s], bv, dW2[0][nt], 0, 0, 0);
+                    dW2[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][s], bv, dW2[1][nt], 0, 0, 0);
+                }
+            wave_lds_fence();
+        }
+        float* gft = grad_feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) global_add(gft + (16 * m2 + 4 * kq + r) * 64 + 16 * t + n, dtg[t][m2][r]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) global_add(grad_W2 + (16 * mt + 4 * kq + r) * 32 + 16 * nt + n, dW2[mt][nt][r]);
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = db2p[m2][r];
+#pragma unroll
+            for (int s = 8; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
+            if (n == 0) global_add(grad_b2 + 16 * m2 + 4 * kq + r, x);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel 2: dW1 += du X^T, dX = W1^T du, dV += trilinear^T dX.
+// ---------------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ void bwd_quarter(f32x4 (&ax)[2][8], f32x4 (&ay)[2][8], f32x4 (&az)[2][4][2],
+                                            const float* __restrict__ W1, const float* dimgbuf, float* xbuf, const float* srcT, float* dV,
+                                            const float* Rm, int lane)
+{
+    const int n = lane & 15, kq = lane >> 4, row = lane & 15;
+    const int i0 = n >> 3, j = n & 7;
+    tri_quarter<Q>(xbuf, srcT, Rm, lane);
+    wave_lds_fence();
+    // ---- dW1 += du X^T -------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {  // x and y slabs: the 16 positions of tile Q, four per k-step
+        const int pl = 4 * s + kq, pa = pl >> 3, pb = pl & 7;
+        const float a0v = dimgbuf[dimg(row, 16 * Q + pl)], a1v = dimgbuf[dimg(16 + row, 16 * Q + pl)];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            const float bx = xbuf[(2 * kt + i0) * 128 + qoff(pa, pb, j)];  // X[k = (c, e = j)][pos = (a0, b)]
+            ax[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bx, ax[0][kt], 0, 0, 0);
+            ax[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bx, ax[1][kt], 0, 0, 0);
+            const float by = xbuf[(2 * kt + i0) * 128 + qoff(pa, j, pb)];  // X[k = (c, b = j)][pos = (a0, e)]
+            ay[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, by, ay[0][kt], 0, 0, 0);
+            ay[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, by, ay[1][kt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // bound the live ranges: one k-step's operands at a time
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {  // z slab: all 64 positions (b, e); k = (c = column, a0)
+        const int pl = 4 * s + kq;
+        const float a0v = dimgbuf[dimg(row, pl)], a1v = dimgbuf[dimg(16 + row, pl)];
+#pragma unroll
+        for (int a0 = 0; a0 < 2; ++a0) {
+            const float bz = xbuf[n * 128 + qoff(a0, pl >> 3, pl & 7)];
+            az[0][Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bz, az[0][Q][a0], 0, 0, 0);
+            az[1][Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bz, az[1][Q][a0], 0, 0, 0);
+        }
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+    // ---- dX = W1^T du, written over the X image --------------------------------------------------
+    // A operands = W1^T fragments W1[o = 4 s' + kq][k], read from L1/L2 where they are used (the 192 registers
+    // they would take are needed by the dW1 accumulators)
+    const float* wl = W1 + kq * 384 + row;                     // + s'*4*384 + k-tile base
+    const float* wzl = W1 + kq * 384 + 256 + row * 8 + 2 * Q;  // + s'*4*384 + a0
+    float bq[8];  // du[o = 4 s' + kq][pos = 16 Q + n]: B operand of the x and y slabs
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) bq[sp] = dimgbuf[dimg(4 * sp + kq, 16 * Q + n)];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[sp * (4 * 384) + 16 * kt], bq[sp], d, 0, 0, 0);
+        // rows k = 16 kt + 4 kq + r -> c = 2 kt + (kq >> 1), e = 4 (kq & 1) + r; column = position (a0 = i0, b = j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xbuf[(2 * kt + (kq >> 1)) * 128 + qoff(i0, j, 4 * (kq & 1) + r)] = d[r];
+        if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[sp * (4 * 384) + 128 + 16 * kt], bq[sp], d, 0, 0, 0);
+        // rows k -> c = 2 kt + (kq >> 1), b = 4 (kq & 1) + r; column = position (a0 = i0, e = j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xbuf[(2 * kt + (kq >> 1)) * 128 + qoff(i0, 4 * (kq & 1) + r, j)] += d[r];
+        if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float bt[8];
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) bt[sp] = dimgbuf[dimg(4 * sp + kq, 16 * t + n)];
+#pragma unroll
+        for (int a0 = 0; a0 < 2; ++a0) {
+            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wzl[sp * (4 * 384) + a0], bt[sp], d, 0, 0, 0);
+            // rows c = 4 kq + r; column = position (b = 2 t + i0, e = j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xbuf[(4 * kq + r) * 128 + qoff(a0, 2 * t + i0, j)] += d[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+    // ---- dV += trilinear^T dX (same lane -> voxel map and coefficients as the gather) ---------------
+    {
+        const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+        const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
+        const float z = (2.0f * (2 * Q + a0) + 1.0f) * 0.125f - 1.0f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int b = 4 * p + 2 * b1 + b0;
+            const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
+            TriCoef k;
+            tri_coef(k, Rm, x, y, z);
+            float d[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) d[c] = xbuf[c * 128 + qoff(a0, b, e)];
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                if (k.w[nb] != 0.0f) {
+                    float* dst = dV + k.a[nb];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) lds_add(dst + c, k.w[nb] * d[c]);
+                }
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
+__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ R, long r_batch_stride,
+    const float* __restrict__ W1, int B, long N, const float* __restrict__ du_ws, float* __restrict__ grad_vol,
+    float* __restrict__ grad_W1)
+{
+    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_dv[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];
+    __shared__ __attribute__((aligned(16))) float lds_x[4 * kQuarterFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    float* dbuf = lds_du + wave * 2048;
+    float* xbuf = lds_x + wave * kQuarterFloats;
+
+    f32x4 ax[2][8], ay[2][8], az[2][4][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            ax[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ay[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0) az[m][q][a0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const long hstep = (long)gridDim.x * 4;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kBwdThreads);
+        for (int i = tid; i < kSrcFloats; i += kBwdThreads) lds_dv[i] = 0.0f;
+        __syncthreads();
+        const float* Rb = R + (long)b * r_batch_stride;
+        for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
+            float Rm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
+            {   // du of this hypothesis -> swizzled LDS image (coalesced float4 loads, aligned float4 stores)
+                const f32x4* src = reinterpret_cast<const f32x4*>(du_ws + ((long)b * N + h) * 2048);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
+                    *reinterpret_cast<f32x4*>(dbuf + dimg(o, pos)) = src[i * 64 + lane];
+                }
+            }
+            wave_lds_fence();
+            // opaque copy of the pointer: otherwise the loop-invariant W1^T fragment loads are hoisted out of
+            // the hypothesis loop into 192 registers, which the dW1 accumulators need (spills)
+            const float* W1h = W1;
+            asm volatile("" : "+s"(W1h));
+            bwd_quarter<0>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
+            bwd_quarter<1>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
+            bwd_quarter<2>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
+            bwd_quarter<3>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
+        }
+        __syncthreads();
+        float* gv = grad_vol + (long)b * (16 * 512);
+        for (int i = tid; i < 16 * 512; i += kBwdThreads) {
+            const int c = i >> 9, v = i & 511;
+            const float x = lds_dv[((v >> 6) * kSrcPlaneRows + (v & 63)) * kSrcStride + c];
+            if (x != 0.0f) global_add(gv + i, x);
+        }
+    }
+    // dW1[o = 16 m + 4 kq + r][k]: x: k = 16 kt + n; y: 128 + 16 kt + n; z: 256 + n*8 + 2 q + a0
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* g = grad_W1 + (16 * m + 4 * kq + r) * 384;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                global_add(g + 16 * kt + n, ax[m][kt][r]);
+                global_add(g + 128 + 16 * kt + n, ay[m][kt][r]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a0 = 0; a0 < 2; ++a0) global_add(g + 256 + n * 8 + 2 * q + a0, az[m][q][a0][r]);
+        }
+}
+
+// ---- host-side launcher -------------------------------------------------------------------------------
+hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
+                                 const float* W1, const float* W2, const float* b2, int B, int64_t N,
+                                 const float* grad_scores, float* du_ws, float* grad_vol, float* grad_feat_tgt,
+                                 float* grad_W1, float* grad_W2, float* grad_b2, int num_cu, hipStream_t stream)
+{
+    hipError_t e;
+    if ((e = hipMemsetAsync(grad_vol, 0, sizeof(float) * (size_t)B * 8192, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(grad_feat_tgt, 0, sizeof(float) * (size_t)B * 2048, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(grad_W1, 0, sizeof(float) * 32 * 384, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(grad_W2, 0, sizeof(float) * 32 * 32, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(grad_b2, 0, sizeof(float) * 32, stream)) != hipSuccess) return e;
+    if (B == 0 || N == 0) return hipSuccess;
+    int gy = B < num_cu ? B : num_cu;
+    int gx = num_cu / gy;
+    const int64_t need = (N + 3) / 4;
+    if (gx > need) gx = (int)need;
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, gy);
+    hipLaunchKernelGGL(score_backward_head_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, feat_tgt, R,
+                       (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, grad_feat_tgt, grad_W2, grad_b2);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, R,
+                       (long)r_batch_stride, W1, B, (long)N, du_ws, grad_vol, grad_W1);
+    return hipGetLastError();
+}
+
+}  // namespace ahv

@@ -177,6 +177,60 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
     return scores, best_key
 
 
+@torch.no_grad()
+def score_hypotheses_backward(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
+                              W2: torch.Tensor, b2: torch.Tensor, grad_scores: torch.Tensor):
+    """Gradients of ``score_hypotheses`` w.r.t. ``(vol_src, feat_tgt, W1, W2, b2)`` given ``dL/dscores (B,N)``
+    (two launches; what ``infoNCE_loss`` back-propagates, modules/model_co3d.py:41-61).  R gets no gradient."""
+    if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
+        raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
+    B = vol_src.shape[0]
+    if tuple(feat_tgt.shape) != (B, 32, 64):
+        raise RuntimeError("feat_tgt must be (B,32,64), got %s" % (tuple(feat_tgt.shape),))
+    N, rstride = _rot_layout(R, B)
+    if tuple(grad_scores.shape) != (B, N):
+        raise RuntimeError("grad_scores must be (B,N) = %s, got %s" % ((B, N), tuple(grad_scores.shape)))
+    dev = _need_gpu(vol_src, feat_tgt, R, W1, W2, b2, grad_scores)
+    W1c, W2c, b2c = _head(W1, W2, b2)
+    vs, ft, Rc, gs = (t.detach().contiguous() for t in (vol_src, feat_tgt, R, grad_scores))
+    lib = _lib.load()
+    nbytes = lib.ahv_score_hypotheses_backward_workspace_bytes(B, N)
+    ws = torch.empty((max(nbytes, 16) // 4,), dtype=torch.float32, device=dev)
+    g_vol = torch.empty((B,) + _VOL, dtype=torch.float32, device=dev)
+    g_ft = torch.empty((B, 32, 64), dtype=torch.float32, device=dev)
+    g_W1 = torch.empty((32, 384), dtype=torch.float32, device=dev)
+    g_W2 = torch.empty((32, 32), dtype=torch.float32, device=dev)
+    g_b2 = torch.empty((32,), dtype=torch.float32, device=dev)
+    _lib.check(lib.ahv_score_hypotheses_backward_f32(vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride,
+                                                     W1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), B, N,
+                                                     gs.data_ptr(), ws.data_ptr(), ws.numel() * 4, g_vol.data_ptr(),
+                                                     g_ft.data_ptr(), g_W1.data_ptr(), g_W2.data_ptr(),
+                                                     g_b2.data_ptr(), _stream()),
+               "ahv_score_hypotheses_backward_f32")
+    return g_vol, g_ft, g_W1, g_W2, g_b2
+
+
+class _ScoreFn(torch.autograd.Function):
+    """Differentiable fused scorer: forward = one fused launch, backward = ``score_hypotheses_backward``."""
+
+    @staticmethod
+    def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2):
+        scores, _ = score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2)
+        ctx.save_for_backward(vol_src, feat_tgt, R, W1, W2, b2)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores):
+        vol_src, feat_tgt, R, W1, W2, b2 = ctx.saved_tensors
+        g_vol, g_ft, g_W1, g_W2, g_b2 = score_hypotheses_backward(vol_src, feat_tgt, R, W1, W2, b2, grad_scores)
+        return g_vol, g_ft, None, g_W1.reshape(W1.shape), g_W2.reshape(W2.shape), g_b2.reshape(b2.shape)
+
+
+def score_hypotheses_autograd(vol_src, feat_tgt, R, W1, W2, b2) -> torch.Tensor:
+    """``scores (B,N)`` with autograd support for vol_src, feat_tgt and the head weights (training path)."""
+    return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2)
+
+
 def _rot_layout(R: torch.Tensor, B: int):
     if R.dim() == 3 and tuple(R.shape[1:]) == (3, 3):
         return R.shape[0], 0

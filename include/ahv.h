@@ -239,6 +239,23 @@ size_t ahv_forward_2d3d_workspace_bytes(int B);
 int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, const float* layer4_tgt, int B,
                          void* workspace, size_t workspace_bytes, float* vol_src, float* vol_tgt, void* stream);
 
+/*
+ * Backward of ahv_score_hypotheses_f32 -- what autograd needs for Estimator.infoNCE_loss / training_step
+ * (modules/model_co3d.py:41-61,71-91; modules/model.py:43-63).  Given
+ * grad_scores[B][N] = dL/dscore it writes (not accumulates)
+ *   grad_vol_src [B][16][8][8][8], grad_feat_tgt [B][32][64], grad_W1 [32][384], grad_W2 [32][32], grad_b2 [32].
+ * R carries no gradient (the reference samples it).  r_batch_stride as in the forward (0 = shared, N*9 = the
+ * per-sample rotations of training).  The workspace holds dL/du, 8 KiB per hypothesis; sums across
+ * hypotheses use float atomics, so results are reproducible to rounding, not bitwise.
+ */
+size_t ahv_score_hypotheses_backward_workspace_bytes(int B, int64_t N);
+
+int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                                      int64_t r_batch_stride, const float* W1, const float* W2, const float* b2,
+                                      int B, int64_t N, const float* grad_scores, void* workspace,
+                                      size_t workspace_bytes, float* grad_vol_src, float* grad_feat_tgt,
+                                      float* grad_W1, float* grad_W2, float* grad_b2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""Backward of the fused scorer (ahv_score_hypotheses_backward_f32) against torch
+autograd through the reference's op sequence (oracle/torch_ref.py, stock torch operators) evaluated in fp64.
+Tolerance: gradients are sums over up to B*N hypotheses of fp32 terms -> 2e-4 of the largest entry."""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+GRAD_RTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(ahv):
+    ahv._lib.load()
+    return ahv.ops
+
+
+def ref_scores(vs, ft, R, W1, W2, b2):
+    """Differentiable reference: per sample rotate -> forward_3d2d -> mean cosine with ft (B,32,64)."""
+    from oracle import torch_ref
+    B = vs.shape[0]
+    out = []
+    for b in range(B):
+        Rb = R[b] if R.dim() == 4 else R
+        n = Rb.shape[0]
+        rot = torch_ref.rotate_volume(vs[b][None].expand(n, -1, -1, -1, -1), Rb)
+        f = torch_ref.forward_3d2d(rot, W1, W2, b2)
+        out.append((f * ft[b][None]).sum(dim=1).mean(dim=-1))
+    return torch.stack(out)
+
+
+def make_case(ahv, dev, B, N, per_sample, seed):
+    g = load_golden("score_n128")
+    rng = np.random.RandomState(seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    vs = t((rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32))
+    ft = torch.nn.functional.normalize(t(rng.standard_normal((B, 32, 64)).astype(np.float32)), dim=1)
+    R = ahv.rotations.haar_rotations_np(N * (B if per_sample else 1), seed + 1)
+    R = t(R.reshape(B, N, 3, 3) if per_sample else R)
+    gs = t(rng.standard_normal((B, N)).astype(np.float32))
+    return vs, ft, R, t(g["W1"]), t(g["W2"]), t(g["b2"]), gs
+
+
+def relerr(got, ref):
+    return ((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("B,N,per_sample", [(1, 1, False), (1, 37, False), (2, 9, True), (3, 130, True), (2, 1100, False)])
+def test_backward_matches_fp64_autograd(ops, ahv, dev, B, N, per_sample):
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, B, N, per_sample, 5 + B + N)
+    got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    leaves = [x.double().requires_grad_(True) for x in (vs, ft, W1, W2, b2)]
+    s = ref_scores(leaves[0], leaves[1], R.double(), leaves[2], leaves[3], leaves[4])
+    ref = torch.autograd.grad(s, leaves, grad_outputs=gs.double())
+    names = ["vol_src", "feat_tgt", "W1", "W2", "b2"]
+    errs = {k: relerr(a, b.reshape(a.shape)) for k, a, b in zip(names, got, ref)}
+    print(B, N, per_sample, {k: "%.1e" % v for k, v in errs.items()})
+    assert all(v < GRAD_RTOL for v in errs.values()), errs
+
+
+def test_autograd_function_trains_like_torch(ops, ahv, dev):
+    """ops.score_hypotheses_autograd inside an infoNCE-style loss: same loss and gradients as the all-torch graph."""
+    vs, ft, R, W1, W2, b2, _ = make_case(ahv, dev, 2, 64, True, 3)
+    def loss_of(score_fn, leaves):
+        s = score_fn(*leaves)
+        logits = s / 0.1
+        return -(torch.log_softmax(logits, dim=1)[:, :4].logsumexp(dim=1)).mean()
+    a = [x.clone().requires_grad_(True) for x in (vs, ft, W1, W2, b2)]
+    la = loss_of(lambda v, f, w1, w2, b: ops.score_hypotheses_autograd(v, f, R, w1, w2, b), a)
+    la.backward()
+    b_ = [x.double().clone().requires_grad_(True) for x in (vs, ft, W1, W2, b2)]
+    lb = loss_of(lambda v, f, w1, w2, b: ref_scores(v, f, R.double(), w1, w2, b), b_)
+    lb.backward()
+    assert abs(la.item() - lb.item()) < 1e-5
+    for x, y in zip(a, b_):
+        assert relerr(x.grad, y.grad) < GRAD_RTOL
+
+
+def test_backward_edge_cases(ops, ahv, dev):
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, 2, 16, False, 9)
+    # zero upstream gradient -> exact zeros; empty hypothesis set -> zeros of the right shapes
+    z = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, torch.zeros_like(gs))
+    assert all(float(t.abs().max()) == 0.0 for t in z)
+    e = ops.score_hypotheses_backward(vs, ft, R[:0], W1, W2, b2, gs[:, :0])
+    assert [tuple(t.shape) for t in e] == [(2, 16, 8, 8, 8), (2, 32, 64), (32, 384), (32, 32), (32,)]
+    assert all(float(t.abs().max()) == 0.0 for t in e)
+    with pytest.raises(RuntimeError):
+        ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs[:, :3])
+    # two calls agree to rounding (float atomics: not bitwise)
+    a = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    b = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    assert all(relerr(x, y.double()) < 1e-5 for x, y in zip(a, b))
