@@ -382,7 +382,10 @@ class Feature_Aligner(nn.Module):
         """(M,16,8,8,8) -> (M,32,64), unit norm over dim 1 (modules/modules.py:112-124). HIP kernel."""
         if self.out_channel != 32:
             raise NotImplementedError("the HIP head is built for out_channel=32 (the reference's only value)")
-        return ops.forward_3d2d(img_feat, *self.head_weights())
+        W1, W2, b2 = self.head_weights()
+        if torch.is_grad_enabled() and (img_feat.requires_grad or W1.requires_grad):
+            return ops.forward_3d2d_autograd(img_feat, W1, W2, b2)  # training: HIP forward + HIP backward
+        return ops.forward_3d2d(img_feat, W1, W2, b2)
 
     # ---- once-per-pair encoder replayed from a hipGraph -------------------------------------------
     def graphed_forward_2d3d(self, batch: int = 1):

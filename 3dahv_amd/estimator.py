@@ -11,8 +11,11 @@ Mirrored here as plain ``nn.Module`` s: constructor ``Estimator(cfg)``, attribut
 ``feature_extraction``, ``forward``, ``test_step``, ``validation_step``, ``eval()``,
 ``load_from_checkpoint(path, cfg=cfg)`` and the ``state_dict`` prefixes
 ``feature_extractor.*`` / ``feature_aligner.*``.  The per-hypothesis loop inside the steps runs
-as ONE fused HIP launch.  Lightning's trainer machinery, ``training_step`` and ``infoNCE_loss``
-(backward pass) are out of scope of this round.
+as ONE fused HIP launch.  ``training_step`` / ``infoNCE_loss`` / ``configure_optimizers`` are here as well: the
+loss back-propagates through the HIP backward of the fused scorer (``ops.score_hypotheses_autograd``,
+``ops.forward_3d2d_autograd``) and through the stock-torch encoder; Lightning's trainer machinery (DDP
+launcher, logging, checkpoint callbacks) is not mirrored -- a plain loop over ``training_step`` +
+``optimizer.step()`` is the counterpart.
 
 The MiDaS DPT/Swin-V2 backbone (``feature_extractor``) is stock timm code that is neither
 installed nor downloadable offline; it is injected (``feature_extractor=`` or
@@ -114,29 +117,57 @@ class _EstimatorBase(nn.Module):
         _ckpt.load_into(model, sd, strict=strict)
         return model
 
-    @torch.no_grad()
     def infoNCE_loss(self, img_feat_1, img_feat_2, sampled_R, gt_delta_R, reduce_mean: Optional[bool] = None):
-        """Forward value of the reference's InfoNCE loss (modules/model_co3d.py:41-61, modules/model.py:43-63):
-        per-sample hypothesis sets ``sampled_R (B,N,3,3)``, positives = hypotheses within ``DATA.ACC_THR`` degrees
-        of ``gt_delta_R``, ``-log(sum_pos exp(s/0.1) / sum_all exp(s/0.1))``.  The (B,N) similarities come from ONE
-        fused HIP launch with per-sample rotations.  No autograd graph: the backward of the rotate/projection
-        path is not built yet, so this serves validation / monitoring.
+        """The reference's InfoNCE loss (modules/model_co3d.py:41-61, modules/model.py:43-63): per-sample
+        hypothesis sets ``sampled_R (B,N,3,3)``, positives = hypotheses within ``DATA.ACC_THR`` degrees of
+        ``gt_delta_R``, ``-log(sum_pos exp(s/0.1) / sum_all exp(s/0.1))``.  The (B,N) similarities come from ONE
+        fused HIP launch with per-sample rotations; under autograd their backward is the two-kernel HIP backward
+        (``ops.score_hypotheses_autograd``), so the loss is differentiable w.r.t. both volumes and the head.
         ``reduce_mean`` defaults to the variant's behaviour: mean (model_co3d.py:59) or per-sample (model.py:61)."""
         import math
-        bs = gt_delta_R.shape[0]
-        gt_sim = (torch.sum(sampled_R.flatten(2) * gt_delta_R.reshape(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
-        positive = 180 * (torch.arccos(gt_sim) / math.pi) <= self.cfg["DATA"]["ACC_THR"]          # (B, N)
+        with torch.no_grad():
+            gt_sim = (torch.sum(sampled_R.flatten(2) * gt_delta_R.reshape(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+            positive = 180 * (torch.arccos(gt_sim) / math.pi) <= self.cfg["DATA"]["ACC_THR"]      # (B, N)
         f_tgt = self.feature_aligner.forward_3d2d(img_feat_2)
-        sim, _ = ops.score_hypotheses(img_feat_1, f_tgt, sampled_R.contiguous(), *self.feature_aligner.head_weights())
+        W1, W2, b2 = self.feature_aligner.head_weights()
+        if torch.is_grad_enabled() and (img_feat_1.requires_grad or f_tgt.requires_grad or W1.requires_grad):
+            sim = ops.score_hypotheses_autograd(img_feat_1, f_tgt, sampled_R.contiguous(), W1, W2, b2)
+        else:
+            sim, _ = ops.score_hypotheses(img_feat_1, f_tgt, sampled_R.contiguous(), W1, W2, b2)
         e = torch.exp(sim / 0.1)
         loss = -torch.log((e * positive).sum(dim=-1) / e.sum(dim=-1).clamp(min=1e-8))
         if reduce_mean is None:
             reduce_mean = isinstance(self, EstimatorCo3d)
         return loss.mean() if reduce_mean else loss
 
-    def training_step(self, batch, batch_idx):
-        raise NotImplementedError("training (the backward of infoNCE_loss through the rotation/projection path) is "
-                                  "the next row of SURVEY.md section 8(f); this build covers inference")
+    def sample_training_rotations(self, gt_src_2_tgt_R):
+        """``cat([gt, random_rotations(B*(num_rota-1))])`` (modules/model_co3d.py:84-86): the ground truth is
+        hypothesis 0 of every sample, the rest are fresh Haar samples (generated on the GPU)."""
+        B, dev = gt_src_2_tgt_R.shape[0], gt_src_2_tgt_R.device
+        self._proposal_draws += 1
+        n = B * (self.num_rota - 1)
+        if dev.type == "cuda":
+            R = ops.random_rotations(n, seed=torch.initial_seed() + self._proposal_draws, device=dev)
+        else:
+            R = random_rotations(n, device=dev)
+        return torch.cat([gt_src_2_tgt_R[:, None], R.reshape(B, self.num_rota - 1, 3, 3)], dim=1)
+
+    def training_loss(self, vol_src, vol_tgt, gt_src_2_tgt_R):
+        """Everything of ``training_step`` after the encoder: sample rotations, InfoNCE (mean over the batch)."""
+        with torch.no_grad():
+            sampled_R = self.sample_training_rotations(gt_src_2_tgt_R)
+        return self.infoNCE_loss(vol_src, vol_tgt, sampled_R, gt_src_2_tgt_R, reduce_mean=True)
+
+    def configure_optimizers(self):
+        """AdamW(eps=1e-5) on the aligner (+ backbone when present) and StepLR(200, 0.1)
+        (modules/model_co3d.py:93-99)."""
+        lr = float(self.cfg["TRAIN"]["LR"])
+        groups = [{"params": self.feature_aligner.parameters(), "lr": lr}]
+        if isinstance(self.feature_extractor, nn.Module):
+            groups.append({"params": self.feature_extractor.parameters(), "lr": lr})
+        optimizer = torch.optim.AdamW(groups, eps=1e-5)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=200, gamma=0.1)
+        return [optimizer], [scheduler]
 
 
 class EstimatorCo3d(_EstimatorBase):
@@ -145,6 +176,17 @@ class EstimatorCo3d(_EstimatorBase):
     def forward(self, img_src, img_tgt):
         f_src, f_tgt = self.feature_extraction(img_src), self.feature_extraction(img_tgt)
         return self.forward_features(f_src, f_tgt)
+
+    def training_step(self, batch, batch_idx):
+        """modules/model_co3d.py:71-91: batch keys ``image (B,2,3,S,S)``, ``relative_rotation (B,1,3,3)``."""
+        img_src, img_tgt = batch["image"][:, 0], batch["image"][:, 1]
+        gt = batch["relative_rotation"].squeeze(1)
+        vol_src, vol_tgt = self.feature_aligner.forward_2d3d(
+            self.feature_extraction(img_src), self.feature_extraction(img_tgt),
+            random_mask=self.cfg["TRAIN"]["MASK"], mask_ratio=self.cfg["TRAIN"]["MASK_RATIO"])
+        loss = self.training_loss(vol_src, vol_tgt, gt)
+        self.log("train_loss", loss.item())
+        return loss
 
 
 class EstimatorObjaverse(_EstimatorBase):
@@ -155,6 +197,28 @@ class EstimatorObjaverse(_EstimatorBase):
             img_src, img_tgt = img_src * mask_src, img_tgt * mask_tgt
         f_src, f_tgt = self.feature_extraction(img_src), self.feature_extraction(img_tgt)
         return self.forward_features(f_src, f_tgt)
+
+    def training_step(self, batch, batch_idx):
+        """modules/model.py:78-116: masks out small objects / far views from the per-sample losses."""
+        mask_src, mask_tgt = batch["src_mask"], batch["ref_mask"]
+        img_src, img_tgt = batch["src_img"], batch["ref_img"]
+        if self.cfg["DATA"]["BG"] is False:
+            img_src, img_tgt = img_src * mask_src, img_tgt * mask_tgt
+        with torch.no_grad():
+            gt = torch.bmm(batch["ref_R"], torch.inverse(batch["src_R"]))
+        vol_src, vol_tgt = self.feature_aligner.forward_2d3d(
+            self.feature_extraction(img_src), self.feature_extraction(img_tgt),
+            random_mask=self.cfg["TRAIN"]["MASK"], mask_ratio=self.cfg["TRAIN"]["MASK_RATIO"])
+        with torch.no_grad():
+            self.Rs = self.sample_training_rotations(gt)
+        thr = self.cfg["DATA"]["SIZE_THR"]
+        valid = (mask_src.flatten(1).sum(dim=-1) > thr) * (mask_tgt.flatten(1).sum(dim=-1) > thr)
+        if "dis_init" in batch:
+            valid = valid * (batch["dis_init"] < self.cfg["DATA"]["VIEW_THR"]).float()
+        loss = self.infoNCE_loss(vol_src, vol_tgt, self.Rs, gt, reduce_mean=False) * valid
+        loss = loss.sum() / valid.sum().clamp(min=1e-8)
+        self.log("train_loss", loss.item())
+        return loss
 
     def _too_small(self, mask_src, mask_tgt):
         thr = self.cfg["DATA"]["SIZE_THR"]

@@ -231,6 +231,32 @@ def score_hypotheses_autograd(vol_src, feat_tgt, R, W1, W2, b2) -> torch.Tensor:
     return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2)
 
 
+class _Forward3d2dFn(torch.autograd.Function):
+    """Differentiable ``forward_3d2d``.  The backward reuses the scorer's: with R = identity the scorer's feature
+    IS forward_3d2d(vol) (an identity rotation reproduces the voxels exactly), and for L = sum(dF * f) the
+    gradients equal those of 64 * score computed against "target" dF -- so one call with N = 1, R = I,
+    feat_tgt = dF and grad_scores = 64 returns d vol, d W1, d W2, d b2."""
+
+    @staticmethod
+    def forward(ctx, vol, W1, W2, b2):
+        ctx.save_for_backward(vol, W1, W2, b2)
+        return forward_3d2d(vol, W1, W2, b2)
+
+    @staticmethod
+    def backward(ctx, dF):
+        vol, W1, W2, b2 = ctx.saved_tensors
+        M = vol.shape[0]
+        eye = torch.eye(3, dtype=torch.float32, device=vol.device).reshape(1, 3, 3)
+        gs = torch.full((M, 1), 64.0, dtype=torch.float32, device=vol.device)
+        g_vol, _, g_W1, g_W2, g_b2 = score_hypotheses_backward(vol, dF.contiguous(), eye, W1, W2, b2, gs)
+        return g_vol, g_W1.reshape(W1.shape), g_W2.reshape(W2.shape), g_b2.reshape(b2.shape)
+
+
+def forward_3d2d_autograd(img_feat, W1, W2, b2) -> torch.Tensor:
+    """``forward_3d2d`` with autograd support for the volume and the head weights (training path)."""
+    return _Forward3d2dFn.apply(img_feat, W1, W2, b2)
+
+
 def _rot_layout(R: torch.Tensor, B: int):
     if R.dim() == 3 and tuple(R.shape[1:]) == (3, 3):
         return R.shape[0], 0
