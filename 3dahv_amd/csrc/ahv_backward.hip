@@ -4,13 +4,13 @@
 //
 //   scores[b][n] = 1/64 sum_pos <normalize(W2 relu(W1 slabs(rot(V_b, R_n))) + b2)[:, pos], tg_b[:, pos]>
 //
-// Two launches, nothing of the 32 KiB-per-hypothesis rotated volumes or 96 KiB slab tensors ever reaches HBM:
-//   1. score_backward_head_kernel   recomputes the forward of each hypothesis (same code as the forward
-//      kernel), back-propagates through the score, the normalisation, GEMM2 and the ReLU and leaves
-//      du = dL/du (32 x 64 floats per hypothesis) in the caller's workspace; accumulates d feat_tgt, d W2, d b2.
-//   2. score_backward_volume_kernel re-gathers each quarter of the rotated volume, accumulates
-//      dW1 += du X^T in registers, forms dX = W1^T du and scatters it through the trilinear weights into a
-//      per-workgroup LDS image of dV that is flushed once per sample.
+// Three launches, nothing of the 32 KiB-per-hypothesis rotated volumes or 96 KiB slab tensors ever reaches HBM:
+//   1.  score_backward_head_kernel   recomputes the forward of each hypothesis (same code as the forward
+//       kernel), back-propagates through the score, the normalisation, GEMM2 and the ReLU and leaves
+//       du = dL/du (32 x 64 floats per hypothesis) in the caller's workspace; accumulates d feat_tgt, d W2, d b2.
+//   2a. score_backward_w1_kernel     re-gathers each quarter of the rotated volume, dW1 += du X^T in registers.
+//   2b. score_backward_volume_kernel forms dX = W1^T du and scatters it through the trilinear weights into a
+//       per-workgroup LDS image of dV that is flushed once per sample.
 // All contractions are fp32 MFMA 16x16x4 (one float per lane and operand, so any LDS layout can feed them).
 // Accumulation across waves/workgroups uses float atomics: gradients are reproducible to rounding, not bitwise.
 #include <hip/hip_runtime.h>
@@ -231,94 +231,190 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Kernel 2: dW1 += du X^T, dX = W1^T du, dV += trilinear^T dX.
+// Kernels 2a / 2b.  Both walk the hypotheses again with du from the workspace.  They are separate launches
+// because each needs 192 registers of persistent state per wave (2a: the dW1 accumulators, 2b: the W1^T
+// fragments) next to a gather / scatter that wants ~100 more: together they spill, apart they do not.
+//   2a  score_backward_w1_kernel      re-gathers each quarter X of the rotated volume, dW1 += du X^T
+//   2b  score_backward_volume_kernel  dX = W1^T du per quarter, dV += trilinear^T dX in an LDS image of the
+//                                     sample's volume gradient, flushed once per sample
 // ---------------------------------------------------------------------------------------------------
+
+// X image of 2a: plane c rotated by 4c floats, so that the z slab's B operand (16 lanes = 16 channels of one
+// voxel) spreads over 8 banks instead of one; all other accesses have c uniform per instruction.
+__device__ __forceinline__ int xoff(int c, int a0, int b, int e) { return c * 128 + ((qoff(a0, b, e) + 4 * c) & 127); }
+
+__device__ __forceinline__ void load_du_image(float* dbuf, const float* __restrict__ du_hyp, int lane)
+{
+    const f32x4* src = reinterpret_cast<const f32x4*>(du_hyp);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // coalesced float4 loads, aligned float4 stores (dimg keeps groups of 4 together)
+        const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
+        *reinterpret_cast<f32x4*>(dbuf + dimg(o, pos)) = src[i * 64 + lane];
+    }
+}
+
 template <int Q>
-__device__ __forceinline__ void bwd_quarter(f32x4 (&ax)[2][8], f32x4 (&ay)[2][8], f32x4 (&az)[2][4][2],
-                                            const float* __restrict__ W1, const float* dimgbuf, float* xbuf, const float* srcT, float* dV,
-                                            const float* Rm, int lane)
+__device__ __forceinline__ void bwd_w1_quarter(f32x4 (&ax)[2][8], f32x4 (&ay)[2][8], f32x4 (&az)[2][4][2],
+                                               const float* dbuf, float* xbuf, const float* srcT, const float* Rm,
+                                               int lane)
 {
     const int n = lane & 15, kq = lane >> 4, row = lane & 15;
     const int i0 = n >> 3, j = n & 7;
-    tri_quarter<Q>(xbuf, srcT, Rm, lane);
+    {   // gather quarter Q (same lane -> voxel map as tri_quarter) into the rotated-plane image
+        const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+        const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
+        const float z = (2.0f * (2 * Q + a0) + 1.0f) * 0.125f - 1.0f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int b = 4 * p + 2 * b1 + b0;
+            const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
+            TriCoefP k;
+            tri_coef_ptr(k, srcT, Rm, x, y, z);
+            float o[16];
+            tri_blend_ptr(o, k);
+            const int q0 = qoff(a0, b, e);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) xbuf[c * 128 + ((q0 + 4 * c) & 127)] = o[c];
+        }
+    }
     wave_lds_fence();
-    // ---- dW1 += du X^T -------------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < 4; ++s) {  // x and y slabs: the 16 positions of tile Q, four per k-step
         const int pl = 4 * s + kq, pa = pl >> 3, pb = pl & 7;
-        const float a0v = dimgbuf[dimg(row, 16 * Q + pl)], a1v = dimgbuf[dimg(16 + row, 16 * Q + pl)];
+        const float a0v = dbuf[dimg(row, 16 * Q + pl)], a1v = dbuf[dimg(16 + row, 16 * Q + pl)];
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            const float bx = xbuf[(2 * kt + i0) * 128 + qoff(pa, pb, j)];  // X[k = (c, e = j)][pos = (a0, b)]
+            const float bx = xbuf[xoff(2 * kt + i0, pa, pb, j)];  // X[k = (c, e = j)][pos = (a0, b)]
             ax[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bx, ax[0][kt], 0, 0, 0);
             ax[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bx, ax[1][kt], 0, 0, 0);
-            const float by = xbuf[(2 * kt + i0) * 128 + qoff(pa, j, pb)];  // X[k = (c, b = j)][pos = (a0, e)]
+            const float by = xbuf[xoff(2 * kt + i0, pa, j, pb)];  // X[k = (c, b = j)][pos = (a0, e)]
             ay[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, by, ay[0][kt], 0, 0, 0);
             ay[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, by, ay[1][kt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);  // bound the live ranges: one k-step's operands at a time
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // z slab: all 64 positions (b, e); k = (c = column, a0)
         const int pl = 4 * s + kq;
-        const float a0v = dimgbuf[dimg(row, pl)], a1v = dimgbuf[dimg(16 + row, pl)];
+        const float a0v = dbuf[dimg(row, pl)], a1v = dbuf[dimg(16 + row, pl)];
 #pragma unroll
         for (int a0 = 0; a0 < 2; ++a0) {
-            const float bz = xbuf[n * 128 + qoff(a0, pl >> 3, pl & 7)];
+            const float bz = xbuf[xoff(n, a0, pl >> 3, pl & 7)];
             az[0][Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bz, az[0][Q][a0], 0, 0, 0);
             az[1][Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bz, az[1][Q][a0], 0, 0, 0);
         }
-        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
-    // ---- dX = W1^T du, written over the X image --------------------------------------------------
-    // A operands = W1^T fragments W1[o = 4 s' + kq][k], read from L1/L2 where they are used (the 192 registers
-    // they would take are needed by the dW1 accumulators)
-    const float* wl = W1 + kq * 384 + row;                     // + s'*4*384 + k-tile base
-    const float* wzl = W1 + kq * 384 + 256 + row * 8 + 2 * Q;  // + s'*4*384 + a0
+}
+
+__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_w1_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ R, long r_batch_stride, int B, long N,
+    const float* __restrict__ du_ws, float* __restrict__ grad_W1)
+{
+    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];
+    __shared__ __attribute__((aligned(16))) float lds_x[4 * kQuarterFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    float* dbuf = lds_du + wave * 2048;
+    float* xbuf = lds_x + wave * kQuarterFloats;
+    f32x4 ax[2][8], ay[2][8], az[2][4][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            ax[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ay[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0) az[m][q][a0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long hstep = (long)gridDim.x * 4;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kBwdThreads);
+        __syncthreads();
+        const float* Rb = R + (long)b * r_batch_stride;
+        for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
+            float Rm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
+            load_du_image(dbuf, du_ws + ((long)b * N + h) * 2048, lane);
+            wave_lds_fence();
+            bwd_w1_quarter<0>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
+            bwd_w1_quarter<1>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
+            bwd_w1_quarter<2>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
+            bwd_w1_quarter<3>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
+        }
+    }
+    // dW1[o = 16 m + 4 kq + r][k]: x: k = 16 kt + n; y: 128 + 16 kt + n; z: 256 + n*8 + 2 q + a0
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* g = grad_W1 + (16 * m + 4 * kq + r) * 384;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                global_add(g + 16 * kt + n, ax[m][kt][r]);
+                global_add(g + 128 + 16 * kt + n, ay[m][kt][r]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a0 = 0; a0 < 2; ++a0) global_add(g + 256 + n * 8 + 2 * q + a0, az[m][q][a0][r]);
+        }
+}
+
+template <int Q>
+__device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const float (&wy)[8][8],
+                                                const float (&wz)[4][2][8], const float* dbuf, float* xbuf,
+                                                float* dV, const float* Rm, int lane)
+{
+    const int n = lane & 15, kq = lane >> 4;
+    const int i0 = n >> 3, j = n & 7;
+    // ---- dX = W1^T du for the voxels of quarter Q ---------------------------------------------------
     float bq[8];  // du[o = 4 s' + kq][pos = 16 Q + n]: B operand of the x and y slabs
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp) bq[sp] = dimgbuf[dimg(4 * sp + kq, 16 * Q + n)];
+    for (int sp = 0; sp < 8; ++sp) bq[sp] = dbuf[dimg(4 * sp + kq, 16 * Q + n)];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
         f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[sp * (4 * 384) + 16 * kt], bq[sp], d, 0, 0, 0);
+        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[kt][sp], bq[sp], d, 0, 0, 0);
         // rows k = 16 kt + 4 kq + r -> c = 2 kt + (kq >> 1), e = 4 (kq & 1) + r; column = position (a0 = i0, b = j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) xbuf[(2 * kt + (kq >> 1)) * 128 + qoff(i0, j, 4 * (kq & 1) + r)] = d[r];
-        if (kt & 1) __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
         f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[sp * (4 * 384) + 128 + 16 * kt], bq[sp], d, 0, 0, 0);
+        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wy[kt][sp], bq[sp], d, 0, 0, 0);
         // rows k -> c = 2 kt + (kq >> 1), b = 4 (kq & 1) + r; column = position (a0 = i0, e = j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) xbuf[(2 * kt + (kq >> 1)) * 128 + qoff(i0, 4 * (kq & 1) + r, j)] += d[r];
-        if (kt & 1) __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float bt[8];
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) bt[sp] = dimgbuf[dimg(4 * sp + kq, 16 * t + n)];
+        for (int sp = 0; sp < 8; ++sp) bt[sp] = dbuf[dimg(4 * sp + kq, 16 * t + n)];
 #pragma unroll
         for (int a0 = 0; a0 < 2; ++a0) {
             f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wzl[sp * (4 * 384) + a0], bt[sp], d, 0, 0, 0);
+            for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[Q][a0][sp], bt[sp], d, 0, 0, 0);
             // rows c = 4 kq + r; column = position (b = 2 t + i0, e = j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xbuf[(4 * kq + r) * 128 + qoff(a0, 2 * t + i0, j)] += d[r];
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
-    // ---- dV += trilinear^T dX (same lane -> voxel map and coefficients as the gather) ---------------
+    // ---- dV += trilinear^T dX (same lane -> voxel map and coefficients as the gather) -------------------
     {
         const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
         const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
@@ -346,38 +442,37 @@ __device__ __forceinline__ void bwd_quarter(f32x4 (&ax)[2][8], f32x4 (&ay)[2][8]
 }
 
 __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
-    const float* __restrict__ vol_src, const float* __restrict__ R, long r_batch_stride,
-    const float* __restrict__ W1, int B, long N, const float* __restrict__ du_ws, float* __restrict__ grad_vol,
-    float* __restrict__ grad_W1)
+    const float* __restrict__ R, long r_batch_stride, const float* __restrict__ W1, int B, long N,
+    const float* __restrict__ du_ws, float* __restrict__ grad_vol)
 {
-    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
     __shared__ __attribute__((aligned(16))) float lds_dv[kSrcFloats];
     __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];
     __shared__ __attribute__((aligned(16))) float lds_x[4 * kQuarterFloats];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, kq = lane >> 4;
+    const int kq = lane >> 4, row = lane & 15;
     float* dbuf = lds_du + wave * 2048;
     float* xbuf = lds_x + wave * kQuarterFloats;
 
-    f32x4 ax[2][8], ay[2][8], az[2][4][2];
+    // W1^T fragments, A operands of dX: [k-tile][k-step over o]: W1[o = 4 s' + kq][k = base + row]
+    float wx[8][8], wy[8][8], wz[4][2][8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int sp = 0; sp < 8; ++sp) {
+        const float* w = W1 + (4 * sp + kq) * 384;
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            ax[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ay[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wx[kt][sp] = w[16 * kt + row];
+            wy[kt][sp] = w[128 + 16 * kt + row];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int a0 = 0; a0 < 2; ++a0) az[m][q][a0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a0 = 0; a0 < 2; ++a0) wz[q][a0][sp] = w[256 + row * 8 + 2 * q + a0];
     }
 
     const long hstep = (long)gridDim.x * 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kBwdThreads);
         for (int i = tid; i < kSrcFloats; i += kBwdThreads) lds_dv[i] = 0.0f;
         __syncthreads();
         const float* Rb = R + (long)b * r_batch_stride;
@@ -385,23 +480,12 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
-            {   // du of this hypothesis -> swizzled LDS image (coalesced float4 loads, aligned float4 stores)
-                const f32x4* src = reinterpret_cast<const f32x4*>(du_ws + ((long)b * N + h) * 2048);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
-                    *reinterpret_cast<f32x4*>(dbuf + dimg(o, pos)) = src[i * 64 + lane];
-                }
-            }
+            load_du_image(dbuf, du_ws + ((long)b * N + h) * 2048, lane);
             wave_lds_fence();
-            // opaque copy of the pointer: otherwise the loop-invariant W1^T fragment loads are hoisted out of
-            // the hypothesis loop into 192 registers, which the dW1 accumulators need (spills)
-            const float* W1h = W1;
-            asm volatile("" : "+s"(W1h));
-            bwd_quarter<0>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
-            bwd_quarter<1>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
-            bwd_quarter<2>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
-            bwd_quarter<3>(ax, ay, az, W1h, dbuf, xbuf, lds_src, lds_dv, Rm, lane);
+            bwd_vol_quarter<0>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
+            bwd_vol_quarter<1>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
+            bwd_vol_quarter<2>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
+            bwd_vol_quarter<3>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
         }
         __syncthreads();
         float* gv = grad_vol + (long)b * (16 * 512);
@@ -411,22 +495,6 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
             if (x != 0.0f) global_add(gv + i, x);
         }
     }
-    // dW1[o = 16 m + 4 kq + r][k]: x: k = 16 kt + n; y: 128 + 16 kt + n; z: 256 + n*8 + 2 q + a0
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* g = grad_W1 + (16 * m + 4 * kq + r) * 384;
-#pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                global_add(g + 16 * kt + n, ax[m][kt][r]);
-                global_add(g + 128 + 16 * kt + n, ay[m][kt][r]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int a0 = 0; a0 < 2; ++a0) global_add(g + 256 + n * 8 + 2 * q + a0, az[m][q][a0][r]);
-        }
 }
 
 // ---- host-side launcher -------------------------------------------------------------------------------
@@ -451,8 +519,11 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     hipLaunchKernelGGL(score_backward_head_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, feat_tgt, R,
                        (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, grad_feat_tgt, grad_W2, grad_b2);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, R,
-                       (long)r_batch_stride, W1, B, (long)N, du_ws, grad_vol, grad_W1);
+    hipLaunchKernelGGL(score_backward_w1_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, R, (long)r_batch_stride,
+                       B, (long)N, du_ws, grad_W1);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kBwdThreads), 0, stream, R, (long)r_batch_stride, W1,
+                       B, (long)N, du_ws, grad_vol);
     return hipGetLastError();
 }
 

@@ -105,3 +105,38 @@ if not only or "enc" in only:
         rel = max(((x - y).abs().max() / y.abs().max()).item() for x, y in zip(ref_hip, ref_t))
         print(json.dumps({"config": "encoder forward_2d3d", "B": B, "hip_us": ms_hip * 1e3, "torch_ops_us": ms_torch * 1e3,
                           "max_rel_diff": rel}))
+
+if not only or "train" in only:
+    # training-size scorer step (reference config.yaml: TRAIN.BS 12, DATA.NUM_ROTA 3000, per-sample rotations):
+    # forward + backward of the (B,N) similarities, HIP fused kernels vs autograd over stock PyTorch-ROCm operators
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref
+    B, N = 12, 3000
+    vs = vol[0, :B].clone().requires_grad_(True)
+    vt = vol[1, :B].clone()
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(B * N, 13)).to(dev).reshape(B, N, 3, 3)
+    P = [W1.clone().requires_grad_(True), W2.clone().requires_grad_(True), b2.clone().requires_grad_(True)]
+    gs = torch.randn(B, N, device=dev)
+
+    def hip_step():
+        ft = ops.forward_3d2d_autograd(vt, *P)
+        s = ops.score_hypotheses_autograd(vs, ft, R, *P)
+        return torch.autograd.grad(s, [vs] + P, grad_outputs=gs)
+
+    def torch_step():
+        ft = torch_ref.forward_3d2d(vt, *P)
+        out = []
+        for b in range(B):
+            rot = torch_ref.rotate_volume(vs[b][None].expand(N, -1, -1, -1, -1), R[b])
+            out.append((torch_ref.forward_3d2d(rot, *P) * ft[b][None]).sum(dim=1).mean(dim=-1))
+        return torch.autograd.grad(torch.stack(out), [vs] + P, grad_outputs=gs)
+
+    ms_hip = timeit(hip_step, 10)
+    ms_fwd = timeit(lambda: ops.score_hypotheses(vs, ops.forward_3d2d(vt, W1, W2, b2), R, W1, W2, b2), 10)
+    ms_bwd = timeit(lambda: ops.score_hypotheses_backward(vs, ops.forward_3d2d(vt, W1, W2, b2), R, W1, W2, b2, gs), 10)
+    ms_torch = timeit(torch_step, 3, warm=1)
+    ga, gb = hip_step(), torch_step()
+    rel = max(((x - y).abs().max() / y.abs().max()).item() for x, y in zip(ga, gb))
+    print(json.dumps({"config": "training scorer step", "B": B, "N": N, "hip_fwd_bwd_ms": ms_hip, "hip_fwd_only_ms": ms_fwd,
+                      "hip_bwd_only_ms": ms_bwd, "torch_autograd_ms": ms_torch, "speedup": ms_torch / ms_hip,
+                      "max_rel_grad_diff_vs_torch_fp32": rel, "hyp_per_s_fwd_bwd": B * N / ms_hip * 1e3}))
