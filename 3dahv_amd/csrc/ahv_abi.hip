@@ -24,8 +24,8 @@ hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_
                                   int64_t*, hipStream_t);
 hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
-                                 const float*, int, int64_t, const float*, float*, float*, float*, float*, float*,
-                                 float*, int, hipStream_t);
+                                 const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*,
+                                 float*, float*, int, hipStream_t);
 extern int g_score_variant;
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
@@ -255,7 +255,8 @@ int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, 
 size_t ahv_score_hypotheses_backward_workspace_bytes(int B, int64_t N)
 {
     if (B <= 0 || N <= 0) return 0;
-    return sizeof(float) * 2048 * (size_t)B * (size_t)N;
+    // dL/du per hypothesis + one max|du| word per sample (rounded up to 16 bytes)
+    return sizeof(float) * (2048 * (size_t)B * (size_t)N + (((size_t)B + 3) & ~(size_t)3));
 }
 
 int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tgt, const float* R,
@@ -282,8 +283,10 @@ int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tg
     const int cu = cu_count();
     if (cu <= 0) return fail(AHV_EDEVICE, "score_backward: no usable HIP device");
     hipError_t e = ahv::launch_score_backward(vol_src, feat_tgt, R, r_batch_stride, W1, W2, b2, B, N, grad_scores,
-                                              static_cast<float*>(workspace), grad_vol_src, grad_feat_tgt, grad_W1,
-                                              grad_W2, grad_b2, cu, static_cast<hipStream_t>(stream));
+                                              static_cast<float*>(workspace),
+                                              reinterpret_cast<unsigned*>(static_cast<float*>(workspace) + 2048 * (size_t)B * (size_t)N),
+                                              grad_vol_src, grad_feat_tgt, grad_W1, grad_W2, grad_b2, cu,
+                                              static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("score_backward: launch", e);
     return AHV_OK;
 }

@@ -28,9 +28,37 @@ constexpr int kBwdThreads = 256;  // 4 waves, one per SIMD: 512 registers per wa
 // positions together (float4 fills) and spreads rows over banks for the transposed reads (k = pos).
 __device__ __forceinline__ int dimg(int o, int pos) { return o * 64 + (pos ^ ((o & 7) << 2)); }
 
-__device__ __forceinline__ void lds_add(float* p, float v)
+__device__ __forceinline__ void lds_add_i64(long long* p, long long v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// |x| < 2^40 -> nearest integer as int64, in a handful of VALU instructions (there is no f32 -> i64 convert):
+// x = h * 2^20 + r with h = rint(x / 2^20); the subtraction is exact.
+__device__ __forceinline__ long long to_fixed(float x)
+{
+    const float h = rintf(x * 0x1p-20f);
+    const float r = x - h * 0x1p20f;
+    return ((long long)(int)h << 20) + (long long)(int)rintf(r);
+}
+
+// Corner weights and DENSE channel-last row offsets (16 words per voxel, voxel = z*64 + y*8 + x).
+__device__ __forceinline__ void tri_coef_dense(float (&w)[8], int (&a)[8], const float* Rm, float x, float y, float z)
+{
+    const float gx = Rm[0] * x + Rm[1] * y + Rm[2] * z;
+    const float gy = Rm[3] * x + Rm[4] * y + Rm[5] * z;
+    const float gz = Rm[6] * x + Rm[7] * y + Rm[8] * z;
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+    int ox0, ox1, oy0, oy1, oz0, oz1;
+    axis_coef(gx, wx0, wx1, ox0, ox1, 16);
+    axis_coef(gy, wy0, wy1, oy0, oy1, 8 * 16);
+    axis_coef(gz, wz0, wz1, oz0, oz1, 64 * 16);
+    const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
+    w[0] = w00 * wx0; w[1] = w00 * wx1; w[2] = w01 * wx0; w[3] = w01 * wx1;
+    w[4] = w10 * wx0; w[5] = w10 * wx1; w[6] = w11 * wx0; w[7] = w11 * wx1;
+    const int a00 = oz0 + oy0, a01 = oz0 + oy1, a10 = oz1 + oy0, a11 = oz1 + oy1;
+    a[0] = a00 + ox0; a[1] = a00 + ox1; a[2] = a01 + ox0; a[3] = a01 + ox1;
+    a[4] = a10 + ox0; a[5] = a10 + ox1; a[6] = a11 + ox0; a[7] = a11 + ox1;
 }
 
 __device__ __forceinline__ void global_add(float* p, float v)
@@ -45,7 +73,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
     long r_batch_stride, const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ b2,
     int B, long N, const float* __restrict__ grad_scores, float* __restrict__ du_ws,
-    float* __restrict__ grad_feat_tgt, float* __restrict__ grad_W2, float* __restrict__ grad_b2)
+    unsigned* __restrict__ du_max_bits, float* __restrict__ grad_feat_tgt, float* __restrict__ grad_W2, float* __restrict__ grad_b2)
 {
     __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
@@ -96,6 +124,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
                     }
         }
         const float* Rb = R + (long)b * r_batch_stride;
+        float du_amax = 0.0f;
         for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
@@ -170,8 +199,12 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dst[(16 * m + 4 * kq + r) * 64 + 16 * t + n] = acc[m][t][r] > 0.0f ? du[m][t][r] : 0.0f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[m][t][r] > 0.0f ? du[m][t][r] : 0.0f;
+                        dst[(16 * m + 4 * kq + r) * 64 + 16 * t + n] = x;
+                        // max |du| of the sample (kernel 2b sizes its fixed-point scale with it); NaN / inf poison it
+                        du_amax = (x == x) ? fmaxf(du_amax, fabsf(x)) : __builtin_inff();
+                    }
 
             // dW2 += dv relu(u)^T: the contraction runs over positions, so both operands go through the
             // wave's LDS image once (dv as A, relu(u) as B).
@@ -205,6 +238,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
                 }
             wave_lds_fence();
         }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) du_amax = fmaxf(du_amax, __shfl_xor(du_amax, sft, 64));
+        if (lane == 0) atomicMax(du_max_bits + b, __float_as_uint(du_amax));  // non-negative floats order like uints
         float* gft = grad_feat_tgt + (long)b * (32 * 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -369,8 +405,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_w1_kernel(
 
 template <int Q>
 __device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const float (&wy)[8][8],
-                                                const float (&wz)[4][2][8], const float* dbuf, float* xbuf,
-                                                float* dV, const float* Rm, int lane)
+                                                const float (&wz)[4][2][8], float* dbuf, float* xbuf,
+                                                long long* dV, float fx_scale, const float* Rm, int lane)
 {
     const int n = lane & 15, kq = lane >> 4;
     const int i0 = n >> 3, j = n & 7;
@@ -385,7 +421,7 @@ __device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const f
         for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[kt][sp], bq[sp], d, 0, 0, 0);
         // rows k = 16 kt + 4 kq + r -> c = 2 kt + (kq >> 1), e = 4 (kq & 1) + r; column = position (a0 = i0, b = j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xbuf[(2 * kt + (kq >> 1)) * 128 + qoff(i0, j, 4 * (kq & 1) + r)] = d[r];
+        for (int r = 0; r < 4; ++r) xbuf[xoff(2 * kt + (kq >> 1), i0, j, 4 * (kq & 1) + r)] = d[r];
     }
     wave_lds_fence();
 #pragma unroll
@@ -395,7 +431,7 @@ __device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const f
         for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wy[kt][sp], bq[sp], d, 0, 0, 0);
         // rows k -> c = 2 kt + (kq >> 1), b = 4 (kq & 1) + r; column = position (a0 = i0, e = j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xbuf[(2 * kt + (kq >> 1)) * 128 + qoff(i0, 4 * (kq & 1) + r, j)] += d[r];
+        for (int r = 0; r < 4; ++r) xbuf[xoff(2 * kt + (kq >> 1), i0, 4 * (kq & 1) + r, j)] += d[r];
     }
     wave_lds_fence();
 #pragma unroll
@@ -410,11 +446,14 @@ __device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const f
             for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[Q][a0][sp], bt[sp], d, 0, 0, 0);
             // rows c = 4 kq + r; column = position (b = 2 t + i0, e = j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xbuf[(4 * kq + r) * 128 + qoff(a0, 2 * t + i0, j)] += d[r];
+            for (int r = 0; r < 4; ++r) xbuf[xoff(4 * kq + r, a0, 2 * t + i0, j)] += d[r];
         }
     }
     wave_lds_fence();
-    // ---- dV += trilinear^T dX (same lane -> voxel map and coefficients as the gather) -------------------
+    // ---- dV += trilinear^T dX ----------------------------------------------------------------------------
+    // Phase A, one voxel per lane (the gather's map): the 8 corner weights and row offsets go to a small table
+    // that takes the place of the du image (reloaded at the start of the next quarter).
+    float* ctab = dbuf;
     {
         const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
         const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
@@ -423,36 +462,77 @@ __device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const f
         for (int p = 0; p < 2; ++p) {
             const int b = 4 * p + 2 * b1 + b0;
             const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
-            TriCoef k;
-            tri_coef(k, Rm, x, y, z);
-            float d[16];
+            float w[8];
+            int a[8];
+            tri_coef_dense(w, a, Rm, x, y, z);
+            float* row = ctab + (a0 * 64 + b * 8 + e) * 16;
+            *reinterpret_cast<f32x4*>(row + 0) = f32x4{w[0], w[1], w[2], w[3]};
+            *reinterpret_cast<f32x4*>(row + 4) = f32x4{w[4], w[5], w[6], w[7]};
+            *reinterpret_cast<f32x4*>(row + 8) = f32x4{__int_as_float(a[0]), __int_as_float(a[1]), __int_as_float(a[2]),
+                                                       __int_as_float(a[3])};
+            *reinterpret_cast<f32x4*>(row + 12) = f32x4{__int_as_float(a[4]), __int_as_float(a[5]), __int_as_float(a[6]),
+                                                        __int_as_float(a[7])};
+        }
+    }
+    wave_lds_fence();
+    // Phase B, one channel per lane: lane (c, vq) adds channel c of four voxels per step.  The four voxels of a
+    // step are 4 apart in b and/or e, so their 2x2x2 corner footprints are disjoint (a rotation preserves
+    // distances): no two lanes of an atomic ever hit the same address, and the 16 channels of a corner row are
+    // 16 consecutive words.  The image is 64-bit fixed point because ds_add_f32 is ~40x slower than the integer
+    // LDS atomics on gfx950 (tools/lds_atomic_probe.cpp: 771 vs 19 (u32) / 28 (u64) cycles per wave-instruction);
+    // as a bonus the per-workgroup sums do not depend on the order of the adds.
+    {
+        const int c = lane & 15, vq = lane >> 4;
+#pragma unroll 1
+        for (int a0 = 0; a0 < 2; ++a0)
+#pragma unroll 2
+            for (int be = 0; be < 16; ++be) {
+                const int b = (be >> 2) + 4 * (vq & 1), e = (be & 3) + 4 * (vq >> 1);
+                const float d = xbuf[xoff(c, a0, b, e)] * fx_scale;
+                const float* row = ctab + (a0 * 64 + b * 8 + e) * 16;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(row + 0), w1 = *reinterpret_cast<const f32x4*>(row + 4);
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(row + 8), o1 = *reinterpret_cast<const f32x4*>(row + 12);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = xbuf[c * 128 + qoff(a0, b, e)];
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-                if (k.w[nb] != 0.0f) {
-                    float* dst = dV + k.a[nb];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) lds_add(dst + c, k.w[nb] * d[c]);
+                for (int nb = 0; nb < 4; ++nb) {
+                    if (w0[nb] != 0.0f) lds_add_i64(dV + __float_as_int(o0[nb]) + c, to_fixed(w0[nb] * d));
+                    if (w1[nb] != 0.0f) lds_add_i64(dV + __float_as_int(o1[nb]) + c, to_fixed(w1[nb] * d));
                 }
             }
-        }
     }
     wave_lds_fence();
 }
 
 __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
     const float* __restrict__ R, long r_batch_stride, const float* __restrict__ W1, int B, long N,
-    const float* __restrict__ du_ws, float* __restrict__ grad_vol)
+    const float* __restrict__ du_ws, const unsigned* __restrict__ du_max_bits, float* __restrict__ grad_vol)
 {
-    __shared__ __attribute__((aligned(16))) float lds_dv[kSrcFloats];
-    __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];
+    __shared__ __attribute__((aligned(16))) long long lds_dv[512 * 16];  // dense channel-last, 64-bit fixed point
+    __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];      // per wave: du image, then the corner table
     __shared__ __attribute__((aligned(16))) float lds_x[4 * kQuarterFloats];
+    __shared__ float lds_bound[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, row = lane & 15;
     float* dbuf = lds_du + wave * 2048;
     float* xbuf = lds_x + wave * kQuarterFloats;
+
+    // |dX| <= (sum over the three slabs of max_k sum_o |W1[o][k]|) * max|du|: fixes the fixed-point scale per sample
+    {
+        float* colsum = lds_x;  // 384 floats of scratch before the hypothesis loop
+        for (int k = tid; k < 384; k += kBwdThreads) {
+            float a = 0.0f;
+            for (int o = 0; o < 32; ++o) a += fabsf(W1[o * 384 + k]);
+            colsum[k] = a;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            float m = 0.0f;
+            for (int k = 0; k < 128; ++k) m = fmaxf(m, colsum[128 * tid + k]);
+            lds_bound[tid] = m;
+        }
+        __syncthreads();
+    }
+    const float w1_bound = lds_bound[0] + lds_bound[1] + lds_bound[2];
 
     // W1^T fragments, A operands of dX: [k-tile][k-step over o]: W1[o = 4 s' + kq][k = base + row]
     float wx[8][8], wy[8][8], wz[4][2][8];
@@ -473,26 +553,38 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
     const long hstep = (long)gridDim.x * 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        for (int i = tid; i < kSrcFloats; i += kBwdThreads) lds_dv[i] = 0.0f;
+        for (int i = tid; i < 512 * 16; i += kBwdThreads) lds_dv[i] = 0ll;
         __syncthreads();
+        // every contribution w * dX (w <= 1) stays below 2^40 in units of 2^-fx_exp: 23 bits of headroom for the sum
+        const float bound = w1_bound * __uint_as_float(du_max_bits[b]);
+        int ex = 0;
+        (void)frexpf(bound, &ex);
+        const bool usable = bound > 0.0f && bound < 3.0e38f;
+        const int fx_exp = usable ? min(max(40 - ex, -80), 80) : 0;
+        const float fx_scale = usable ? ldexpf(1.0f, fx_exp) : 0.0f;
         const float* Rb = R + (long)b * r_batch_stride;
         for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
-            load_du_image(dbuf, du_ws + ((long)b * N + h) * 2048, lane);
-            wave_lds_fence();
-            bwd_vol_quarter<0>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
-            bwd_vol_quarter<1>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
-            bwd_vol_quarter<2>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
-            bwd_vol_quarter<3>(wx, wy, wz, dbuf, xbuf, lds_dv, Rm, lane);
+            const float* du_h = du_ws + ((long)b * N + h) * 2048;
+            load_du_image(dbuf, du_h, lane); wave_lds_fence();
+            bwd_vol_quarter<0>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
+            load_du_image(dbuf, du_h, lane); wave_lds_fence();
+            bwd_vol_quarter<1>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
+            load_du_image(dbuf, du_h, lane); wave_lds_fence();
+            bwd_vol_quarter<2>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
+            load_du_image(dbuf, du_h, lane); wave_lds_fence();
+            bwd_vol_quarter<3>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
         }
         __syncthreads();
+        // non-finite upstream gradients: the bound is inf/NaN, nothing was accumulated -> report NaN like autograd would
+        const float unscale = usable ? ldexpf(1.0f, -fx_exp) : (bound == 0.0f ? 0.0f : __builtin_nanf(""));
         float* gv = grad_vol + (long)b * (16 * 512);
         for (int i = tid; i < 16 * 512; i += kBwdThreads) {
             const int c = i >> 9, v = i & 511;
-            const float x = lds_dv[((v >> 6) * kSrcPlaneRows + (v & 63)) * kSrcStride + c];
-            if (x != 0.0f) global_add(gv + i, x);
+            const long long a = lds_dv[v * 16 + c];
+            if (a != 0ll || !usable) global_add(gv + i, (float)a * unscale + (usable ? 0.0f : unscale));
         }
     }
 }
@@ -500,7 +592,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
 // ---- host-side launcher -------------------------------------------------------------------------------
 hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
                                  const float* W1, const float* W2, const float* b2, int B, int64_t N,
-                                 const float* grad_scores, float* du_ws, float* grad_vol, float* grad_feat_tgt,
+                                 const float* grad_scores, float* du_ws, unsigned* du_max_bits, float* grad_vol,
+                                 float* grad_feat_tgt,
                                  float* grad_W1, float* grad_W2, float* grad_b2, int num_cu, hipStream_t stream)
 {
     hipError_t e;
@@ -510,6 +603,7 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     if ((e = hipMemsetAsync(grad_W2, 0, sizeof(float) * 32 * 32, stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(grad_b2, 0, sizeof(float) * 32, stream)) != hipSuccess) return e;
     if (B == 0 || N == 0) return hipSuccess;
+    if ((e = hipMemsetAsync(du_max_bits, 0, sizeof(unsigned) * (size_t)B, stream)) != hipSuccess) return e;
     int gy = B < num_cu ? B : num_cu;
     int gx = num_cu / gy;
     const int64_t need = (N + 3) / 4;
@@ -517,13 +611,14 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     if (gx < 1) gx = 1;
     const dim3 grid(gx, gy);
     hipLaunchKernelGGL(score_backward_head_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, feat_tgt, R,
-                       (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, grad_feat_tgt, grad_W2, grad_b2);
+                       (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2,
+                       grad_b2);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(score_backward_w1_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, R, (long)r_batch_stride,
                        B, (long)N, du_ws, grad_W1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kBwdThreads), 0, stream, R, (long)r_batch_stride, W1,
-                       B, (long)N, du_ws, grad_vol);
+                       B, (long)N, du_ws, du_max_bits, grad_vol);
     return hipGetLastError();
 }
 
