@@ -15,7 +15,7 @@ RCCL and on ``gloo``).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, Iterable, Optional, Tuple
 
 import numpy as np
 import torch
@@ -115,3 +115,34 @@ def score_hypotheses_sharded(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: t
         b, i = unpack_keys_host(key.cpu().numpy())
         best, idx = torch.from_numpy(b), torch.from_numpy(i)
     return scores, best, idx
+
+
+def all_reduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Data-parallel gradient averaging, the exchange Lightning's DDP strategy performs for the reference's
+    ``trainer.fit`` (modules/model_co3d.py:101-145 with ``strategy='ddp'`` in train_co3d.py).  Gradients are packed
+    into flat buckets of up to ``bucket_bytes`` (the aligner has ~230 tensors / 192 MB: a few large RCCL
+    all-reduces instead of hundreds of small ones), summed, divided by the world size and unpacked in place.
+    Parameters without a gradient on this rank (``bn_down``) are skipped on every rank alike.  Returns the
+    number of buckets.  With no process group it is a no-op."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = dist.get_world_size(group)
+    grads = [p.grad for p in params if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        nbytes = g.numel() * g.element_size()
+        if cur and (size + nbytes > bucket_bytes or g.dtype != cur[0].dtype or g.device != cur[0].device):
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(g)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    for b in buckets:
+        flat = torch._utils._flatten_dense_tensors(b)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        for g, f in zip(b, torch._utils._unflatten_dense_tensors(flat, b)):
+            g.copy_(f)
+    return len(buckets)

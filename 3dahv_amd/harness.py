@@ -167,3 +167,44 @@ def test_linemod_category(cfg, model, loader: Iterable[dict], clsID: int, out_di
     os.makedirs(out_dir, exist_ok=True)
     np.savetxt(os.path.join(out_dir, "linemod_pred_Rs_%06d.txt" % clsID), np.asarray(pred_Rs))
     return err.mean().item(), acc30, acc15
+
+
+class SyntheticTrainingPairs:
+    """Synthetic stand-in for the CO3D training loader (modules/model_co3d.py:101-134): batches with the keys
+    ``training_step`` reads -- ``image (B,2,3,S,S)`` and ``relative_rotation (B,1,3,3)``."""
+
+    def __init__(self, batch_size: int, steps: int, size: int = 256, seed: int = 0):
+        self.batch_size, self.steps, self.size, self.seed = batch_size, steps, size, seed
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for s in range(self.steps):
+            g = torch.Generator().manual_seed(self.seed * 100003 + s)
+            yield {"image": torch.randn(self.batch_size, 2, 3, self.size, self.size, generator=g),
+                   "relative_rotation": random_rotations(self.batch_size, generator=g)[:, None]}
+
+
+def fit(cfg, model, loader: Iterable[dict], device=None, max_steps: Optional[int] = None, group=None):
+    """Plain-loop counterpart of ``trainer.fit(model, train_dataloader)`` (modules/model_co3d.py:141-145): per
+    batch ``training_step`` -> ``backward`` -> data-parallel gradient averaging (when a process group exists)
+    -> AdamW step; StepLR once per epoch (= one pass over ``loader``).  Returns the list of losses."""
+    from . import dist as adist
+    if device is None:
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    (opt,), (sched,) = model.configure_optimizers()
+    model.train()
+    losses = []
+    for step, batch in enumerate(loader):
+        if max_steps is not None and step >= max_steps:
+            break
+        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, step)
+        loss.backward()
+        adist.all_reduce_gradients(model.parameters(), group=group)
+        opt.step()
+        losses.append(float(loss.item()))
+    sched.step()
+    return losses

@@ -81,3 +81,54 @@ def test_sharded_argmax_world2():
         b, i, s, lo, hi = by[(r, "local")]
         assert list(i) == list(g["best_idx_shared"])
     assert np.array_equal(by[(0, "shared")][0], by[(1, "shared")][0])
+
+
+def _grad_worker(rank, world, port, q):
+    import importlib
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ahv = importlib.import_module("3dahv_amd")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 3))
+        for p in net[3].parameters():      # a module that takes no part (like the reference's bn_down): grad None
+            p.requires_grad_(True)
+        x = torch.randn(4, 7, generator=torch.Generator().manual_seed(10 + rank))
+        net[:3](x).square().sum().backward()
+        n_buckets = ahv.dist.all_reduce_gradients(net.parameters(), bucket_bytes=64)   # tiny buckets: several
+        q.put((rank, n_buckets, [None if p.grad is None else p.grad.clone().numpy() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_averaging_world2():
+    """all_reduce_gradients = mean over ranks of each rank's gradients, bucketed; unused parameters stay None."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference: average of the two ranks' gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 3))
+    ref = None
+    for rank in range(2):
+        net.zero_grad()
+        x = torch.randn(4, 7, generator=torch.Generator().manual_seed(10 + rank))
+        net[:3](x).square().sum().backward()
+        g = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        ref = g if ref is None else [None if a is None else a + b for a, b in zip(ref, g)]
+    for rank, n_buckets, grads in got:
+        assert n_buckets >= 2
+        for a, b in zip(grads, ref):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.allclose(a, (b / 2).numpy(), atol=1e-6)
