@@ -33,13 +33,12 @@ __device__ __forceinline__ void lds_add_i64(long long* p, long long v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// |x| < 2^40 -> nearest integer as int64, in a handful of VALU instructions (there is no f32 -> i64 convert):
-// x = h * 2^20 + r with h = rint(x / 2^20); the subtraction is exact.
+// |x| < 2^40 -> nearest integer as int64 (there is no f32 -> i64 convert): add 1.5 * 2^52 in fp64, where one ulp
+// is exactly 1, and read the integer out of the mantissa.
 __device__ __forceinline__ long long to_fixed(float x)
 {
-    const float h = rintf(x * 0x1p-20f);
-    const float r = x - h * 0x1p20f;
-    return ((long long)(int)h << 20) + (long long)(int)rintf(r);
+    const double magic = 6755399441055744.0;  // 2^52 + 2^51
+    return __double_as_longlong((double)x + magic) - __double_as_longlong(magic);
 }
 
 // Corner weights and DENSE channel-last row offsets (16 words per voxel, voxel = z*64 + y*8 + x).

@@ -109,8 +109,22 @@ if not only or "enc" in only:
 if not only or "train" in only:
     # training-size scorer step (reference config.yaml: TRAIN.BS 12, DATA.NUM_ROTA 3000, per-sample rotations):
     # forward + backward of the (B,N) similarities, HIP fused kernels vs autograd over stock PyTorch-ROCm operators
-    sys.path.insert(0, REPO)
-    from oracle import torch_ref
+    import types
+    import torch.nn.functional as F
+
+    def _rotate_volume(volume, R):  # the reference's operator sequence (utils.py:123-129), stock operators
+        theta = torch.cat([R, R.new_zeros(R.shape[0], 3, 1)], dim=-1)
+        grid = F.affine_grid(theta, list(volume.shape), align_corners=False)
+        return F.grid_sample(volume, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+    def _forward_3d2d(v, W1, W2, b2):  # modules/modules.py:112-124
+        m, c, d, h, w = v.shape
+        slabs = torch.cat([v.permute(0, 1, 4, 2, 3).reshape(m, c * w, d, h), v.permute(0, 1, 3, 2, 4).reshape(m, c * h, d, w),
+                           v.reshape(m, c * d, h, w)], dim=1)
+        u = F.relu(F.conv2d(slabs, W1.reshape(32, 384, 1, 1)))
+        return F.normalize(F.conv2d(u, W2.reshape(32, 32, 1, 1), b2), p=2, dim=1).flatten(2)
+
+    torch_ref = types.SimpleNamespace(rotate_volume=_rotate_volume, forward_3d2d=_forward_3d2d)
     B, N = 12, 3000
     vs = vol[0, :B].clone().requires_grad_(True)
     vt = vol[1, :B].clone()
