@@ -6,9 +6,11 @@ Same names, argument meaning and error behaviour as the reference callables:
 * ``forward_3d2d(img_feat, W1, W2, b2)``  -- Feature_Aligner.forward_3d2d, modules/modules.py:112-124
 * ``score_features`` / ``argmax``  -- the inline lines test_co3d.py:143 / :145
 * ``score_hypotheses``  -- all of the above fused into one launch (test_co3d.py:137-145)
+* ``score_hypotheses_autograd`` / ``forward_3d2d_autograd`` / ``score_hypotheses_backward``  -- the same with
+  autograd edges for training (infoNCE_loss, modules/model_co3d.py:41-61): HIP forward + HIP backward
 
 Tensors must live on the GPU (``torch.device('cuda')`` is HIP on ROCm); launches go
-to torch's current stream.  Inference only: outputs carry no autograd graph.
+to torch's current stream.  The plain ops carry no autograd graph; the ``*_autograd`` ones do.
 """
 from __future__ import annotations
 
