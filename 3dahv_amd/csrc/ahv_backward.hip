@@ -491,10 +491,18 @@ __device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const f
                 const float* row = ctab + (a0 * 64 + b * 8 + e) * 16;
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(row + 0), w1 = *reinterpret_cast<const f32x4*>(row + 4);
                 const f32x4 o0 = *reinterpret_cast<const f32x4*>(row + 8), o1 = *reinterpret_cast<const f32x4*>(row + 12);
+                // unconditional: a zero weight adds 0 to a clamped (valid) row.  Branching on the weight put every
+                // atomic in its own basic block behind an s_waitcnt lgkmcnt(0), i.e. serialised their latencies.
+                long long fx[8];
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    if (w0[nb] != 0.0f) lds_add_i64(dV + __float_as_int(o0[nb]) + c, to_fixed(w0[nb] * d));
-                    if (w1[nb] != 0.0f) lds_add_i64(dV + __float_as_int(o1[nb]) + c, to_fixed(w1[nb] * d));
+                    fx[nb] = to_fixed(w0[nb] * d);
+                    fx[4 + nb] = to_fixed(w1[nb] * d);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    lds_add_i64(dV + __float_as_int(o0[nb]) + c, fx[nb]);
+                    lds_add_i64(dV + __float_as_int(o1[nb]) + c, fx[4 + nb]);
                 }
             }
     }
