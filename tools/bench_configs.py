@@ -154,3 +154,31 @@ if not only or "train" in only:
     print(json.dumps({"config": "training scorer step", "B": B, "N": N, "hip_fwd_bwd_ms": ms_hip, "hip_fwd_only_ms": ms_fwd,
                       "hip_bwd_only_ms": ms_bwd, "torch_autograd_ms": ms_torch, "speedup": ms_torch / ms_hip,
                       "max_rel_grad_diff_vs_torch_fp32": rel, "hyp_per_s_fwd_bwd": B * N / ms_hip * 1e3}))
+
+if not only or "trainstep" in only:
+    # whole training_step (modules/model_co3d.py:71-91) at the reference's batch: where the time goes
+    cfg = {"RUN_NAME": "t", "DATA": {"NUM_ROTA": 3000, "BG": True, "SIZE_THR": 25, "OBJ_SIZE": 256, "ACC_THR": 30, "VIEW_THR": 90},
+           "TRAIN": {"MASK": True, "MASK_RATIO": 0.25, "LR": 1e-4}}
+    torch.manual_seed(0)
+    m = ahv.estimator.EstimatorCo3d(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1)).to(dev).train()
+    (opt,), _ = m.configure_optimizers()
+    gg = torch.Generator().manual_seed(3)
+    batch = {"image": torch.randn(12, 2, 3, 256, 256, generator=gg).to(dev),
+             "relative_rotation": ahv.rotations.random_rotations(12, generator=gg).to(dev)[:, None]}
+
+    def full_step():
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+
+    def encoder_only():
+        opt.zero_grad(set_to_none=True)
+        vs, vt = m.feature_aligner.forward_2d3d(m.feature_extraction(batch["image"][:, 0]),
+                                                m.feature_extraction(batch["image"][:, 1]), random_mask=True, mask_ratio=0.25)
+        (vs.square().mean() + vt.square().mean()).backward()
+
+    ms_full = timeit(full_step, 5, warm=2)
+    ms_enc = timeit(encoder_only, 5, warm=2)
+    print(json.dumps({"config": "training_step B=12 N=3000 (synthetic backbone)", "full_step_ms": ms_full,
+                      "encoder_fwd_bwd_torch_autograd_ms": ms_enc, "scorer_and_loss_and_adamw_ms": ms_full - ms_enc}))
