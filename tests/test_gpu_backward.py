@@ -158,3 +158,31 @@ def test_training_steps_reduce_the_loss(ahv, dev):
     # every aligner parameter takes part, except bn_down, which the reference constructs but never applies
     assert all(p.grad is not None for k, p in m.feature_aligner.named_parameters() if "bn_down" not in k)
     assert min(losses[3:]) < losses[0], losses   # same pair every step: the loss must come down
+
+
+def test_backward_many_samples_and_gradient_scales(ops, ahv, dev):
+    """More samples than workgroups in y (each workgroup flushes / re-zeroes its volume-gradient image between
+    samples), and upstream gradients far from 1 (the dV image is fixed point with a per-sample scale derived on the
+    device from max|du|)."""
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, 260, 3, True, 21)
+    got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    leaves = [x.double().requires_grad_(True) for x in (vs, ft, W1, W2, b2)]
+    ref = torch.autograd.grad(ref_scores(leaves[0], leaves[1], R.double(), *leaves[2:]), leaves, grad_outputs=gs.double())
+    for a, b in zip(got, ref):
+        assert relerr(a, b.reshape(a.shape)) < GRAD_RTOL
+    # per-sample check of the volume gradient (a global max would hide a sample that was dropped)
+    per = ((got[0].double() - ref[0]).flatten(1).abs().max(dim=1).values / ref[0].flatten(1).abs().max(dim=1).values)
+    assert per.max().item() < GRAD_RTOL
+
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, 2, 50, False, 22)
+    base = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    for scale in (1e-9, 1e7):
+        mixed = gs * torch.tensor([[scale], [1.0]], device=dev)       # two samples, very different magnitudes
+        out = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, mixed)
+        assert relerr(out[0][0], base[0][0].double() * scale) < 1e-5
+        assert relerr(out[0][1], base[0][1].double()) < 1e-5
+    nan = gs.clone()
+    nan[0, 3] = float("nan")                                          # poisoned sample -> NaN, the other one intact
+    out = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, nan)
+    assert torch.isnan(out[0][0]).any() and torch.isfinite(out[0][1]).all()
+    assert relerr(out[0][1], base[0][1].double()) < 1e-5
