@@ -385,3 +385,32 @@ def test_fused_many_samples_few_hypotheses(ops, ahv, oracle, g128, dev, variant)
         assert ops.unpack_best(key)[1].cpu().tolist() == ref_idx.tolist()
     finally:
         lib.ahv_set_option(b"score_variant", prev)
+
+
+def test_planted_rotation_recovered_at_full_size(ops, ahv, G, dev):
+    """Size-independent property at BASELINE.json's N = 50 000: if the target volume IS the source rotated by one of
+    the hypotheses, that hypothesis scores 1 (its feature equals the target's) and wins the arg-max, wherever it
+    sits; and coarse (Haar) -> fine (local perturbations) brings an UNLISTED rotation to within a few degrees."""
+    N = 50_000
+    R = ops.random_rotations(N, seed=5, device=dev)
+    for planted in (0, 31_337, N - 1):
+        vt = ops.rotate_volume(G["vol_src"], R[planted][None])
+        ft = ops.forward_3d2d(vt, G["W1"], G["W2"], G["b2"])
+        scores, key = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
+        val, idx = ops.unpack_best(key)
+        assert idx.item() == planted and abs(val.item() - 1.0) < 1e-5
+        assert (scores[0] > 1.0 + 1e-5).sum().item() == 0
+    # unlisted ground truth: the winner of 50 000 Haar samples is its nearest-looking neighbour; refine around it
+    R_true = torch.from_numpy(ahv.rotations.haar_rotations_np(1, 123)).to(dev)
+    vt = ops.rotate_volume(G["vol_src"], R_true)
+    ft = ops.forward_3d2d(vt, G["W1"], G["W2"], G["b2"])
+    _, key = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], want_scores=False)
+    _, _, R1 = ops.select_rotation(key, R)
+    e1 = ahv.rotations.geodesic_deg(R1, R_true).item()
+    fine = ahv.rotations.refine_rotations(R1[0].cpu(), 4000, max_angle_deg=max(e1 * 1.5, 2.0),
+                                          generator=torch.Generator().manual_seed(1)).to(dev)
+    _, key2 = ops.score_hypotheses(G["vol_src"], ft, fine, G["W1"], G["W2"], G["b2"], want_scores=False)
+    _, _, R2 = ops.select_rotation(key2, fine)
+    e2 = ahv.rotations.geodesic_deg(R2, R_true).item()
+    print("coarse error %.2f deg -> refined %.2f deg" % (e1, e2))
+    assert e1 < 15.0 and e2 < e1 and e2 < 3.0
