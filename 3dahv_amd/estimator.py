@@ -121,7 +121,7 @@ class _EstimatorBase(nn.Module):
         """The reference's InfoNCE loss (modules/model_co3d.py:41-61, modules/model.py:43-63): per-sample
         hypothesis sets ``sampled_R (B,N,3,3)``, positives = hypotheses within ``DATA.ACC_THR`` degrees of
         ``gt_delta_R``, ``-log(sum_pos exp(s/0.1) / sum_all exp(s/0.1))``.  The (B,N) similarities come from ONE
-        fused HIP launch with per-sample rotations; under autograd their backward is the two-kernel HIP backward
+        fused HIP launch with per-sample rotations; under autograd their backward is the three-kernel HIP backward
         (``ops.score_hypotheses_autograd``), so the loss is differentiable w.r.t. both volumes and the head.
         ``reduce_mean`` defaults to the variant's behaviour: mean (model_co3d.py:59) or per-sample (model.py:61)."""
         import math

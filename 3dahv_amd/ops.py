@@ -183,7 +183,7 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
 def score_hypotheses_backward(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
                               W2: torch.Tensor, b2: torch.Tensor, grad_scores: torch.Tensor):
     """Gradients of ``score_hypotheses`` w.r.t. ``(vol_src, feat_tgt, W1, W2, b2)`` given ``dL/dscores (B,N)``
-    (two launches; what ``infoNCE_loss`` back-propagates, modules/model_co3d.py:41-61).  R gets no gradient."""
+    (three launches; what ``infoNCE_loss`` back-propagates, modules/model_co3d.py:41-61).  R gets no gradient."""
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
         raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
     B = vol_src.shape[0]
