@@ -50,7 +50,7 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ref(N);
-    for (int variant = 0; variant < 5; ++variant) {
+    for (int variant = (argc > 3 ? atoi(argv[3]) : 0); variant < (argc > 3 ? atoi(argv[3]) + 1 : 5); ++variant) {
         ahv::g_score_variant = variant;
         for (int rep = 0; rep < 3; ++rep) {
             for (int w = 0; w < 3; ++w)
