@@ -267,15 +267,41 @@ class BidirectionTransformer(nn.Module):
         b, _, h, w = x.shape
         tok = lambda t: t.flatten(2).transpose(1, 2)                      # (B, hw, C)
         img = lambda t, hh, ww: t.transpose(1, 2).reshape(b, -1, hh, ww)  # back to (B, C, h, w)
-        xs = tok(self.proj_in(self.norm(x)))
-        cs = tok(self.proj_context_in(self.norm(context)))
+        xs = tok(conv_mm(self.proj_in, self.norm(x)))
+        cs = tok(conv_mm(self.proj_context_in, self.norm(context)))
         if self._hip_eligible(xs):
             xs, cs = self._hip_blocks(xs, cs)
         else:  # other widths (test fixtures), autograd, CPU tensors: stock torch operators
             for blk in self.transformer_blocks:
                 xs, cs = blk(xs, cs)
         hc, wc = context.shape[-2:]
-        return self.proj_out(img(xs, h, w)) + x, self.proj_context_out(img(cs, hc, wc)) + context
+        return (conv_mm(self.proj_out, img(xs, h, w)) + x,
+                conv_mm(self.proj_context_out, img(cs, hc, wc)) + context)
+
+
+def conv_mm(conv: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """``conv(x)`` for the 1x1 / 3x3(x3) stride-1 same-padding convolutions of the aligner, evaluated as
+    unfold + matmul when autograd is recording on the GPU.  Same arithmetic, different operator: MIOpen has no
+    tuned fp32 kernels for these tiny 8x8 / 8^3 images on gfx950 and falls back to ``naive_conv_*`` -- 12 ms of a
+    23-ms encoder forward+backward at B = 12 (rocprofv3) -- whereas the GEMM form goes through hipBLASLt/rocBLAS in
+    both directions.  Everywhere else (CPU, no_grad) the convolution module itself runs."""
+    if not (x.is_cuda and torch.is_grad_enabled()):
+        return conv(x)
+    w, k = conv.weight, conv.kernel_size[0]
+    B, C = x.shape[:2]
+    sp = x.shape[2:]
+    if k == 1:
+        out = w.reshape(w.shape[0], C) @ x.flatten(2)
+    elif x.dim() == 4:
+        out = w.reshape(w.shape[0], -1) @ F.unfold(x, 3, padding=1)
+    else:
+        cols = F.pad(x, (1, 1, 1, 1, 1, 1)).unfold(2, 3, 1).unfold(3, 3, 1).unfold(4, 3, 1)  # (B,C,D,H,W,3,3,3)
+        cols = cols.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(B, C * 27, -1)
+        out = w.reshape(w.shape[0], -1) @ cols
+    out = out.reshape(B, -1, *sp)
+    if conv.bias is not None:
+        out = out + conv.bias.reshape(1, -1, *([1] * len(sp)))
+    return out
 
 
 class _ResBlock(nn.Module):
@@ -294,8 +320,8 @@ class _ResBlock(nn.Module):
             self.bn_down = (nn.BatchNorm3d if three_d else nn.BatchNorm2d)(cout)
 
     def forward(self, x):
-        out = self.conv2(F.relu(self.conv1(x)))
-        return out + (x if self.downsample is None else self.downsample(x))
+        out = conv_mm(self.conv2, F.relu(conv_mm(self.conv1, x)))
+        return out + (x if self.downsample is None else conv_mm(self.downsample[0], x))
 
 
 def random_masking(x: torch.Tensor, mask_ratio: float) -> torch.Tensor:
@@ -362,7 +388,8 @@ class Feature_Aligner(nn.Module):
                 src = src * random_masking(src, mask_ratio).reshape(-1, 1, 8, 8, 8)
                 tgt = tgt * random_masking(tgt, mask_ratio).reshape(-1, 1, 8, 8, 8)
             return src, tgt
-        src, tgt = self.feature_embedding(img_feat_src), self.feature_embedding(img_feat_tgt)
+        embed = lambda t: self.feature_embedding[1](conv_mm(self.feature_embedding[0], t))
+        src, tgt = embed(img_feat_src), embed(img_feat_tgt)
         pe = self.posemb_sincos_2d(src, channel=self.mid_channel)[None]
         src, tgt = self.att(src + pe, tgt + pe)
         # channel index = c' * 8 + d: the 2-D map's channels become (c', depth)

@@ -178,7 +178,10 @@ if not only or "trainstep" in only:
                                                 m.feature_extraction(batch["image"][:, 1]), random_mask=True, mask_ratio=0.25)
         (vs.square().mean() + vt.square().mean()).backward()
 
-    ms_full = timeit(full_step, 5, warm=2)
-    ms_enc = timeit(encoder_only, 5, warm=2)
-    print(json.dumps({"config": "training_step B=12 N=3000 (synthetic backbone)", "full_step_ms": ms_full,
-                      "encoder_fwd_bwd_torch_autograd_ms": ms_enc, "scorer_and_loss_and_adamw_ms": ms_full - ms_enc}))
+    for blas in ("cublaslt", "cublas"):  # hipBLASLt (torch's default here) / rocBLAS (what harness.fit selects)
+        torch.backends.cuda.preferred_blas_library(blas)
+        ms_full = timeit(full_step, 5, warm=2)
+        ms_enc = timeit(encoder_only, 5, warm=2)
+        print(json.dumps({"config": "training_step B=12 N=3000 (synthetic backbone)",
+                          "blas": {"cublaslt": "hipBLASLt", "cublas": "rocBLAS"}[blas], "full_step_ms": ms_full,
+                          "encoder_fwd_bwd_torch_autograd_ms": ms_enc, "scorer_and_loss_and_adamw_ms": ms_full - ms_enc}))
