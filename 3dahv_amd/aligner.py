@@ -287,6 +287,11 @@ def conv_mm(conv: nn.Module, x: torch.Tensor) -> torch.Tensor:
     both directions.  Everywhere else (CPU, no_grad) the convolution module itself runs."""
     if not (x.is_cuda and torch.is_grad_enabled()):
         return conv(x)
+    return conv_as_matmul(conv, x)
+
+
+def conv_as_matmul(conv: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """The GEMM form behind ``conv_mm``: kernel 1 or 3, stride 1, padding k // 2, 2-D or 3-D."""
     w, k = conv.weight, conv.kernel_size[0]
     B, C = x.shape[:2]
     sp = x.shape[2:]

@@ -71,3 +71,26 @@ def test_forward_3d2d_has_no_cpu_path(ahv):
     fa = ahv.aligner.Feature_Aligner(64, 32, 32, 4, 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         fa.forward_3d2d(torch.zeros(1, 16, 8, 8, 8))
+
+
+def test_conv_as_matmul_equals_conv_forward_and_backward(ahv):
+    """aligner.conv_mm swaps the aligner's convolutions for unfold + matmul under autograd on the GPU; the GEMM form
+    must be the same function (values and gradients) for every convolution shape the aligner has."""
+    import torch.nn as nn
+    torch.manual_seed(0)
+    cases = [(nn.Conv2d(24, 8, 1, bias=False), (2, 24, 8, 8)), (nn.Conv2d(8, 8, 1), (2, 8, 8, 8)),
+             (nn.Conv2d(8, 8, 3, padding=1, bias=False), (3, 8, 8, 8)),
+             (nn.Conv3d(4, 2, 3, padding=1, bias=False), (2, 4, 8, 8, 8)), (nn.Conv3d(4, 2, 1, bias=False), (2, 4, 8, 8, 8))]
+    for conv, shape in cases:
+        conv = conv.double()
+        x1 = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        y1, y2 = conv(x1), ahv.aligner.conv_as_matmul(conv, x2)
+        assert y1.shape == y2.shape and torch.allclose(y1, y2, atol=1e-12)
+        g = torch.randn_like(y1)
+        params = list(conv.parameters())
+        r1 = torch.autograd.grad(y1, [x1] + params, grad_outputs=g)
+        r2 = torch.autograd.grad(y2, [x2] + params, grad_outputs=g)
+        for a, b in zip(r1, r2):
+            assert torch.allclose(a, b, atol=1e-11)
+    assert ahv.aligner.conv_mm(cases[0][0], torch.randn(2, 24, 8, 8, dtype=torch.float64)).shape == (2, 8, 8, 8)  # CPU: the module itself
