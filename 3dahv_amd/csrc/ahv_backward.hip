@@ -567,7 +567,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
         int ex = 0;
         (void)frexpf(bound, &ex);
         const bool usable = bound > 0.0f && bound < 3.0e38f;
-        const int fx_exp = usable ? min(max(40 - ex, -80), 80) : 0;
+        // a word collects at most 8 corners x (hypotheses of this workgroup): give up precision bits, never range,
+        // when that exceeds the 2^22 adds the 63-bit word has room for (only beyond ~500 000 hypotheses per workgroup)
+        const long adds = 8 * ((N + gridDim.x - 1) / gridDim.x);
+        const int spare = (adds > (1l << 22)) ? (64 - __builtin_clzl((unsigned long)(adds - 1))) - 22 : 0;
+        const int fx_exp = usable ? min(max(40 - spare - ex, -80), 80) : 0;
         const float fx_scale = usable ? ldexpf(1.0f, fx_exp) : 0.0f;
         const float* Rb = R + (long)b * r_batch_stride;
         for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
