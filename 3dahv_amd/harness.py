@@ -225,3 +225,77 @@ def _fit_loop(model, loader, opt, device, max_steps, group):
         opt.step()
         losses.append(float(loss.item()))
     return losses
+
+
+class GraphedTrainStep:
+    """One whole ``EstimatorCo3d`` training iteration -- backbone, encoder, InfoNCE through the HIP scorer,
+    backward, AdamW -- captured ONCE in a hipGraph and replayed per batch.
+
+    Why: at the reference's batch (12 pairs) the iteration is ~1 850 kernel launches of a few microseconds each;
+    issued eagerly the host cannot keep the GPU fed and the step is launch-bound.  The graph needs static shapes
+    and buffers, so the batch is copied into fixed tensors, and the per-step hypothesis set (ground truth at index
+    0 + fresh Haar samples, modules/model_co3d.py:84-86) is written into a fixed ``(B, num_rota, 3, 3)`` buffer
+    just before each replay.  ``random_masking`` draws from torch's graph-safe Philox state, so every replay masks
+    differently.  The learning rate is a device scalar (``set_lr``) because a captured AdamW cannot see Python
+    floats change."""
+
+    def __init__(self, model, batch_size: int, image_size: int = 256, device=None, warmup: int = 3):
+        from . import ops
+        self.model, self.ops = model, ops
+        dev = torch.device(device if device is not None else "cuda")
+        self.images = torch.zeros(batch_size, 2, 3, image_size, image_size, device=dev)
+        self.gt = torch.eye(3, device=dev).repeat(batch_size, 1, 1)
+        self.R = torch.eye(3, device=dev).repeat(batch_size, model.num_rota, 1, 1)
+        self.lr = torch.tensor(float(model.cfg["TRAIN"]["LR"]), device=dev)
+        groups = [{"params": list(model.feature_aligner.parameters()), "lr": self.lr}]
+        if isinstance(model.feature_extractor, torch.nn.Module):
+            groups.append({"params": list(model.feature_extractor.parameters()), "lr": self.lr})
+        self.optimizer = torch.optim.AdamW(groups, eps=1e-5, capturable=True)
+        self._draws = 0
+        model.train()
+        prev_blas = torch.backends.cuda.preferred_blas_library()
+        torch.backends.cuda.preferred_blas_library("cublas")  # rocBLAS: see fit()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):  # lazy initialisation (libraries, optimizer state) must not be captured
+                    self._fill_rotations()
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self._loss().backward()
+                    self.optimizer.step()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.loss = self._loss()
+                self.loss.backward()
+                self.optimizer.step()
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev_blas)
+
+    def _loss(self):
+        m = self.model
+        vol_src, vol_tgt = m.feature_aligner.forward_2d3d(
+            m.feature_extraction(self.images[:, 0]), m.feature_extraction(self.images[:, 1]),
+            random_mask=m.cfg["TRAIN"]["MASK"], mask_ratio=m.cfg["TRAIN"]["MASK_RATIO"])
+        return m.infoNCE_loss(vol_src, vol_tgt, self.R, self.gt, reduce_mean=True)
+
+    def _fill_rotations(self):
+        B, n = self.R.shape[0], self.R.shape[1] - 1
+        self._draws += 1
+        self.R[:, 0].copy_(self.gt)
+        self.R[:, 1:].copy_(self.ops.random_rotations(B * n, seed=torch.initial_seed() + self._draws,
+                                                      device=self.R.device).reshape(B, n, 3, 3))
+
+    def set_lr(self, lr: float):
+        self.lr.fill_(lr)
+
+    def __call__(self, batch: dict) -> torch.Tensor:
+        """Runs one iteration on ``batch`` (keys as ``training_step``); returns the loss as a device scalar that the
+        next call overwrites (no host synchronisation here)."""
+        self.images.copy_(batch["image"], non_blocking=True)
+        self.gt.copy_(batch["relative_rotation"].reshape(-1, 3, 3), non_blocking=True)
+        self._fill_rotations()
+        self.graph.replay()
+        return self.loss

@@ -186,3 +186,49 @@ def test_backward_many_samples_and_gradient_scales(ops, ahv, dev):
     out = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, nan)
     assert torch.isnan(out[0][0]).any() and torch.isfinite(out[0][1]).all()
     assert relerr(out[0][1], base[0][1].double()) < 1e-5
+
+
+def test_graphed_train_step_matches_eager(ahv, dev):
+    """harness.GraphedTrainStep (whole iteration in one hipGraph) against the eager iteration: same rotations
+    (same seed and draw counter), masking off -> same losses and same parameters after three steps."""
+    import copy
+    cfg = tiny_cfg(48)
+    cfg["TRAIN"]["MASK"] = False
+    torch.manual_seed(0)
+    m1 = ahv.estimator.EstimatorCo3d(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1)).to(dev).train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(5)
+    batches = [{"image": torch.randn(2, 2, 3, 256, 256, generator=g).to(dev),
+                "relative_rotation": ahv.rotations.random_rotations(2, generator=g).to(dev)[:, None]} for _ in range(3)]
+    state0 = copy.deepcopy(m2.state_dict())
+    step = ahv.harness.GraphedTrainStep(m2, batch_size=2, device=dev, warmup=2)
+    # the warm-up iterations trained m2 on zeros: rewind weights, optimizer state and the rotation draw counter
+    m2.load_state_dict(state0)
+    for st in step.optimizer.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    step._draws = 0
+    graphed = [float(step(b).item()) for b in batches]
+
+    opt = torch.optim.AdamW([{"params": m1.feature_aligner.parameters(), "lr": 1e-4},
+                             {"params": m1.feature_extractor.parameters(), "lr": 1e-4}], eps=1e-5)
+    eager = []
+    for i, b in enumerate(batches):
+        gt = b["relative_rotation"].squeeze(1)
+        R = torch.cat([gt[:, None], ahv.ops.random_rotations(2 * 47, seed=torch.initial_seed() + i + 1, device=dev).reshape(2, 47, 3, 3)], dim=1)
+        opt.zero_grad()
+        vs, vt = m1.feature_aligner.forward_2d3d(m1.feature_extraction(b["image"][:, 0]), m1.feature_extraction(b["image"][:, 1]),
+                                                 random_mask=False, mask_ratio=0.0)
+        loss = m1.infoNCE_loss(vs, vt, R, gt, reduce_mean=True)
+        loss.backward()
+        opt.step()
+        eager.append(float(loss.item()))
+    assert np.allclose(graphed, eager, rtol=2e-4, atol=1e-5), (graphed, eager)
+    # Adam's first steps are +-lr * sign-like, so rounding-level gradient differences (other GEMM backend, float
+    # atomics) move single weights by a fraction of lr: compare the UPDATE vectors, not the weights elementwise
+    up1 = torch.cat([(a - state0[k]).flatten() for k, a in m1.state_dict().items() if a.is_floating_point()])
+    up2 = torch.cat([(b - state0[k]).flatten() for k, b in m2.state_dict().items() if b.is_floating_point()])
+    cos = torch.nn.functional.cosine_similarity(up1, up2, dim=0).item()
+    assert cos > 0.999 and up1.abs().max().item() > 1e-5, cos
+    assert (up1 - up2).abs().max().item() < 6e-4

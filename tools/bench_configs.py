@@ -185,3 +185,9 @@ if not only or "trainstep" in only:
         print(json.dumps({"config": "training_step B=12 N=3000 (synthetic backbone)",
                           "blas": {"cublaslt": "hipBLASLt", "cublas": "rocBLAS"}[blas], "full_step_ms": ms_full,
                           "encoder_fwd_bwd_torch_autograd_ms": ms_enc, "scorer_and_loss_and_adamw_ms": ms_full - ms_enc}))
+    # the same iteration captured once in a hipGraph and replayed (harness.GraphedTrainStep)
+    torch.backends.cuda.preferred_blas_library("cublaslt")
+    gstep = ahv.harness.GraphedTrainStep(m, batch_size=12, device=dev)
+    ms_graph = timeit(lambda: gstep(batch), 10, warm=2)
+    print(json.dumps({"config": "training_step B=12 N=3000 (synthetic backbone)", "mode": "one hipGraph per iteration (rocBLAS)",
+                      "full_step_ms": ms_graph, "loss": float(gstep.loss.item())}))
