@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
         }
         const float* Rb = R + (long)b * r_batch_stride;
         float du_amax = 0.0f;
-        for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
+        for (long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y); h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_w1_kernel(
         stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kBwdThreads);
         __syncthreads();
         const float* Rb = R + (long)b * r_batch_stride;
-        for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
+        for (long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y); h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
         const int fx_exp = usable ? min(max(40 - spare - ex, -80), 80) : 0;
         const float fx_scale = usable ? ldexpf(1.0f, fx_exp) : 0.0f;
         const float* Rb = R + (long)b * r_batch_stride;
-        for (long h = (long)wave * gridDim.x + blockIdx.x; h < N; h += hstep) {
+        for (long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y); h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];

@@ -42,6 +42,19 @@ __device__ __forceinline__ int qoff(int a0, int b, int e)
     return (e ^ (b & 6)) | (a0 << 3) | ((b & 1) << 4) | ((b >> 1) << 5);
 }
 
+// XCD-aware work assignment.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the
+// workgroups that share an L2), while hypothesis h goes to "residue" h % G: with residue = blockIdx.x the 3.5
+// rotations that share a 128-byte line of R would be fetched by workgroups on 3-4 different XCDs, i.e. from
+// HBM several times (measured: 10.9 MB per launch for 1.8 MB of R).  The bijective remap below hands each
+// XCD a contiguous range of residues, so neighbouring hypotheses meet in one L2.  Pure placement: any
+// residue permutation is correct.
+__device__ __forceinline__ int xcd_residue(int bid, int nwg, int ny)
+{
+    if (nwg < 16 || (ny > 1 && (nwg & 7) != 0)) return bid;  // with gy > 1 the label is (x + y*gx) % 8
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // Orders a wave's own LDS writes before its later LDS reads/writes at compiler
 // level.  Hardware executes one wave's DS instructions in order, so no
 // instruction is needed; without this the compiler may legally hoist a lane's

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): the last, partial round of
         // the persistent grid then spreads over ALL CUs with few waves each (a lone wave on a SIMD runs
         // ~1.6x faster than a pair) instead of filling some CUs completely and leaving the rest idle.
-        long h = (long)wave * gridDim.x + blockIdx.x;
+        long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
         float Rn[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rn[i] = Rb[(h < N ? h : 0) * 9 + i];
