@@ -168,6 +168,125 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
+// Tiled linear for MANY rows (M >= 1024, i.e. B >= 16): C[M][N] = X[M][K] . W[N][K]^T, fp32 MFMA 16x16x4.
+// The skinny kernel above splits K over the waves of a workgroup and pays an 8-way LDS reduction per 64 x 32
+// output tile: right for 64..512 rows (weights are the traffic), 44 % of the matrix peak at 2048 rows.  Here a
+// workgroup (256 threads, 2 x 2 waves) owns a 128 x 128 output tile and walks K in steps of 16 through a
+// double-buffered LDS stage; a wave owns 64 x 64 (16 accumulator tiles).  Both operands are K-contiguous, so
+// a tile row in LDS is one 64-byte line [16 k] and, with the k ordering "MFMA k-step s, lane group kq <-> k = 4 kq
+// + s", an operand fragment is one lane-linear (conflict-free) ds_read_b128 serving four MFMA k-steps.
+// GEGLU (the FF-in projection, attention.py:81-88): the 128 tile columns are, per wave column wc, 32 VALUE columns
+// and their 32 GATE columns, so value and gate of one output element sit in the same lane and the epilogue writes
+// (v + b_v) * gelu(g + b_g) straight into the [M][H] buffer.
+// -------------------------------------------------------------------------------------------------
+struct TileArgs {
+    LinProb p[2];  // tile0 unused
+    int M, K, ntiles;  // ntiles = column tiles per problem
+    long ldx, ldw;
+    int geglu_h;
+};
+
+template <bool GEGLU>
+__global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2][128 * 16];
+    __shared__ __attribute__((aligned(16))) float sB[2][128 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int pi = (int)blockIdx.x / a.ntiles, tile = (int)blockIdx.x - pi * a.ntiles;
+    const LinProb pr = a.p[pi];
+    const int m0 = blockIdx.y * 128;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // staging: thread -> (row = tid / 4 (+64), 16-byte chunk = tid % 4) of both tiles
+    const int srow = tid >> 2, sch = tid & 3;
+    const float* xg[2];
+    const float* wg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = srow + 64 * i;  // tile row
+        xg[i] = pr.X + (long)(m0 + j) * a.ldx + 4 * sch;
+        int wrow;
+        if (GEGLU) wrow = ((j >> 5) & 1) * a.geglu_h + tile * 64 + 32 * (j >> 6) + (j & 31);
+        else wrow = tile * 128 + j;
+        wg[i] = pr.W + (long)wrow * a.ldw + 4 * sch;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[2], gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ga[i] = *reinterpret_cast<const f32x4*>(xg[i]);
+        gb[i] = *reinterpret_cast<const f32x4*>(wg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<f32x4*>(&sA[0][(srow + 64 * i) * 16 + 4 * sch]) = ga[i];
+        *reinterpret_cast<f32x4*>(&sB[0][(srow + 64 * i) * 16 + 4 * sch]) = gb[i];
+    }
+    __syncthreads();
+    const int nk = a.K / 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ga[i] = *reinterpret_cast<const f32x4*>(xg[i] + 16 * (kt + 1));
+                gb[i] = *reinterpret_cast<const f32x4*>(wg[i] + 16 * (kt + 1));
+            }
+        }
+        f32x4 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = *reinterpret_cast<const f32x4*>(&sA[cur][(64 * wr + 16 * i + r16) * 16 + 4 * kq]);
+            fb[i] = *reinterpret_cast<const f32x4*>(&sB[cur][(64 * wc + 16 * i + r16) * 16 + 4 * kq]);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s4], fb[j][s4], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<f32x4*>(&sA[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch]) = ga[i];
+                *reinterpret_cast<f32x4*>(&sB[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch]) = gb[i];
+            }
+        }
+        __syncthreads();
+    }
+    // D layout: acc[i][j][r] = C[m0 + 64 wr + 16 i + 4 kq + r][column 64 wc + 16 j + r16 of the tile]
+    if (GEGLU) {
+        const int H = a.geglu_h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = tile * 64 + 32 * wc + 16 * j + r16;
+            const float bv = pr.bias[col], bg = pr.bias[H + col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = m0 + 64 * wr + 16 * i + 4 * kq + r;
+                    pr.P[row * H + col] = (acc[i][j][r] + bv) * gelu_erf(acc[i][j + 2][r] + bg);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pr.P[(long)(m0 + 64 * wr + 16 * i + 4 * kq + r) * pr.N + tile * 128 + 64 * wc + 16 * j + r16] = acc[i][j][r];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Attention, 64 keys x 64 head dims; grid = (B * nprob, heads), wave = 16 queries.
 // S^T[j][i] = sum_d K[j][d] Q[i][d]  (keys on rows/registers, queries on lanes);  softmax over j runs
 // down the registers (+ lane groups l^16, l^32);  O^T[d][i] = sum_j V[j][d] P^T[j][i], whose B operand
@@ -437,6 +556,25 @@ static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long 
     return hipGetLastError();
 }
 
+// Many-row path of two-problem plain / GEGLU linears (both streams in one launch); KS = 1 output layout.
+static bool tile_eligible(int M, int K, int N, int geglu_h)
+{
+    if (M < 1024 || (M & 127) || (K & 15)) return false;
+    return geglu_h > 0 ? (geglu_h % 64 == 0 && N == 2 * geglu_h) : (N % 128 == 0);
+}
+
+static hipError_t launch_linear_tile(const LinSpec* specs, long ldx, long ldw, int M, int K, int geglu_h, hipStream_t s)
+{
+    TileArgs a;
+    a.M = M; a.K = K; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
+    for (int i = 0; i < 2; ++i) a.p[i] = LinProb{specs[i].X, specs[i].W, specs[i].P, specs[i].bias, specs[i].N, 0};
+    a.ntiles = geglu_h > 0 ? geglu_h / 64 : specs[0].N / 128;
+    const dim3 grid(2 * a.ntiles, M / 128);
+    if (geglu_h > 0) hipLaunchKernelGGL(linear_tile_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(linear_tile_kernel<false>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 size_t transformer_workspace_floats(int B)
 {
     const size_t M = (size_t)64 * (size_t)(B > 0 ? B : 0);
@@ -504,7 +642,11 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         LinSpec sp[2];
         // FF in + GEGLU: writes the gated activations [M][2048] into `part`
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].cat, w[i]->w_ff1, ws[i].part, w[i]->b_ff1, 4096};
-        AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 2048, s), "ff in + geglu");
+        // B >= 16, even: the FF-in projection (N = 4096) has enough 128 x 128 tiles to fill the chip; FF-out
+        // (N = 256: 64 tiles, K = 2048) does not and stays on the split-K kernel (75 vs 147 us at B = 32)
+        const bool tiled = tile_eligible(M, 512, 4096, 2048);
+        if (tiled) AHV_TRY(launch_linear_tile(sp, 512, 512, M, 512, 2048, s), "ff in + geglu (tiled)");
+        else AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 2048, s), "ff in + geglu");
         // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
         AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
