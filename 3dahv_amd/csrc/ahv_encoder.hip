@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 // -------------------------------------------------------------------------------------------------
 struct TileArgs {
     LinProb p[2];  // tile0 unused
-    int M, K, ntiles;  // ntiles = column tiles per problem
+    int M, K, ntiles;  // K = K range of ONE split (blockIdx.z = ks), ntiles = column tiles per problem
     long ldx, ldw;
     int geglu_h;
 };
@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int j = srow + 64 * i;  // tile row
-        xg[i] = pr.X + (long)(m0 + j) * a.ldx + 4 * sch;
+        xg[i] = pr.X + (long)(m0 + j) * a.ldx + (long)blockIdx.z * a.K + 4 * sch;
         int wrow;
         if (GEGLU) wrow = ((j >> 5) & 1) * a.geglu_h + tile * 64 + 32 * (j >> 6) + (j & 31);
         else wrow = tile * 128 + j;
-        wg[i] = pr.W + (long)wrow * a.ldw + 4 * sch;
+        wg[i] = pr.W + (long)wrow * a.ldw + (long)blockIdx.z * a.K + 4 * sch;
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -276,13 +276,14 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
                 }
         }
     } else {
+        float* P = pr.P + (long)blockIdx.z * a.M * pr.N;  // split-K slab [ks][M][N]
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    pr.P[(long)(m0 + 64 * wr + 16 * i + 4 * kq + r) * pr.N + tile * 128 + 64 * wc + 16 * j + r16] = acc[i][j][r];
+                    P[(long)(m0 + 64 * wr + 16 * i + 4 * kq + r) * pr.N + tile * 128 + 64 * wc + 16 * j + r16] = acc[i][j][r];
     }
 }
 
@@ -563,13 +564,14 @@ static bool tile_eligible(int M, int K, int N, int geglu_h)
     return geglu_h > 0 ? (geglu_h % 64 == 0 && N == 2 * geglu_h) : (N % 128 == 0);
 }
 
-static hipError_t launch_linear_tile(const LinSpec* specs, long ldx, long ldw, int M, int K, int geglu_h, hipStream_t s)
+static hipError_t launch_linear_tile(const LinSpec* specs, long ldx, long ldw, int M, int K, int KS, int geglu_h,
+                                     hipStream_t s)
 {
     TileArgs a;
-    a.M = M; a.K = K; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
+    a.M = M; a.K = K / KS; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
     for (int i = 0; i < 2; ++i) a.p[i] = LinProb{specs[i].X, specs[i].W, specs[i].P, specs[i].bias, specs[i].N, 0};
     a.ntiles = geglu_h > 0 ? geglu_h / 64 : specs[0].N / 128;
-    const dim3 grid(2 * a.ntiles, M / 128);
+    const dim3 grid(2 * a.ntiles, M / 128, geglu_h > 0 ? 1 : KS);
     if (geglu_h > 0) hipLaunchKernelGGL(linear_tile_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(linear_tile_kernel<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
@@ -642,14 +644,14 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         LinSpec sp[2];
         // FF in + GEGLU: writes the gated activations [M][2048] into `part`
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].cat, w[i]->w_ff1, ws[i].part, w[i]->b_ff1, 4096};
-        // B >= 16, even: the FF-in projection (N = 4096) has enough 128 x 128 tiles to fill the chip; FF-out
-        // (N = 256: 64 tiles, K = 2048) does not and stays on the split-K kernel (75 vs 147 us at B = 32)
+        // B >= 16, even: 128 x 128 tiles; FF-out (N = 256: only 64 tiles per stream) keeps its 4-way split-K
         const bool tiled = tile_eligible(M, 512, 4096, 2048);
-        if (tiled) AHV_TRY(launch_linear_tile(sp, 512, 512, M, 512, 2048, s), "ff in + geglu (tiled)");
+        if (tiled) AHV_TRY(launch_linear_tile(sp, 512, 512, M, 512, 1, 2048, s), "ff in + geglu (tiled)");
         else AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 2048, s), "ff in + geglu");
         // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
-        AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
+        if (tiled) AHV_TRY(launch_linear_tile(sp, 2048, 2048, M, 2048, 4, 0, s), "ff out (tiled, split-K 4)");
+        else AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
         LnArgs ln;
         ln.KS = 4; ln.M = M;
         for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
