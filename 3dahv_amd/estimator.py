@@ -220,6 +220,15 @@ class EstimatorObjaverse(_EstimatorBase):
         self.log("train_loss", loss.item())
         return loss
 
+    def configure_optimizers(self):
+        """modules/model.py:212-218: the backbone trains at a tenth of the aligner's rate, StepLR(20, 0.1)."""
+        lr = float(self.cfg["TRAIN"]["LR"])
+        groups = [{"params": self.feature_aligner.parameters(), "lr": lr}]
+        if isinstance(self.feature_extractor, nn.Module):
+            groups.append({"params": self.feature_extractor.parameters(), "lr": 0.1 * lr})
+        optimizer = torch.optim.AdamW(groups, eps=1e-5)
+        return [optimizer], [torch.optim.lr_scheduler.StepLR(optimizer, step_size=20, gamma=0.1)]
+
     def _too_small(self, mask_src, mask_tgt):
         thr = self.cfg["DATA"]["SIZE_THR"]
         return bool(torch.any(mask_src.flatten(1).sum(dim=-1) < thr) or torch.any(mask_tgt.flatten(1).sum(dim=-1) < thr))

@@ -138,3 +138,16 @@ def test_patch_install_rebinds_reference_callables(ahv):
         assert Feature_Aligner().forward_3d2d(None) == "reference"
     finally:
         sys.modules.pop("fake_script", None)
+
+
+def test_configure_optimizers_follow_each_variant(ahv):
+    """AdamW eps 1e-5 in both; co3d: one rate, StepLR(200) (model_co3d.py:93-99); objaverse: backbone at a tenth,
+    StepLR(20) (model.py:212-218)."""
+    cfg = small_cfg()
+    cfg["TRAIN"] = {"LR": 1e-4, "MASK": True, "MASK_RATIO": 0.25}
+    for cls, rates, step in ((ahv.estimator.EstimatorCo3d, (1e-4, 1e-4), 200), (ahv.estimator.EstimatorObjaverse, (1e-4, 1e-5), 20)):
+        m = cls(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1))
+        (opt,), (sched,) = m.configure_optimizers()
+        assert isinstance(opt, torch.optim.AdamW) and all(g["eps"] == 1e-5 for g in opt.param_groups)
+        assert tuple(pytest.approx(g["lr"]) for g in opt.param_groups) == rates
+        assert sched.step_size == step and sched.gamma == 0.1
