@@ -49,7 +49,13 @@ class PatchifyBackbone(nn.Module):
             self.proj.bias.zero_()
 
     def forward(self, img):
-        return self.proj(img)
+        # a stride = kernel convolution is a reshape + one GEMM; written that way because MIOpen has only its naive
+        # fp32 kernels for this shape on gfx950 (4.4 ms forward + 2.8 ms weight gradient per step at B = 12)
+        p = self.proj.kernel_size[0]
+        B, C, H, W = img.shape
+        x = img.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // p) * (W // p), C * p * p)
+        y = x @ self.proj.weight.reshape(self.proj.out_channels, -1).t() + self.proj.bias
+        return y.transpose(1, 2).reshape(B, -1, H // p, W // p)
 
 
 class _EstimatorBase(nn.Module):
