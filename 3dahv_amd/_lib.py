@@ -34,6 +34,7 @@ SIGNATURES = {
     "ahv_score_features_f32": (_int, [_vp, _vp, _int, _i64, _vp, _vp]),
     "ahv_argmax_f32": (_int, [_vp, _int, _i64, _i64, _vp, _u32, _vp]),
     "ahv_random_rotations_f32": (_int, [ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
+    "ahv_so3_grid_f32": (_int, [_i64, _i64, _i64, _vp, _vp]),
     "ahv_select_rotation_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
     "ahv_compose_rotations_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp]),
 }

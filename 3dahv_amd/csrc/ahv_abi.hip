@@ -23,6 +23,7 @@ hipError_t launch_compose_rotations(const uint64_t*, const float*, int64_t, int6
 hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*,
                                   int64_t*, hipStream_t);
 hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStream_t);
+hipError_t launch_so3_grid(int64_t, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
                                  const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*,
                                  float*, float*, int, hipStream_t);
@@ -298,6 +299,17 @@ int ahv_random_rotations_f32(uint64_t seed, uint64_t offset, int64_t N, float* o
     if (!out) return fail(AHV_EINVAL, "random_rotations: null pointer");
     hipError_t e = ahv::launch_random_rotations(seed, offset, N, out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("random_rotations: launch", e);
+    return AHV_OK;
+}
+
+int ahv_so3_grid_f32(int64_t n_total, int64_t offset, int64_t N, float* out, void* stream)
+{
+    if (N < 0 || offset < 0 || n_total <= 0 || offset + N > n_total)
+        return fail(AHV_EINVAL, "so3_grid: need 0 <= offset, 0 <= N, offset + N <= n_total");
+    if (N == 0) return AHV_OK;
+    if (!out) return fail(AHV_EINVAL, "so3_grid: null pointer");
+    hipError_t e = ahv::launch_so3_grid(n_total, offset, N, out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("so3_grid: launch", e);
     return AHV_OK;
 }
 

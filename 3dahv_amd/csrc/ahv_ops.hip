@@ -496,6 +496,29 @@ __global__ __launch_bounds__(256) void random_rotations_kernel(unsigned long lon
     o[6] = t * (qi * qk - qj * qr);        o[7] = t * (qj * qk + qi * qr);        o[8] = 1.0f - t * (qi * qi + qj * qj);
 }
 
+// Super-Fibonacci SO(3) grid (Alexa, CVPR 2022): point i of n is the quaternion
+// (sqrt(t) sin a, sqrt(t) cos a, sqrt(1-t) sin b, sqrt(1-t) cos b), t = (i + 1/2)/n, a = 2 pi (i + 1/2)/sqrt(2),
+// b = 2 pi (i + 1/2)/psi.  The angles reach 10^6 rad, so their turn fraction is taken in fp64 before sin/cos.
+__global__ __launch_bounds__(256) void so3_grid_kernel(long n_total, long offset, long N, float* __restrict__ out)
+{
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double s = (double)(offset + n) + 0.5;
+    const double t = s / (double)n_total;
+    double fa = s * 0.70710678118654752440, fb = s * (1.0 / 1.533751168755204288118041);
+    fa -= floor(fa);
+    fb -= floor(fb);
+    float sa, ca, sb, cb;
+    sincosf(6.28318530717958647692f * (float)fa, &sa, &ca);
+    sincosf(6.28318530717958647692f * (float)fb, &sb, &cb);
+    const float r = sqrtf((float)t), Rr = sqrtf((float)(1.0 - t));
+    const float qr = r * sa, qi = r * ca, qj = Rr * sb, qk = Rr * cb;  // unit norm by construction
+    float* o = out + n * 9;
+    o[0] = 1.0f - 2.0f * (qj * qj + qk * qk); o[1] = 2.0f * (qi * qj - qk * qr);        o[2] = 2.0f * (qi * qk + qj * qr);
+    o[3] = 2.0f * (qi * qj + qk * qr);        o[4] = 1.0f - 2.0f * (qi * qi + qk * qk); o[5] = 2.0f * (qj * qk - qi * qr);
+    o[6] = 2.0f * (qi * qk - qj * qr);        o[7] = 2.0f * (qj * qk + qi * qr);        o[8] = 1.0f - 2.0f * (qi * qi + qj * qj);
+}
+
 // ---- launchers ----------------------------------------------------------------------
 hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C,
                                 int D, int H, int W, float* out, int num_cu, hipStream_t stream)
@@ -585,6 +608,13 @@ hipError_t launch_random_rotations(uint64_t seed, uint64_t offset, int64_t N, fl
 {
     hipLaunchKernelGGL(random_rotations_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream,
                        (unsigned long long)seed, (unsigned long long)offset, (long)N, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_so3_grid(int64_t n_total, int64_t offset, int64_t N, float* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(so3_grid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (long)n_total,
+                       (long)offset, (long)N, out);
     return hipGetLastError();
 }
 

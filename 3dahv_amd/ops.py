@@ -307,6 +307,19 @@ def compose_rotations(best_key: torch.Tensor, R: torch.Tensor, D: torch.Tensor, 
 
 
 @torch.no_grad()
+def so3_grid(n_total: int, device, offset: int = 0, n: int | None = None) -> torch.Tensor:
+    """Rows ``[offset, offset + n)`` of the deterministic ``n_total``-point super-Fibonacci SO(3) grid, generated on
+    the device (``rotations.so3_grid_np`` is the host form of the same grid)."""
+    n = n_total - offset if n is None else n
+    out = torch.empty((n, 3, 3), dtype=torch.float32, device=device)
+    if out.device.type != "cuda":
+        raise RuntimeError("3dahv_amd ops run on the GPU only (no CPU fallback); got device %s" % out.device)
+    lib = _lib.load()
+    _lib.check(lib.ahv_so3_grid_f32(n_total, offset, n, out.data_ptr(), _stream()), "ahv_so3_grid_f32")
+    return out
+
+
+@torch.no_grad()
 def random_rotations(n: int, seed: int = 0, offset: int = 0, device=None, out: torch.Tensor | None = None) -> torch.Tensor:
     """Drop-in for ``pytorch3d.transforms.random_rotations(n)`` generated on the GPU: Haar-uniform (n,3,3) fp32.
     Rotation i depends only on ``(seed, offset + i)``: ``random_rotations(n, s)[a:b]`` equals

@@ -169,6 +169,13 @@ int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t 
 int ahv_random_rotations_f32(uint64_t seed, uint64_t offset, int64_t N, float* out, void* stream);
 
 /*
+ * Rows [offset, offset + N) of the deterministic, nearly uniform n_total-point SO(3) grid (super-Fibonacci
+ * spiral), out [N][3][3].  Build-defined: the reference has no grid (test_linemod.py:43 samples randomly);
+ * BASELINE.json configs[2] asks for a dense one.  Shards can be generated independently (offset).
+ */
+int ahv_so3_grid_f32(int64_t n_total, int64_t offset, int64_t N, float* out, void* stream);
+
+/*
  * Weights of one BasicTransformerBlock of the reference's encoder (transformer/attention.py:240-258),
  * device pointers, fp32, torch layouts (Linear weight = [out][in]).  State-dict names in comments.
  */

@@ -414,3 +414,20 @@ def test_planted_rotation_recovered_at_full_size(ops, ahv, G, dev):
     e2 = ahv.rotations.geodesic_deg(R2, R_true).item()
     print("coarse error %.2f deg -> refined %.2f deg" % (e1, e2))
     assert e1 < 15.0 and e2 < e1 and e2 < 3.0
+
+
+def test_device_so3_grid_matches_host_grid(ops, ahv, dev):
+    """ahv_so3_grid_f32 = rotations.so3_grid_np (fp64 host maths) to fp32 rounding, also for the far end of a
+    200 000-point grid (angles ~ 10^6 rad) and for shards generated independently."""
+    for n in (1, 1000, 200_000):
+        host = ahv.rotations.so3_grid_np(n)
+        got = ops.so3_grid(n, dev).cpu().numpy()
+        assert got.shape == (n, 3, 3) and np.abs(got - host).max() < 2e-6
+    lo, hi = ahv.dist.shard_range(200_000, 3, 8)
+    shard = ops.so3_grid(200_000, dev, offset=lo, n=hi - lo)
+    assert torch.equal(shard, ops.so3_grid(200_000, dev)[lo:hi])
+    Rd = ops.so3_grid(50_000, dev).double()
+    eye = torch.eye(3, dtype=torch.float64, device=dev)
+    assert (Rd @ Rd.transpose(1, 2) - eye).abs().max().item() < 5e-6 and (torch.linalg.det(Rd) - 1).abs().max().item() < 5e-6
+    with pytest.raises(RuntimeError):
+        ops.so3_grid(10, dev, offset=8, n=5)

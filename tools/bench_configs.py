@@ -34,7 +34,7 @@ only = sys.argv[1:]
 if not only or "3" in only:
     # configs[2]: LINEMOD pair, dense SO(3) grid N=200k; fused and op-level (materialising, HBM-bound) pipelines
     N = 200_000
-    R = torch.from_numpy(ahv.rotations.so3_grid_np(N)).to(dev)
+    R = ops.so3_grid(N, dev)  # deterministic super-Fibonacci grid, generated on the device
     vs, vt = vol[0, :1], vol[1, :1]
     ft = ops.forward_3d2d(vt, W1, W2, b2)
     ms = timeit(lambda: ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False), 10)
