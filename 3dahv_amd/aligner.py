@@ -118,8 +118,12 @@ def hip_forward_2d3d(fa, src, tgt):
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=src.device)
     vol_src = torch.empty((B, 16, 8, 8, 8), dtype=torch.float32, device=src.device)
     vol_tgt = torch.empty_like(vol_src)
-    _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed[0]), src.detach().contiguous().data_ptr(),
-                                        tgt.detach().contiguous().data_ptr(), B, ws.data_ptr(), nbytes,
+    # keep the contiguous copies alive until the launch is enqueued: a temporary whose data_ptr() is taken inline is
+    # returned to the allocator at once and the NEXT temporary may land on the same block (strided batches, e.g. the
+    # harness's feats[:, 0], then read the target's copy as the source)
+    src_c, tgt_c = src.detach().contiguous(), tgt.detach().contiguous()
+    _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed[0]), src_c.data_ptr(),
+                                        tgt_c.data_ptr(), B, ws.data_ptr(), nbytes,
                                         vol_src.data_ptr(), vol_tgt.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream), "ahv_forward_2d3d_f32")
     return vol_src, vol_tgt

@@ -111,3 +111,14 @@ def test_patch_rebinds_forward_2d3d_of_a_reference_shaped_module(ahv, fa):
     for x, y in zip(got, want):
         assert rel(x, y) < 2e-5
     assert masked[0].shape == (1, 16, 8, 8, 8)
+
+
+def test_forward_2d3d_strided_batch_inputs(fa):
+    """Inputs that need a contiguous copy (a strided batch such as feats[:, 0] of a (P, 2, C, 8, 8) tensor): the
+    copies must outlive the launch -- regression for temporaries freed (and their block reused) before the kernel ran."""
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(3, 2, 768, 8, 8, generator=g).cuda()
+    with torch.no_grad():
+        a, b = fa.forward_2d3d(feats[:, 0], feats[:, 1], random_mask=False, mask_ratio=0.0)
+        ra, rb = fa.forward_2d3d(feats[:, 0].contiguous(), feats[:, 1].contiguous(), random_mask=False, mask_ratio=0.0)
+    assert torch.equal(a, ra) and torch.equal(b, rb)

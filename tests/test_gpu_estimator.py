@@ -105,6 +105,12 @@ def test_harness_gpu_equals_oracle_verify(ahv, oracle, dev):
                                                  proposals=torch.from_numpy(ahv.rotations.haar_rotations_np(256, 5)))
     assert [d["idx"] for d in d_hip] == [d["idx"] for d in d_ref]
     assert np.allclose(e_hip, e_ref, atol=1e-4)
+    # the default on the GPU batches the ordered pairs of a sequence; one by one (as the reference) gives the same
+    np.random.seed(0)
+    e_one, d_one = ahv.harness.evaluate_category(c, m, seqs, device=dev, return_details=True, batch_pairs=False,
+                                                 proposals=torch.from_numpy(ahv.rotations.haar_rotations_np(256, 5)))
+    assert [(d["pair"], d["idx"]) for d in d_one] == [(d["pair"], d["idx"]) for d in d_hip]
+    assert np.allclose(e_one, e_hip, atol=1e-5) and np.allclose([d["best"] for d in d_one], [d["best"] for d in d_hip], atol=1e-6)
 
 
 def test_patched_reference_callables_run_on_hip(ahv, dev, g128):

@@ -191,3 +191,24 @@ if not only or "trainstep" in only:
     ms_graph = timeit(lambda: gstep(batch), 10, warm=2)
     print(json.dumps({"config": "training_step B=12 N=3000 (synthetic backbone)", "mode": "one hipGraph per iteration (rocBLAS)",
                       "full_step_ms": ms_graph, "loss": float(gstep.loss.item())}))
+
+if not only or "pairs" in only:
+    # end-to-end per-pair throughput of the evaluation loop (test_co3d.py:93-154 counterpart): encoder + verify at
+    # N = 50 000 + metric, synthetic layer_4 features; ordered pairs one by one (reference order) vs batched
+    cfgp = {"RUN_NAME": "t", "DATA": {"NUM_ROTA": 50000, "BG": True, "SIZE_THR": 25, "OBJ_SIZE": 256}}
+    torch.manual_seed(0)
+    mp_ = ahv.estimator.EstimatorCo3d(cfgp).to(dev).eval()
+    P = ops.random_rotations(50000, seed=1, device=dev)
+    graphed = mp_.feature_aligner.graphed_forward_2d3d(2)
+    for name, kw in (("one by one (reference order)", dict(batch_pairs=False)), ("ordered pairs batched", dict(batch_pairs=True)),
+                     ("batched + encoder replayed from a hipGraph", dict(batch_pairs=True, encoder_fn=graphed))):
+        seqs = list(ahv.harness.SyntheticSequences(40, 2, seed=1))     # materialised: data generation is not timed
+        np.random.seed(0)
+        ahv.harness.evaluate_category(cfgp, mp_, seqs[:4], device=dev, proposals=P, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e = ahv.harness.evaluate_category(cfgp, mp_, seqs, device=dev, proposals=P, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": name, "pairs": len(e),
+                          "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))
