@@ -51,6 +51,17 @@ def test_argument_validation_needs_no_gpu(lib, ahv):
     assert rc == -1 and b"flags" in lib.ahv_last_error()
     with pytest.raises(ahv._lib.AhvError):
         ahv._lib.check(rc, "x")
+    # backward entry point: workspace size is a pure function; pointer / stride / workspace checks come first
+    assert lib.ahv_score_hypotheses_backward_workspace_bytes(2, 10) == 4 * (2048 * 20 + 4)
+    assert lib.ahv_score_hypotheses_backward_workspace_bytes(0, 10) == 0
+    bw = lib.ahv_score_hypotheses_backward_f32
+    assert bw(1, 1, 1, 0, 1, 1, 1, 1, 10, 1, 16, 1 << 30, 1, 1, None, 1, 1, None) == -1 and b"weight-gradient" in lib.ahv_last_error()
+    assert bw(None, 1, 1, 0, 1, 1, 1, 1, 10, 1, 16, 1 << 30, 1, 1, 1, 1, 1, None) == -1 and b"null" in lib.ahv_last_error()
+    assert bw(1, 1, 1, 7, 1, 1, 1, 1, 10, 1, 16, 1 << 30, 1, 1, 1, 1, 1, None) == -1 and b"r_batch_stride" in lib.ahv_last_error()
+    assert bw(1, 1, 1, 0, 1, 1, 1, 1, 10, 1, 16, 100, 1, 1, 1, 1, 1, None) == -1 and b"workspace of 100" in lib.ahv_last_error()
+    assert bw(1, 1, 1, 0, 1, 1, 1, 1, 10, 1, 20, 1 << 30, 1, 1, 1, 1, 1, None) == -1 and b"aligned" in lib.ahv_last_error()
+    assert lib.ahv_so3_grid_f32(10, 8, 5, 1, None) == -1 and b"so3_grid" in lib.ahv_last_error()
+    assert lib.ahv_so3_grid_f32(10, 0, 0, None, None) == 0
 
 
 def test_ops_refuse_cpu_tensors(ahv):
