@@ -60,7 +60,7 @@ class SyntheticSequences:
 def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2, device=None,
                       proposals: Optional[torch.Tensor] = None, verify_fn: Optional[Callable] = None,
                       return_details: bool = False, batch_pairs: Optional[bool] = None,
-                      encoder_fn: Optional[Callable] = None):
+                      encoder_fn: Optional[Callable] = None, batch_sequences: int = 1):
     """Counterpart of ``evaluate_category`` (test_co3d.py:93-154).  Returns the array of angular errors.
 
     Per-pair results stay on the device and are fetched once per category (the reference synchronises per pair with
@@ -83,6 +83,31 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
     if verify_fn is None:
         verify_fn = lambda vs, vt, P: model.verify(vs, vt, P)[1:3]  # (best, idx): fused HIP launch
     details, pending = [], []
+    queue = []  # per sequence: (feats (P,2,...), R_gt (P,3,3), model_id, uses layer4)
+
+    def flush():
+        """One encoder call and one fused verify launch for every queued ordered pair."""
+        if not queue:
+            return
+        feats = torch.cat([q[0] for q in queue])
+        R_gt = torch.cat([q[1] for q in queue])
+        embed = (encoder_fn or model.forward_features) if queue[0][3] else model
+        vol_src, vol_tgt = embed(feats[:, 0], feats[:, 1])
+        best, idx = verify_fn(vol_src, vol_tgt, proposals)
+        R_pred = proposals[idx.reshape(-1)]
+        err = geodesic_deg(R_pred, R_gt).reshape(-1)
+        pending.append(err)                                                # stays on the device: no sync per pair
+        if return_details:
+            bs, ids, el = best.reshape(-1).tolist(), idx.reshape(-1).tolist(), err.tolist()
+            k = 0
+            for q in queue:
+                for i in range(q[0].shape[0]):
+                    details.append({"model_id": q[2], "pair": q[4][i], "best": float(bs[k]), "idx": int(ids[k]),
+                                    "R_pred": R_pred[k].cpu().numpy(), "err": el[k]})
+                    k += 1
+        queue.clear()
+
+    pairs_per_flush = (len(permutations) if batch_pairs else 1) * max(int(batch_sequences), 1)
     for meta in sequences:
         key_frames = np.random.choice(meta["n"], num_frames, replace=False)
         if "get_data" in meta:  # lazy source (co3d.Co3dSequences): decode only the key frames (test_co3d.py:112)
@@ -93,21 +118,13 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
         sel = torch.as_tensor(np.asarray(key_frames), device=device)[permutations.to(device)]   # (P, 2) frame ids
         rot = meta["R"].to(device)[sel]                                     # (P, 2, 3, 3)
         R_gt = torch.bmm(rot[:, 0].transpose(1, 2), rot[:, 1])
-        feats = (meta["layer4"] if "layer4" in meta else meta["image"]).to(device)[sel]   # (P, 2, ...)
-        embed = (encoder_fn or model.forward_features) if "layer4" in meta else model
-        groups = [slice(0, len(permutations))] if batch_pairs else [slice(i, i + 1) for i in range(len(permutations))]
-        for g in groups:
-            vol_src, vol_tgt = embed(feats[g, 0], feats[g, 1])
-            best, idx = verify_fn(vol_src, vol_tgt, proposals)
-            R_pred = proposals[idx.reshape(-1)]
-            err = geodesic_deg(R_pred, R_gt[g]).reshape(-1)
-            pending.append(err)                                            # stays on the device: no sync per pair
-            if return_details:
-                bs, ids, el = best.reshape(-1).tolist(), idx.reshape(-1).tolist(), err.tolist()
-                for j, i in enumerate(range(*g.indices(len(permutations)))):
-                    details.append({"model_id": meta["model_id"], "pair": tuple(permutations[i].tolist()),
-                                    "best": float(bs[j]), "idx": int(ids[j]), "R_pred": R_pred[j].cpu().numpy(),
-                                    "err": el[j]})
+        uses_l4 = "layer4" in meta
+        feats = (meta["layer4"] if uses_l4 else meta["image"]).to(device)[sel]   # (P, 2, ...)
+        for i in range(len(permutations)):
+            queue.append((feats[i:i + 1], R_gt[i:i + 1], meta["model_id"], uses_l4, [tuple(permutations[i].tolist())]))
+            if sum(q[0].shape[0] for q in queue) >= pairs_per_flush:
+                flush()
+    flush()
     errors = torch.cat(pending).tolist() if pending else []               # ONE host synchronisation per category
     errors = np.array(errors)
     return (errors, details) if return_details else errors

@@ -111,6 +111,12 @@ def test_harness_gpu_equals_oracle_verify(ahv, oracle, dev):
                                                  proposals=torch.from_numpy(ahv.rotations.haar_rotations_np(256, 5)))
     assert [(d["pair"], d["idx"]) for d in d_one] == [(d["pair"], d["idx"]) for d in d_hip]
     assert np.allclose(e_one, e_hip, atol=1e-5) and np.allclose([d["best"] for d in d_one], [d["best"] for d in d_hip], atol=1e-6)
+    # several sequences per batch: same pairs in the same order, same answers
+    np.random.seed(0)
+    e_grp, d_grp = ahv.harness.evaluate_category(c, m, seqs, device=dev, return_details=True, batch_sequences=2,
+                                                 proposals=torch.from_numpy(ahv.rotations.haar_rotations_np(256, 5)))
+    assert [(d["model_id"], d["pair"], d["idx"]) for d in d_grp] == [(d["model_id"], d["pair"], d["idx"]) for d in d_hip]
+    assert np.allclose(e_grp, e_hip, atol=1e-5)
 
 
 def test_patched_reference_callables_run_on_hip(ahv, dev, g128):
