@@ -21,6 +21,25 @@ from . import _lib
 _VOL = (16, 8, 8, 8)
 
 
+class score_variant:
+    """Select the fused-scorer kernel: ``ops.score_variant(4)`` as a statement switches for the process,
+    ``with ops.score_variant(4): ...`` for a block.  3 = all-fp32 (default); 4 = GEMM1 as split-f16 MFMA
+    products with fp32 accumulation (1.85x faster, scores as close to the fp64 truth as the fp32 kernel's --
+    DESIGN.md section 4.1); 0-2 = earlier fp32 kernels kept for A/B runs."""
+
+    def __init__(self, variant: int):
+        self.prev = _lib.load().ahv_set_option(b"score_variant", int(variant))
+        if self.prev < 0:
+            _lib.check(self.prev, "ahv_set_option")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().ahv_set_option(b"score_variant", self.prev)
+        return False
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

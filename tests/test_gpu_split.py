@@ -122,3 +122,13 @@ def test_split_soak_against_fp32_kernel(ops, ahv, variant, dev):
         top2 = torch.topk(s32, min(2, N), dim=1).values
         clear = (top2[:, 0] - top2[:, -1] > 2e-6) | (N == 1)
         assert torch.equal(i4[clear], i32[clear])
+
+
+def test_score_variant_context_manager(ops, ahv, dev):
+    lib = ahv._lib.load()
+    assert lib.ahv_set_option(b"score_variant", 3) >= 0
+    with ops.score_variant(4):
+        assert lib.ahv_set_option(b"score_variant", 4) == 4      # reads back the variant in force
+    assert lib.ahv_set_option(b"score_variant", 3) == 3          # restored on exit
+    with pytest.raises(RuntimeError):
+        ops.score_variant(9)

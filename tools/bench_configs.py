@@ -214,3 +214,14 @@ if not only or "pairs" in only:
         dt = time.perf_counter() - t0
         print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": name, "pairs": len(e),
                           "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))
+    with ops.score_variant(4):  # opt-in split-f16 scorer
+        seqs = list(ahv.harness.SyntheticSequences(40, 2, seed=1))
+        np.random.seed(0)
+        ahv.harness.evaluate_category(cfgp, mp_, seqs[:4], device=dev, proposals=P, batch_sequences=16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e = ahv.harness.evaluate_category(cfgp, mp_, seqs, device=dev, proposals=P, batch_sequences=16)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": "16 sequences per batch, score_variant 4 (split-f16, opt-in)",
+                          "pairs": len(e), "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))
