@@ -431,3 +431,23 @@ def test_device_so3_grid_matches_host_grid(ops, ahv, dev):
     assert (Rd @ Rd.transpose(1, 2) - eye).abs().max().item() < 5e-6 and (torch.linalg.det(Rd) - 1).abs().max().item() < 5e-6
     with pytest.raises(RuntimeError):
         ops.so3_grid(10, dev, offset=8, n=5)
+
+
+def test_fused_on_a_side_stream_and_in_a_graph(ops, G, g128, dev):
+    """Launches go to torch's CURRENT stream (whatever it is) and are capturable: same scores from a side stream and
+    from a replayed hipGraph as from the default stream."""
+    ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
+    ref, ref_key = ops.score_hypotheses(G["vol_src"], ft, G["R"], G["W1"], G["W2"], G["b2"])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s1, k1 = ops.score_hypotheses(G["vol_src"], ft, G["R"], G["W1"], G["W2"], G["b2"])
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(s1, ref) and torch.equal(k1, ref_key)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        s2, k2 = ops.score_hypotheses(G["vol_src"], ft, G["R"], G["W1"], G["W2"], G["b2"])
+    s2.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(s2, ref) and torch.equal(k2, ref_key)
