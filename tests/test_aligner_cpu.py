@@ -94,3 +94,48 @@ def test_conv_as_matmul_equals_conv_forward_and_backward(ahv):
         for a, b in zip(r1, r2):
             assert torch.allclose(a, b, atol=1e-11)
     assert ahv.aligner.conv_mm(cases[0][0], torch.randn(2, 24, 8, 8, dtype=torch.float64)).shape == (2, 8, 8, 8)  # CPU: the module itself
+
+
+# ---- G7 `encoder_full`: the mirror at the size the HIP kernels are built for (768 / 256 / 4 x 64 / depth 4) ----
+@pytest.fixture(scope="module")
+def full(ahv):
+    from .procfill import procedural_state_dict
+    g = load_golden("encoder_full")
+    fa = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).eval()
+    fa.load_state_dict(procedural_state_dict(fa.state_dict()), strict=True)
+    assert sum(p.numel() for p in fa.parameters()) == int(g["n_param"])
+    return g, fa
+
+
+def test_full_size_mirror_matches_reference_fixture(full):
+    """Reference Feature_Aligner(768,256,32,4,4).forward_2d3d (modules/modules.py:86-110) -> mirror, <= 1e-5 of the
+    tensor's largest entry on both volumes and on the tokens after BidirectionTransformerBlock 0."""
+    g, fa = full
+    grabbed = {}
+    hook = fa.att.transformer_blocks[0].register_forward_hook(
+        lambda m, i, o: grabbed.update(tin=(i[0].detach(), i[1].detach()), tout=(o[0].detach(), o[1].detach())))
+    x_src, x_tgt = torch.from_numpy(g["x_src"]).float(), torch.from_numpy(g["x_tgt"]).float()
+    with torch.no_grad():
+        v_src, v_tgt = fa.forward_2d3d(x_src, x_tgt, random_mask=False, mask_ratio=0)
+    hook.remove()
+    rel = lambda a, b: float(np.max(np.abs(a.numpy() - b)) / np.max(np.abs(b)))
+    assert rel(grabbed["tin"][0][:, :8], g["tok_in_src_first8"]) < 1e-5
+    assert rel(grabbed["tin"][1][:, :8], g["tok_in_tgt_first8"]) < 1e-5
+    assert rel(grabbed["tout"][0], g["tok0_src"]) < 1e-5 and rel(grabbed["tout"][1], g["tok0_tgt"]) < 1e-5
+    assert rel(v_src, g["vol_src"]) < 1e-5 and rel(v_tgt, g["vol_tgt"]) < 1e-5
+
+
+def test_procedural_fill_is_stable():
+    """The fill must not drift with the numpy version: a few pinned values (generated when the fixture was)."""
+    from .procfill import procedural_tensor
+    a = procedural_tensor("att.transformer_blocks.0.attn_self_1.ff.net.0.proj.weight", (4096, 512))
+    b = procedural_tensor("att.norm.weight", (256,))
+    c = procedural_tensor("feature_embedding_2d.2.bias", (32,))
+    assert a.dtype == np.float32 and abs(float(np.abs(a).max()) - 1 / np.sqrt(512)) < 1e-6
+    assert 0.75 <= float(b.min()) and float(b.max()) <= 1.25 and abs(float(c.max())) <= 0.1
+    import hashlib
+    h = hashlib.sha256(a.tobytes() + b.tobytes() + c.tobytes()).hexdigest()
+    assert h == PROCFILL_SHA, h
+
+
+PROCFILL_SHA = "64658f846e85ec49b4fc90c1ded4fda17c2d5e5ad0592ce1e5770ee6503354d8"

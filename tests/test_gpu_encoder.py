@@ -122,3 +122,56 @@ def test_forward_2d3d_strided_batch_inputs(fa):
         a, b = fa.forward_2d3d(feats[:, 0], feats[:, 1], random_mask=False, mask_ratio=0.0)
         ra, rb = fa.forward_2d3d(feats[:, 0].contiguous(), feats[:, 1].contiguous(), random_mask=False, mask_ratio=0.0)
     assert torch.equal(a, ra) and torch.equal(b, rb)
+
+
+# ---- G7 `encoder_full`: reference -> HIP, one hop, at the size the kernels are built for -----------------------
+@pytest.fixture(scope="module")
+def full(ahv):
+    """Mirror module carrying the key-seeded procedural weights the REFERENCE's Feature_Aligner carried when
+    tools/gen_golden.py produced tests/golden/encoder_full.npz (modules/modules.py:86-110)."""
+    from .conftest import load_golden
+    from .procfill import procedural_state_dict
+    g = load_golden("encoder_full")
+    m = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).eval()
+    m.load_state_dict(procedural_state_dict(m.state_dict()), strict=True)
+    return g, m.cuda()
+
+
+@pytest.mark.parametrize("B", [1, 2, 17])  # 17 = the stored pair tiled (skinny kernels, odd row count)
+def test_hip_forward_2d3d_matches_reference_fixture(full, B):
+    """ahv_forward_2d3d_f32 vs the reference's own outputs: <= 1e-4 of the largest entry (measured ~1e-6)."""
+    g, m = full
+    xs = torch.from_numpy(g["x_src"]).float().cuda()
+    xt = torch.from_numpy(g["x_tgt"]).float().cuda()
+    pick = [i % 2 for i in range(B)]
+    with torch.no_grad():
+        assert m._hip_2d3d_eligible(xs[pick])
+        v_src, v_tgt = m.forward_2d3d(xs[pick], xt[pick], random_mask=False, mask_ratio=0.0)
+    want_s = torch.from_numpy(g["vol_src"]).cuda()[pick]
+    want_t = torch.from_numpy(g["vol_tgt"]).cuda()[pick]
+    assert v_src.shape == (B, 16, 8, 8, 8)
+    assert rel(v_src, want_s) < 1e-4 and rel(v_tgt, want_t) < 1e-4, (rel(v_src, want_s), rel(v_tgt, want_t))
+
+
+def test_hip_block0_tokens_match_reference_fixture(full):
+    """ahv_transformer_blocks_f32 restricted to BidirectionTransformerBlock 0 (transformer/attention.py:269-274)
+    vs the tokens a forward hook grabbed from the reference; block input = GroupNorm + proj_in of the embedded
+    features, evaluated by the mirror's stock operators (pinned to the same fixture on CPU, first 8 tokens here)."""
+    import copy
+    g, m = full
+    xs = torch.from_numpy(g["x_src"]).float().cuda()
+    xt = torch.from_numpy(g["x_tgt"]).float().cuda()
+    att1 = copy.deepcopy(m.att)
+    att1.transformer_blocks = torch.nn.ModuleList([att1.transformer_blocks[0]])
+    att1.invalidate_packed()
+    with torch.no_grad():
+        embed = lambda t: m.feature_embedding[1](m.feature_embedding[0](t))
+        pe = m.posemb_sincos_2d(xs, channel=256)[None]
+        tok = lambda t: t.flatten(2).transpose(1, 2)
+        ts = tok(att1.proj_in(att1.norm(embed(xs) + pe)))
+        tc = tok(att1.proj_context_in(att1.norm(embed(xt) + pe)))
+        assert rel(ts[:, :8], torch.from_numpy(g["tok_in_src_first8"]).cuda()) < 1e-4
+        assert rel(tc[:, :8], torch.from_numpy(g["tok_in_tgt_first8"]).cuda()) < 1e-4
+        gx, gc = att1._hip_blocks(ts, tc)
+    assert rel(gx, torch.from_numpy(g["tok0_src"]).cuda()) < 1e-4
+    assert rel(gc, torch.from_numpy(g["tok0_tgt"]).cuda()) < 1e-4

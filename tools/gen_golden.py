@@ -89,11 +89,43 @@ def axis_rot(axis, deg):
     return np.array(m, dtype=np.float32)
 
 
+def gen_encoder_full(Feature_Aligner):
+    """G7 `encoder_full`: the reference's FULL-SIZE Feature_Aligner(768,256,32,4,4).forward_2d3d
+    (modules/modules.py:86-110, transformer/attention.py:372-396) on a stored layer_4 pair, B = 2, with every
+    state-dict tensor overwritten by the key-seeded procedural fill of tests/procfill.py (the mirror has the same
+    keys, so the 192 MB of weights are rebuilt from the key names instead of being stored).  Inputs are rounded to
+    fp16-representable values and stored as fp16 (exact, half the bytes).  Also captured: the token tensors after
+    BidirectionTransformerBlock 0 (transformer/attention.py:269-274) through a forward hook."""
+    from tests.procfill import procedural_state_dict
+    torch.manual_seed(70)
+    fa = Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).eval()
+    fa.load_state_dict(procedural_state_dict(fa.state_dict()), strict=True)
+    x_src = torch.randn(2, 768, 8, 8).half()
+    x_tgt = torch.randn(2, 768, 8, 8).half()
+    grabbed = {}
+    hook = fa.att.transformer_blocks[0].register_forward_hook(
+        lambda mod, inp, out: grabbed.update(tok_in_src=inp[0].detach().clone(), tok_in_tgt=inp[1].detach().clone(),
+                                             tok0_src=out[0].detach().clone(), tok0_tgt=out[1].detach().clone()))
+    with torch.no_grad():
+        v_src, v_tgt = fa.forward_2d3d(x_src.float(), x_tgt.float(), random_mask=False, mask_ratio=0)
+    hook.remove()
+    n_param = sum(p.numel() for p in fa.parameters())
+    np.savez(os.path.join(OUT, "encoder_full.npz"), x_src=x_src.numpy(), x_tgt=x_tgt.numpy(),
+             tok0_src=grabbed["tok0_src"].numpy(), tok0_tgt=grabbed["tok0_tgt"].numpy(),
+             tok_in_src_first8=grabbed["tok_in_src"][:, :8].numpy(), tok_in_tgt_first8=grabbed["tok_in_tgt"][:, :8].numpy(),
+             vol_src=v_src.numpy(), vol_tgt=v_tgt.numpy(), n_param=np.int64(n_param))
+    print("G7 params %d, volume std %.3f max %.3f, tokens-after-block-0 std %.3f" % (
+        n_param, v_src.std().item(), v_src.abs().max().item(), grabbed["tok0_src"].std().item()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     torch.set_float32_matmul_precision("highest")
     rotate_volume, Feature_Aligner = import_reference()
+    if "--only-encoder-full" in sys.argv:
+        gen_encoder_full(Feature_Aligner)
+        return
 
     # ---- full-size aligner with seeded random weights; volumes via the reference's forward_2d3d
     torch.manual_seed(0)
@@ -196,6 +228,8 @@ def main():
     simm = (torch.sum(tp.view(-1, 9) * tg.view(-1, 9), dim=-1).clamp(-1, 3) - 1) / 2
     err = torch.arccos(simm) * 180.0 / np.pi
     np.savez(os.path.join(OUT, "metric.npz"), R_pred=Rp, R_gt=Rg, err_deg=err.numpy())
+
+    gen_encoder_full(Feature_Aligner)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", total)
