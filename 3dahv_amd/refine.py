@@ -7,6 +7,13 @@ small rotations (``rotations.refine_rotations(I, N2, max_angle)``; D[0] = I, so 
 score below stage 1).  Everything between the two stages stays on the device: the winner index is
 decoded from the packed key by ``ahv_compose_rotations_f32``; no host round trip, so the whole step
 (target features, 2 fused scorer launches, compose, select) replays from a graph.
+
+Multi-rank (one process per GPU): both hypothesis sets are sharded contiguously (``dist.shard_range``);
+each stage ends in the 8*B-byte packed-key all-reduce(max) of ``dist.all_reduce_best``, and the winner's
+rotation row (written by its owner rank only, zeros elsewhere) is summed.  The verify semantics per stage
+are those of modules/model.py:183-196.  With the ``nccl`` backend (= RCCL) the collectives are enqueued on
+the capturing stream like any kernel, so the two stages AND their all-reduces replay from one hipGraph
+(SURVEY.md section 8(d) cfg 5); other backends (gloo rehearsals, CPU tests) run the step eagerly.
 """
 from __future__ import annotations
 
@@ -21,10 +28,16 @@ from .rotations import refine_rotations
 
 
 class CoarseToFine:
+    """``backend`` provides ``forward_3d2d, score_hypotheses, compose_rotations, select_rotation, unpack_best``
+    with the signatures of ``3dahv_amd.ops`` (the default and the only product backend: HIP kernels, no CPU
+    path); CPU tests inject an oracle-backed object to execute the multi-rank control flow under gloo."""
+
     def __init__(self, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, R_coarse: torch.Tensor,
                  D: Optional[torch.Tensor] = None, n_fine: int = 1000, max_angle_deg: float = 10.0,
-                 batch: int = 1, use_graph: bool = True, group=None, seed: int = 0):
+                 batch: int = 1, use_graph: bool = True, group=None, seed: int = 0, backend=None,
+                 want_scores: bool = False, force_collectives: bool = False):
         dev = R_coarse.device
+        self.ops = ops if backend is None else backend
         self.W1, self.W2, self.b2 = W1, W2, b2
         self.R_coarse = R_coarse.contiguous()
         if D is None:
@@ -33,30 +46,48 @@ class CoarseToFine:
         self.D = D.to(dev).contiguous()
         self.B = batch
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.want_scores = want_scores
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
+        # a 1-rank RCCL group with force_collectives exercises "collectives inside the captured graph" on one GPU
+        self.collectives = self.world > 1 or (force_collectives and inited)
         self.c_lo, self.c_hi = shard_range(self.R_coarse.shape[0], self.rank, self.world)
         self.f_lo, self.f_hi = shard_range(self.D.shape[0], self.rank, self.world)
-        self.use_graph = use_graph and self.world == 1  # collectives are issued eagerly between the stages
+        capturable = (not self.collectives) or (inited and dist.get_backend(group) == "nccl")
+        self.use_graph = bool(use_graph and dev.type == "cuda" and capturable)
         self._graph = None
         self._static = None
 
+    def _merge(self, key):
+        if self.collectives:
+            if self.world > 1:
+                all_reduce_best(key, self.group)
+            else:  # forced on a 1-rank group: same call sequence, same captured nodes
+                key.bitwise_xor_(-(1 << 63))
+                dist.all_reduce(key, op=dist.ReduceOp.MAX, group=self.group)
+                key.bitwise_xor_(-(1 << 63))
+        return key
+
     # ---- the step, written once; runs eagerly or under capture
     def _step(self, vol_src, vol_tgt):
-        f_tgt = ops.forward_3d2d(vol_tgt, self.W1, self.W2, self.b2)
+        o = self.ops
+        f_tgt = o.forward_3d2d(vol_tgt, self.W1, self.W2, self.b2)
         Rc = self.R_coarse[self.c_lo:self.c_hi]
-        _, key1 = ops.score_hypotheses(vol_src, f_tgt, Rc, self.W1, self.W2, self.b2, n_offset=self.c_lo,
-                                       want_scores=False)
-        all_reduce_best(key1, self.group)
+        s1, key1 = o.score_hypotheses(vol_src, f_tgt, Rc, self.W1, self.W2, self.b2, n_offset=self.c_lo,
+                                      want_scores=self.want_scores)
+        self._merge(key1)
         # every rank holds the whole coarse set, so the winner (a global index) is always in range
-        R_fine = ops.compose_rotations(key1, self.R_coarse, self.D[self.f_lo:self.f_hi])
-        _, key2 = ops.score_hypotheses(vol_src, f_tgt, R_fine, self.W1, self.W2, self.b2, n_offset=self.f_lo,
-                                       want_scores=False)
-        all_reduce_best(key2, self.group)
-        score, idx, R_pred = ops.select_rotation(key2, R_fine, n_offset=self.f_lo)
-        if self.world > 1:  # only the owner rank wrote its row
+        R_fine = o.compose_rotations(key1, self.R_coarse, self.D[self.f_lo:self.f_hi])
+        s2, key2 = o.score_hypotheses(vol_src, f_tgt, R_fine, self.W1, self.W2, self.b2, n_offset=self.f_lo,
+                                      want_scores=self.want_scores)
+        self._merge(key2)
+        score, idx, R_pred = o.select_rotation(key2, R_fine, n_offset=self.f_lo)
+        if self.collectives:  # only the owner rank wrote its row, the others hold zeros
             dist.all_reduce(R_pred, group=self.group)
-        coarse_score, coarse_idx = ops.unpack_best(key1)
+        coarse_score, coarse_idx = o.unpack_best(key1)
+        # this rank's slices of the two score sets and of the refinement set (None unless want_scores)
+        self.last = {"coarse_scores": s1, "fine_scores": s2, "R_fine": R_fine if self.want_scores else None}
         return score, idx, R_pred, coarse_score, coarse_idx
 
     @torch.no_grad()
@@ -70,9 +101,11 @@ class CoarseToFine:
             self._static = (vol_src.clone(), vol_tgt.clone())
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):  # warm-up outside capture (lazy initialisation inside the launchers)
-                self._step(*self._static)
+            with torch.cuda.stream(s):  # warm-up outside capture (lazy initialisation inside the launchers / RCCL)
+                for _ in range(2):
+                    self._step(*self._static)
             torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._out = self._step(*self._static)

@@ -57,3 +57,117 @@ def test_coarse_to_fine_matches_two_stage_reference(ahv, setup, use_graph):
         assert torch.equal(idx, i2)
         assert torch.allclose(score, v2, rtol=1e-5) and torch.all(score >= c_score - 1e-6)
         assert torch.allclose(R_pred, fine[torch.arange(3), i2], atol=1e-6)
+
+
+# ---- BASELINE.json configs[4] at full size: 10 000 coarse + 1 000 refined, hipGraph, against the ORACLE ----------
+@pytest.mark.parametrize("B", [1, 3])
+def test_configs4_full_size_graph_vs_oracle(ahv, oracle, setup, B):
+    """Both stages of CoarseToFine (use_graph=True) against oracle.score_hypotheses on the same two hypothesis
+    sets (verify semantics: modules/model.py:183-196): coarse winner exact, scores of both stages <= 1e-4
+    relative, fine index exact, R_pred = the winning refinement."""
+    dev, vs3, vt3, W1, W2, b2 = setup
+    vs, vt = vs3[:B].contiguous(), vt3[:B].contiguous()
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(10_000, 40)).to(dev)
+    c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, max_angle_deg=10.0, batch=B, use_graph=True,
+                                  want_scores=True)
+    assert c2f.use_graph
+    W = [t.cpu().numpy() for t in (W1, W2, b2)]
+    rel = lambda got, ref: float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-2)))
+    for rep in range(2):  # second replay: swapped inputs through the same captured graph
+        a, b = (vs, vt) if rep == 0 else (vt, vs)
+        score, idx, R_pred, c_score, c_idx = [t.clone().cpu().numpy() for t in c2f(a, b)]
+        s1 = c2f.last["coarse_scores"].cpu().numpy()
+        s2 = c2f.last["fine_scores"].cpu().numpy()
+        R_fine = c2f.last["R_fine"].cpu().numpy()
+        an, bn = a.cpu().numpy(), b.cpu().numpy()
+        ref1, best1, idx1 = oracle.score_hypotheses(an, bn, R.cpu().numpy(), *W)
+        assert np.array_equal(c_idx, idx1)
+        assert rel(s1, ref1) < 1e-4 and rel(c_score, best1) < 1e-4
+        want_fine = np.matmul(R.cpu().numpy()[idx1][:, None], c2f.D.cpu().numpy()[None])
+        assert R_fine.shape == (B, 1000, 3, 3) and np.max(np.abs(R_fine - want_fine)) < 1e-6
+        ref2, best2, idx2 = oracle.score_hypotheses(an, bn, R_fine, *W)   # per-sample sets (B,N2,3,3)
+        assert rel(s2, ref2) < 1e-4 and rel(score, best2) < 1e-4
+        assert np.array_equal(idx, idx2), (idx, idx2, np.sort(ref2, axis=1)[:, -2:])
+        assert np.array_equal(R_pred, R_fine[np.arange(B), idx2])
+        assert np.all(score >= c_score - 1e-6)
+
+
+RANK_WORKER = r'''
+import importlib, os, sys, numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["AHV_REPO"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+backend = os.environ["AHV_BACKEND"]
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+solo = [dist.new_group([r]) for r in range(world)][rank]   # every rank creates every group; keeps its own
+ahv = importlib.import_module("3dahv_amd")
+g = np.load(os.path.join(os.environ["AHV_REPO"], "tests", "golden", "batched.npz"))
+h = np.load(os.path.join(os.environ["AHV_REPO"], "tests", "golden", "score_n128.npz"))
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+vs, vt, W1, W2, b2 = T(g["vol_src"]), T(g["vol_tgt"]), T(h["W1"]), T(h["W2"]), T(h["b2"])
+R = torch.from_numpy(ahv.rotations.haar_rotations_np(10_000, 40)).to(dev)
+force = backend == "nccl"
+multi = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=True, force_collectives=force)
+single = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=False, group=solo)
+assert single.world == 1 and not single.collectives
+assert multi.collectives and multi.use_graph == (backend == "nccl")
+for rep in range(3):
+    a, b = (vs, vt) if rep != 1 else (vt, vs)
+    got = [t.clone() for t in multi(a, b)]
+    ref = [t.clone() for t in single(a, b)]
+    for x, y in zip(got, ref):
+        assert torch.equal(x, y), (rank, rep, x, y)
+    flat = torch.cat([t.double().flatten() for t in got]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    if backend == "gloo":
+        dist.all_gather(both, flat)
+        assert all(torch.equal(both[0], o) for o in both)
+torch.cuda.synchronize()
+if rank == 0:
+    print("OK world=%d backend=%s graph=%s shards=%s" % (world, backend, multi.use_graph, (multi.c_lo, multi.c_hi, multi.f_lo, multi.f_hi)))
+dist.destroy_process_group()
+'''
+
+
+def _launch_ranks(tmp_path, world, backend):
+    import os
+    import socket
+    import subprocess
+    import sys
+    from .conftest import REPO
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "c2f_worker.py"
+    script.write_text(RANK_WORKER)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AHV_REPO=REPO, AHV_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0], outs
+    return outs[0]
+
+
+def test_configs4_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    """world = 2 (gloo rendezvous, both ranks on the one GPU of the test box; HIP kernels): the sharded two-stage
+    step with its three exchanges returns, on every rank, exactly what one rank scoring everything returns."""
+    out = _launch_ranks(tmp_path, 2, "gloo")
+    assert "world=2" in out and "graph=False" in out
+
+
+def test_configs4_rccl_collectives_captured_in_the_graph(tmp_path):
+    """A 1-rank RCCL group with the collectives forced: the whole step -- 2 scorer launches, compose, select AND
+    the three all-reduces -- is captured into ONE hipGraph and replayed (SURVEY 8(d) cfg 5); results equal the
+    eager single-rank step.  (Two RCCL ranks cannot share one GPU; the N-rank data path is the gloo test above.)"""
+    out = _launch_ranks(tmp_path, 1, "nccl")
+    assert "graph=True" in out
