@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libahv_hip.so")
 
 AHV_SCORE_RESET_BEST = 1
+AHV_SCORE_SPLIT_F16 = 2
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -25,11 +26,13 @@ _u32 = ctypes.c_uint
 SIGNATURES = {
     "ahv_abi_version": (_int, []),
     "ahv_last_error": (ctypes.c_char_p, []),
-    "ahv_set_option": (_int, [ctypes.c_char_p, _int]),
     "ahv_device_cu_count": (_int, []),
     "ahv_score_hypotheses_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32, _vp]),
+    "ahv_score_hypotheses_clocked_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32,
+                                                _vp, _vp]),
     "ahv_unpack_best": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ahv_rotate_volume_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
+    "ahv_rotate_volume_backward_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
     "ahv_forward_3d2d_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "ahv_score_features_f32": (_int, [_vp, _vp, _int, _i64, _vp, _vp]),
     "ahv_argmax_f32": (_int, [_vp, _int, _i64, _i64, _vp, _u32, _vp]),

@@ -6,9 +6,11 @@ with ``load_state_dict``.
 
 * ``forward_3d2d`` (per hypothesis, hot) runs the HIP kernel through the C ABI.
 * ``forward_2d3d`` (once per pair: conv embedding, sin/cos position code, the
-  bidirectional 3D-aware transformer of transformer/attention.py:196-396, 3-D res-block) is
-  issued with stock PyTorch-ROCm operators for now; its fused kernels are the next row of
-  SURVEY.md section 8(f).  It is pinned by the ``encoder_small`` golden fixture.
+  bidirectional 3D-aware transformer of transformer/attention.py:196-396, 3-D res-block) runs as ONE
+  C-ABI call (``ahv_forward_2d3d_f32``, csrc/ahv_encoder.hip) for inference calls on the GPU at the
+  reference's configuration (768 -> 256, 4 heads); training-style calls (autograd recording) and other widths
+  (the ``encoder_small`` fixture) use stock torch operators.  Pinned to the reference by the ``encoder_small``
+  (shrunken) and ``encoder_full`` (768/256/4x64/depth 4) golden fixtures.
 """
 from __future__ import annotations
 
@@ -22,39 +24,106 @@ import torch.nn.functional as F
 from . import ops
 
 
-# packed ahv_block_weights tables, kept outside the modules so that they are neither pickled nor deep-copied
+# packed weight tables for the C ABI, kept outside the modules so that they are neither pickled nor deep-copied
 _PACKED = weakref.WeakKeyDictionary()
-
 
 
 # ----------------------------------------------------------------------------- weight packing for the C ABI
 # These work on ANY module tree with the reference's attribute names (this file's mirror or the reference's
 # own Feature_Aligner / BidirectionTransformer), which is what lets patch.install() rebind forward_2d3d.
+#
+# A packed table mixes ALIASES of live parameters (already contiguous fp32: biases, LayerNorm, w_out, w_ff*) with
+# COPIES (q|k|v concatenation, tap-major conv weights, zero-padded 3-D conv weights).  In-place parameter updates
+# (optimizer.step(), harness.fit, GraphedTrainStep) change the aliases but not the copies, so every table carries
+# the version key of the parameters it was built from and is refreshed when that key differs: copies are
+# re-filled IN PLACE (their addresses -- which a captured hipGraph has baked in -- stay valid); only when a
+# parameter's storage itself moved does the table get new pointers (``moved``; graph owners then re-capture).
 def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _version_key(module):
+    return tuple((p._version, p.data_ptr()) for p in module.parameters())
+
+
+class _Packed:
+    __slots__ = ("table", "keep", "device", "key", "entries", "epoch")
+
+    def __init__(self, table, device):
+        self.table, self.device = table, device
+        self.keep, self.entries, self.key, self.epoch = [], [], None, 0
+
+    def put(self, setter, build):
+        """setter(ptr) stores the device pointer in the C struct; build() returns the fp32 tensor."""
+        t = build()
+        self.keep.append(t)
+        self.entries.append((setter, build))
+        setter(t.data_ptr())
+
+    def refresh(self):
+        """Re-evaluate every entry after a parameter change; returns True when any pointer changed."""
+        moved = False
+        for i, (setter, build) in enumerate(self.entries):
+            new, old = build(), self.keep[i]
+            if new.data_ptr() == old.data_ptr():
+                continue  # alias of a live parameter: already current
+            if new.shape == old.shape and not _is_alias(new):
+                old.copy_(new)  # a copy: refill in place, address unchanged
+            else:  # the parameter's own storage moved (.to(), .data = ...)
+                self.keep[i] = new
+                setter(new.data_ptr())
+                moved = True
+        if moved:
+            self.epoch += 1
+        return moved
+
+
+def _is_alias(t):
+    return getattr(t, "_ahv_alias", False)
+
+
+def _entry(param_fn, device):
+    """build() for one packed tensor: param_fn() gives the (possibly derived) tensor from the live parameters."""
+    def build():
+        src = param_fn()
+        out = _f32(src, device)
+        out._ahv_alias = out.data_ptr() == src.data_ptr()
+        return out
+    return build
+
+
+def _struct_setter(struct, name, index=None):
+    def set_(ptr):
+        if index is None:
+            setattr(struct, name, ptr)
+        else:
+            getattr(struct, name)[index] = ptr
+    return set_
 
 
 def pack_transformer(att, device):
     """ahv_block_weights table: per layer attn_self_1, attn_self_2, attn_cross_1, attn_cross_2; q|k|v weights
     concatenated to one [768][256] matrix (one GEMM for self-attention, row slices for cross-attention)."""
     from . import _lib
-    keep, table = [], (_lib.BlockWeights * (4 * len(att.transformer_blocks)))()
+    table = (_lib.BlockWeights * (4 * len(att.transformer_blocks)))()
+    pk = _Packed(table, device)
     i = 0
     for layer in att.transformer_blocks:
         for blk in (layer.attn_self_1, layer.attn_self_2, layer.attn_cross_1, layer.attn_cross_2):
             a, ff = blk.attn, blk.ff
-            tensors = dict(
-                w_qkv=torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dim=0),
-                w_out=a.to_out[0].weight, b_out=a.to_out[0].bias, ln1_g=blk.norm1.weight, ln1_b=blk.norm1.bias,
-                w_ff1=ff.net[0].proj.weight, b_ff1=ff.net[0].proj.bias, w_ff2=ff.net[2].weight,
-                b_ff2=ff.net[2].bias, ln2_g=blk.norm2.weight, ln2_b=blk.norm2.bias)
-            for name, t in tensors.items():
-                t = _f32(t, device)
-                keep.append(t)
-                setattr(table[i], name, t.data_ptr())
+            fns = dict(
+                w_qkv=lambda a=a: torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dim=0),
+                w_out=lambda a=a: a.to_out[0].weight, b_out=lambda a=a: a.to_out[0].bias,
+                ln1_g=lambda b=blk: b.norm1.weight, ln1_b=lambda b=blk: b.norm1.bias,
+                w_ff1=lambda f=ff: f.net[0].proj.weight, b_ff1=lambda f=ff: f.net[0].proj.bias,
+                w_ff2=lambda f=ff: f.net[2].weight, b_ff2=lambda f=ff: f.net[2].bias,
+                ln2_g=lambda b=blk: b.norm2.weight, ln2_b=lambda b=blk: b.norm2.bias)
+            for name, fn in fns.items():
+                pk.put(_struct_setter(table[i], name), _entry(fn, device))
             i += 1
-    _PACKED[att] = (table, keep, device)
-    return _PACKED[att]
+    pk.key = _version_key(att)
+    _PACKED[att] = pk
+    return pk
 
 
 def posemb_sincos_2d_tokens(channel: int, device, temperature: float = 10000.0) -> torch.Tensor:
@@ -67,41 +136,78 @@ def posemb_sincos_2d_tokens(channel: int, device, temperature: float = 10000.0) 
     return pe.reshape(channel, 64).t().contiguous()
 
 
+def _packed_transformer(att, device):
+    """Current table of `att` on `device` (built, refreshed or reused according to the version key)."""
+    pk = _PACKED.get(att)
+    if pk is None or pk.device != device:
+        return pack_transformer(att, device)
+    key = _version_key(att)
+    if key != pk.key:
+        pk.refresh()
+        pk.key = key
+    return pk
+
+
 def pack_aligner(fa, device):
     """ahv_aligner_weights (include/ahv.h): conv weights repacked tap-major, the 1x1x1 skip of the 3-D
     res-block folded into its first convolution as 16 extra output rows."""
     from . import _lib
-    blocks, keep_b, _ = pack_transformer(fa.att, device)
+    blocks = _packed_transformer(fa.att, device)
     rb2, rb3 = fa.feature_embedding[1], fa.feature_embedding_3d
-    dev0 = rb3.conv1.weight.device
-    w3d_1 = torch.zeros(32, 32, 32, dtype=torch.float32, device=dev0)  # [row][tap padded to 32][ci]
-    w3d_1[:16, :27] = rb3.conv1.weight.detach().permute(0, 2, 3, 4, 1).reshape(16, 27, 32)
-    w3d_1[16:, 13] = rb3.downsample[0].weight.detach().reshape(16, 32)  # centre tap (1,1,1) = 1*9 + 1*3 + 1
-    w3d_2 = torch.zeros(16, 32, 16, dtype=torch.float32, device=dev0)
-    w3d_2[:, :27] = rb3.conv2.weight.detach().permute(0, 2, 3, 4, 1).reshape(16, 27, 16)
-    tensors = dict(
-        w_emb=fa.feature_embedding[0].weight.reshape(256, 768),
-        w_conv1=rb2.conv1.weight.permute(0, 2, 3, 1).reshape(256, 2304),
-        w_conv2=rb2.conv2.weight.permute(0, 2, 3, 1).reshape(256, 2304),
-        posemb=posemb_sincos_2d_tokens(256, dev0), gn_g=fa.att.norm.weight, gn_b=fa.att.norm.bias,
-        w3d_1=w3d_1.reshape(32, 1024), w3d_2=w3d_2.reshape(16, 512))
-    pairs = dict(w_in=(fa.att.proj_in.weight.reshape(256, 256), fa.att.proj_context_in.weight.reshape(256, 256)),
-                 b_in=(fa.att.proj_in.bias, fa.att.proj_context_in.bias),
-                 w_out=(fa.att.proj_out.weight.reshape(256, 256), fa.att.proj_context_out.weight.reshape(256, 256)),
-                 b_out=(fa.att.proj_out.bias, fa.att.proj_context_out.bias))
-    aw, keep = _lib.AlignerWeights(), [keep_b]
-    for name, t in tensors.items():
-        t = _f32(t, device)
-        keep.append(t)
-        setattr(aw, name, t.data_ptr())
-    for name, (a, b) in pairs.items():
-        ta, tb = _f32(a, device), _f32(b, device)
-        keep += [ta, tb]
-        arr = getattr(aw, name)
-        arr[0], arr[1] = ta.data_ptr(), tb.data_ptr()
-    aw.blocks, aw.depth = blocks, len(fa.att.transformer_blocks)
-    _PACKED[fa] = (aw, keep, device)
-    return _PACKED[fa]
+
+    def w3d_1():
+        w = torch.zeros(32, 32, 32, dtype=torch.float32, device=rb3.conv1.weight.device)  # [row][tap padded to 32][ci]
+        w[:16, :27] = rb3.conv1.weight.detach().permute(0, 2, 3, 4, 1).reshape(16, 27, 32)
+        w[16:, 13] = rb3.downsample[0].weight.detach().reshape(16, 32)  # centre tap (1,1,1) = 1*9 + 1*3 + 1
+        return w.reshape(32, 1024)
+
+    def w3d_2():
+        w = torch.zeros(16, 32, 16, dtype=torch.float32, device=rb3.conv2.weight.device)
+        w[:, :27] = rb3.conv2.weight.detach().permute(0, 2, 3, 4, 1).reshape(16, 27, 16)
+        return w.reshape(16, 512)
+
+    posemb = posemb_sincos_2d_tokens(256, device)  # a constant, not a parameter
+    fns = dict(
+        w_emb=lambda: fa.feature_embedding[0].weight.reshape(256, 768),
+        w_conv1=lambda: rb2.conv1.weight.permute(0, 2, 3, 1).reshape(256, 2304),
+        w_conv2=lambda: rb2.conv2.weight.permute(0, 2, 3, 1).reshape(256, 2304),
+        posemb=lambda: posemb, gn_g=lambda: fa.att.norm.weight, gn_b=lambda: fa.att.norm.bias,
+        w3d_1=w3d_1, w3d_2=w3d_2)
+    pairs = dict(
+        w_in=(lambda: fa.att.proj_in.weight.reshape(256, 256), lambda: fa.att.proj_context_in.weight.reshape(256, 256)),
+        b_in=(lambda: fa.att.proj_in.bias, lambda: fa.att.proj_context_in.bias),
+        w_out=(lambda: fa.att.proj_out.weight.reshape(256, 256), lambda: fa.att.proj_context_out.weight.reshape(256, 256)),
+        b_out=(lambda: fa.att.proj_out.bias, lambda: fa.att.proj_context_out.bias))
+    aw = _lib.AlignerWeights()
+    pk = _Packed(aw, device)
+    for name, fn in fns.items():
+        pk.put(_struct_setter(aw, name), _entry(fn, device))
+    for name, (fa_, fb_) in pairs.items():
+        pk.put(_struct_setter(aw, name, 0), _entry(fa_, device))
+        pk.put(_struct_setter(aw, name, 1), _entry(fb_, device))
+    aw.blocks, aw.depth = blocks.table, len(fa.att.transformer_blocks)
+    pk.keep.append(blocks)  # keeps the block table (and its tensors) alive with this one
+    pk.key = _version_key(fa)
+    _PACKED[fa] = pk
+    return pk
+
+
+def _packed_aligner(fa, device):
+    pk = _PACKED.get(fa)
+    if pk is None or pk.device != device or _PACKED.get(fa.att) is not pk.keep[-1]:
+        return pack_aligner(fa, device)
+    key = _version_key(fa)
+    if key != pk.key:
+        _packed_transformer(fa.att, device)  # shares fa.att's parameters: refresh its table first
+        pk.refresh()
+        pk.key = key
+    return pk
+
+
+def packed_epoch(fa) -> int:
+    """Changes whenever a packed POINTER of `fa` changed (graph owners compare it and re-capture)."""
+    pk, pa = _PACKED.get(fa), _PACKED.get(getattr(fa, "att", None)) if hasattr(fa, "att") else None
+    return (pk.epoch if pk is not None else -1, pa.epoch if pa is not None else -1, id(pk), id(pa))
 
 
 @torch.no_grad()
@@ -109,9 +215,7 @@ def hip_forward_2d3d(fa, src, tgt):
     """forward_2d3d(random_mask=False) of `fa` (mirror or reference module) through ahv_forward_2d3d_f32."""
     import ctypes
     from . import _lib
-    packed = _PACKED.get(fa)
-    if packed is None or packed[2] != src.device or _PACKED.get(fa.att) is None:
-        packed = pack_aligner(fa, src.device)
+    packed = _packed_aligner(fa, src.device)
     B = src.shape[0]
     lib = _lib.load()
     nbytes = lib.ahv_forward_2d3d_workspace_bytes(B)
@@ -122,10 +226,11 @@ def hip_forward_2d3d(fa, src, tgt):
     # returned to the allocator at once and the NEXT temporary may land on the same block (strided batches, e.g. the
     # harness's feats[:, 0], then read the target's copy as the source)
     src_c, tgt_c = src.detach().contiguous(), tgt.detach().contiguous()
-    _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed[0]), src_c.data_ptr(),
-                                        tgt_c.data_ptr(), B, ws.data_ptr(), nbytes,
-                                        vol_src.data_ptr(), vol_tgt.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream), "ahv_forward_2d3d_f32")
+    with torch.cuda.device(src.device):  # the C side sizes grids from the current device; launch on ITS stream
+        _lib.check(lib.ahv_forward_2d3d_f32(ctypes.byref(packed.table), src_c.data_ptr(),
+                                            tgt_c.data_ptr(), B, ws.data_ptr(), nbytes,
+                                            vol_src.data_ptr(), vol_tgt.data_ptr(),
+                                            torch.cuda.current_stream(src.device).cuda_stream), "ahv_forward_2d3d_f32")
     return vol_src, vol_tgt
 
 
@@ -249,22 +354,21 @@ class BidirectionTransformer(nn.Module):
                 and self.n_heads == 4 and self.d_head == 64 and xs.shape[1] == 64 and not torch.is_grad_enabled())
 
     def _pack(self, device):
-        return pack_transformer(self, device)
+        return _packed_transformer(self, device)
 
     def _hip_blocks(self, xs, cs):
         from . import _lib
-        packed = _PACKED.get(self)
-        if packed is None or packed[2] != xs.device:
-            packed = self._pack(xs.device)
-        table = packed[0]
+        table = _packed_transformer(self, xs.device).table
         B = xs.shape[0]
         xs, cs = xs.contiguous().clone(), cs.contiguous().clone()  # the kernels update the streams in place
         lib = _lib.load()
         nbytes = lib.ahv_transformer_workspace_bytes(B)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=xs.device)
-        _lib.check(lib.ahv_transformer_blocks_f32(table, len(self.transformer_blocks), xs.data_ptr(), cs.data_ptr(), B,
-                                                  ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
-                   "ahv_transformer_blocks_f32")
+        with torch.cuda.device(xs.device):
+            _lib.check(lib.ahv_transformer_blocks_f32(table, len(self.transformer_blocks), xs.data_ptr(), cs.data_ptr(),
+                                                      B, ws.data_ptr(), nbytes,
+                                                      torch.cuda.current_stream(xs.device).cuda_stream),
+                       "ahv_transformer_blocks_f32")
         return xs, cs
 
     def forward(self, x, context):
@@ -383,7 +487,7 @@ class Feature_Aligner(nn.Module):
                 and self.att.n_heads == 4)
 
     def _pack_aligner(self, device):
-        return pack_aligner(self, device)
+        return _packed_aligner(self, device)
 
     def _hip_forward_2d3d(self, src, tgt):
         return hip_forward_2d3d(self, src, tgt)
@@ -419,9 +523,7 @@ class Feature_Aligner(nn.Module):
         if self.out_channel != 32:
             raise NotImplementedError("the HIP head is built for out_channel=32 (the reference's only value)")
         W1, W2, b2 = self.head_weights()
-        if torch.is_grad_enabled() and (img_feat.requires_grad or W1.requires_grad):
-            return ops.forward_3d2d_autograd(img_feat, W1, W2, b2)  # training: HIP forward + HIP backward
-        return ops.forward_3d2d(img_feat, W1, W2, b2)
+        return ops.forward_3d2d(img_feat, W1, W2, b2)  # carries an autograd edge (HIP backward) when one is needed
 
     # ---- once-per-pair encoder replayed from a hipGraph -------------------------------------------
     def graphed_forward_2d3d(self, batch: int = 1):
@@ -435,24 +537,37 @@ class Feature_Aligner(nn.Module):
             raise RuntimeError("graph capture needs the GPU")
         xs = torch.zeros(batch, self.in_channel, 8, 8, device=dev)
         xt = torch.zeros_like(xs)
-        with torch.no_grad():
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):  # warm-up: lazy library initialisation must not be captured
-                    self.forward_2d3d(xs, xt, random_mask=False, mask_ratio=0.0)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.forward_2d3d(xs, xt, random_mask=False, mask_ratio=0.0)
+        state = {}
+
+        def capture():
+            with torch.no_grad():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):  # warm-up: lazy library initialisation must not be captured
+                        self.forward_2d3d(xs, xt, random_mask=False, mask_ratio=0.0)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self.forward_2d3d(xs, xt, random_mask=False, mask_ratio=0.0)
+            state.update(graph=graph, out=out, epoch=packed_epoch(self))
+
+        capture()
 
         def run(layer4_src, layer4_tgt):
+            # Parameters updated in place since the capture (optimizer.step()): refill the packed copies at their
+            # captured addresses; parameters whose storage moved: capture again.
+            if self._hip_2d3d_eligible(xs):
+                _packed_aligner(self, dev)
+                if packed_epoch(self) != state["epoch"]:
+                    capture()
             xs.copy_(layer4_src)
             xt.copy_(layer4_tgt)
-            graph.replay()
-            return out
+            state["graph"].replay()
+            run.graph = state["graph"]
+            return state["out"]
 
-        run.graph = graph
+        run.graph = state["graph"]
         return run
 
     # ---- fused entry point (not in the reference: its call sites inline these three steps) ----

@@ -11,13 +11,19 @@ from __future__ import annotations
 import torch
 
 
-def read_state_dict(path: str, map_location="cpu") -> dict:
-    """Returns the flat ``state_dict`` of a Lightning ``.ckpt`` (or of a bare state-dict file)."""
+def read_state_dict(path: str, map_location="cpu", trusted: bool = False) -> dict:
+    """Returns the flat ``state_dict`` of a Lightning ``.ckpt`` (or of a bare state-dict file).
+
+    Loaded with ``weights_only=True`` (tensors and plain containers only).  Lightning checkpoints that pickle other
+    objects (hyper-parameters, callbacks) need the full unpickler, which can execute arbitrary code from the file:
+    that is an explicit opt-in, ``trusted=True``, for files whose origin you trust -- never a silent retry."""
     try:
-        blob = torch.load(path, map_location=map_location, weights_only=True)
-    except Exception:
-        # Lightning checkpoints pickle a few non-tensor objects (hyper-parameters, callbacks)
-        blob = torch.load(path, map_location=map_location, weights_only=False)
+        blob = torch.load(path, map_location=map_location, weights_only=not trusted)
+    except Exception as e:
+        if trusted:
+            raise
+        raise RuntimeError("%s could not be read with weights_only=True (%s: %s).  If the file comes from a source "
+                           "you trust, pass trusted=True to allow full unpickling." % (path, type(e).__name__, e)) from e
     if isinstance(blob, dict) and "state_dict" in blob:
         blob = blob["state_dict"]
     if not isinstance(blob, dict) or not all(isinstance(k, str) for k in blob):
@@ -30,9 +36,12 @@ def split_prefix(state_dict: dict, prefix: str) -> dict:
     return {k[len(p):]: v for k, v in state_dict.items() if k.startswith(p)}
 
 
-def load_into(model, state_dict: dict, strict: bool = True) -> None:
+def load_into(model, state_dict: dict, strict: bool = True, strict_backbone: bool = False) -> None:
     """Loads ``feature_aligner.*`` (always) and ``feature_extractor.*`` (when the model has a backbone
-    with matching keys).  ``strict`` applies to the aligner: it is the part this build owns."""
+    with matching keys).  ``strict`` applies to the aligner: it is the part this build owns.  A checkpoint that
+    carries backbone weights the model's backbone cannot take (different key set) is never skipped silently: it
+    warns -- the aligner would otherwise run on a randomly initialised backbone unnoticed -- or raises with
+    ``strict_backbone``."""
     aligner = split_prefix(state_dict, "feature_aligner")
     if not aligner:
         raise KeyError("checkpoint has no feature_aligner.* tensors")
@@ -40,9 +49,16 @@ def load_into(model, state_dict: dict, strict: bool = True) -> None:
     backbone = split_prefix(state_dict, "feature_extractor")
     fx = getattr(model, "feature_extractor", None)
     if backbone and fx is not None:
-        own = fx.state_dict()
+        own = fx.state_dict() if hasattr(fx, "state_dict") else {}
         if set(own) == set(backbone):
             fx.load_state_dict(backbone, strict=True)
+        else:
+            msg = ("checkpoint holds %d feature_extractor.* tensors that do not match the model's backbone (%d keys, "
+                   "%d in common): backbone weights NOT loaded" % (len(backbone), len(own), len(set(own) & set(backbone))))
+            if strict_backbone:
+                raise KeyError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
 
 
 def save_lightning_style(path: str, model, extra: dict | None = None) -> None:

@@ -10,10 +10,13 @@
 
 namespace ahv {
 hipError_t launch_score_hypotheses(const float*, const float*, const float*, int64_t, int64_t, const float*,
-                                   const float*, const float*, int, int64_t, float*, uint64_t*, int, hipStream_t);
+                                   const float*, const float*, int, int64_t, float*, uint64_t*, int, bool, uint64_t*,
+                                   hipStream_t);
 hipError_t launch_unpack_best(const uint64_t*, int, float*, int64_t*, hipStream_t);
 hipError_t launch_rotate_volume(const float*, int64_t, const float*, int64_t, int, int, int, int, float*, int,
                                 hipStream_t);
+hipError_t launch_rotate_volume_backward(const float*, int64_t, const float*, int64_t, int, int, int, int, float*, int,
+                                         hipStream_t);
 hipError_t launch_forward_3d2d(const float*, const float*, const float*, const float*, int64_t, float*, int,
                                hipStream_t);
 hipError_t launch_score_features(const float*, const float*, int, int64_t, float*, int, hipStream_t);
@@ -27,7 +30,6 @@ hipError_t launch_so3_grid(int64_t, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
                                  const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*,
                                  float*, float*, int, hipStream_t);
-extern int g_score_variant;
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
 size_t forward_2d3d_workspace_floats(int B);
@@ -77,17 +79,6 @@ int ahv_abi_version(void) { return (1 << 16) | 0; }
 
 const char* ahv_last_error(void) { return g_err; }
 
-int ahv_set_option(const char* name, int value)
-{
-    if (name && std::strcmp(name, "score_variant") == 0) {
-        if (value < 0 || value > 4) return fail(AHV_EINVAL, "set_option: score_variant must be 0..4");
-        const int prev = ahv::g_score_variant;
-        ahv::g_score_variant = value;
-        return prev;
-    }
-    return fail(AHV_EINVAL, "set_option: unknown option '%s'", name ? name : "(null)");
-}
-
 int ahv_device_cu_count(void)
 {
     const int cu = cu_count();
@@ -95,10 +86,9 @@ int ahv_device_cu_count(void)
     return cu;
 }
 
-int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
-                             int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2,
-                             const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
-                             unsigned flags, void* stream)
+static int score_common(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
+                        int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
+                        float* scores, uint64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream)
 {
     if (B < 0 || N < 0) return fail(AHV_EINVAL, "score: negative size (B=%d, N=%lld)", B, (long long)N);
     if (B > 0 && N > 0 && (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2))
@@ -107,7 +97,7 @@ int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const 
         return fail(AHV_EINVAL, "score: r_batch_stride %lld must be 0 or >= N*9", (long long)r_batch_stride);
     if (n_offset < 0 || n_offset + N > 4294967296ll)
         return fail(AHV_EINVAL, "score: n_offset + N must fit in 32 bits");
-    if (flags & ~AHV_SCORE_RESET_BEST) return fail(AHV_EINVAL, "score: unknown flags 0x%x", flags);
+    if (flags & ~(AHV_SCORE_RESET_BEST | AHV_SCORE_SPLIT_F16)) return fail(AHV_EINVAL, "score: unknown flags 0x%x", flags);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (best_key && (flags & AHV_SCORE_RESET_BEST) && B > 0) {
         hipError_t e = hipMemsetAsync(best_key, 0, sizeof(uint64_t) * (size_t)B, s);
@@ -117,9 +107,29 @@ int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const 
     const int cu = cu_count();
     if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
     hipError_t e = ahv::launch_score_hypotheses(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N,
-                                                scores, best_key, cu, s);
+                                                scores, best_key, cu, (flags & AHV_SCORE_SPLIT_F16) != 0,
+                                                clock_stamps, s);
     if (e != hipSuccess) return hip_fail("score: launch", e);
     return AHV_OK;
+}
+
+int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                             int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2,
+                             const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
+                             unsigned flags, void* stream)
+{
+    return score_common(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key, flags,
+                        nullptr, stream);
+}
+
+int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                                     int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2,
+                                     const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
+                                     unsigned flags, uint64_t* clock_stamps, void* stream)
+{
+    if (!clock_stamps) return fail(AHV_EINVAL, "score_clocked: null clock_stamps");
+    return score_common(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key, flags,
+                        clock_stamps, stream);
 }
 
 int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
@@ -145,6 +155,31 @@ int ahv_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, const floa
     hipError_t e = ahv::launch_rotate_volume(vol, vol_batch_stride, R, N, C, D, H, W, out, cu,
                                              static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("rotate_volume: launch", e);
+    return AHV_OK;
+}
+
+int ahv_rotate_volume_backward_f32(const float* grad_out, int64_t vol_batch_stride, const float* R, int64_t N, int C,
+                                   int D, int H, int W, float* grad_vol, void* stream)
+{
+    if (N < 0 || C < 1 || D < 1 || H < 1 || W < 1)
+        return fail(AHV_EINVAL, "rotate_volume_backward: bad shape N=%lld C=%d D=%d H=%d W=%d", (long long)N, C, D, H, W);
+    const int64_t vol_elems = (int64_t)C * D * H * W;
+    if (vol_batch_stride != 0 && vol_batch_stride < vol_elems)
+        return fail(AHV_EINVAL, "rotate_volume_backward: batch stride must be 0 or >= C*D*H*W");
+    if (!grad_vol) return fail(AHV_EINVAL, "rotate_volume_backward: null grad_vol");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n_vol = vol_batch_stride == 0 ? 1 : N;
+    if (n_vol > 0) {
+        const size_t bytes = sizeof(float) * (size_t)(vol_batch_stride == 0 ? vol_elems : (N - 1) * vol_batch_stride + vol_elems);
+        hipError_t e = hipMemsetAsync(grad_vol, 0, bytes, s);
+        if (e != hipSuccess) return hip_fail("rotate_volume_backward: hipMemsetAsync", e);
+    }
+    if (N == 0) return AHV_OK;
+    if (!grad_out || !R) return fail(AHV_EINVAL, "rotate_volume_backward: null pointer");
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    hipError_t e = ahv::launch_rotate_volume_backward(grad_out, vol_batch_stride, R, N, C, D, H, W, grad_vol, cu, s);
+    if (e != hipSuccess) return hip_fail("rotate_volume_backward: launch", e);
     return AHV_OK;
 }
 

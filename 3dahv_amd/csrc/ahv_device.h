@@ -362,4 +362,16 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
     return k;
 }
 
+// sum over the 64 lanes with DPP row operations (no LDS round trips); result valid in lane 63
+__device__ __forceinline__ float wave_sum_dpp(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));  // row_shr:1
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true));  // row_shr:2
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xE, true));  // row_shr:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xC, true));  // row_shr:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, true));  // row_bcast:15
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, true));  // row_bcast:31
+    return x;
+}
+
 }  // namespace ahv

@@ -106,6 +106,58 @@ __global__ __launch_bounds__(256) void rotate_volume_generic_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// Adjoint of rotate_volume w.r.t. the volume (the reference's rotate_volume is differentiable and
+// infoNCE_loss back-propagates through it, modules/model_co3d.py:49-54): every output voxel scatters
+// its gradient to the 8 trilinear corners it was blended from, with the forward's weights (zero for
+// corners outside the volume).  grad_vol is zeroed by the caller; sums use float atomics, so the
+// result is reproducible to rounding, not bitwise.  With vol_batch_stride = 0 (the stride-0 expand
+// the reference passes) all N hypotheses accumulate into ONE volume.  Compatibility path for
+// unmodified reference scripts; the training path proper is the fused backward (ahv_backward.hip).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rotate_volume_backward_kernel(
+    const float* __restrict__ grad_out, long vol_batch_stride, const float* __restrict__ R, long N, int C, int D,
+    int H, int W, float* __restrict__ grad_vol)
+{
+    const long plane = (long)D * H * W;
+    const long total = N * plane;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / plane;
+        const long v = i - n * plane;
+        const int w = (int)(v % W), h = (int)((v / W) % H), d = (int)(v / ((long)W * H));
+        const float* r = R + n * 9;
+        const float x = (2.0f * w + 1.0f) / (float)W - 1.0f;
+        const float y = (2.0f * h + 1.0f) / (float)H - 1.0f;
+        const float z = (2.0f * d + 1.0f) / (float)D - 1.0f;
+        const float gx = r[0] * x + r[1] * y + r[2] * z;
+        const float gy = r[3] * x + r[4] * y + r[5] * z;
+        const float gz = r[6] * x + r[7] * y + r[8] * z;
+        float wx[2], wy[2], wz[2];
+        long ox[2], oy[2], oz[2];
+        axis_generic(gx, W, wx[0], wx[1], ox[0], ox[1]);
+        axis_generic(gy, H, wy[0], wy[1], oy[0], oy[1]);
+        axis_generic(gz, D, wz[0], wz[1], oz[0], oz[1]);
+        float wgt[8];
+        long off[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+            wgt[k] = wz[dz] * wy[dy] * wx[dx];
+            off[k] = (oz[dz] * H + oy[dy]) * W + ox[dx];
+        }
+        float* dst = grad_vol + n * vol_batch_stride;
+        const float* g = grad_out + n * C * plane + v;
+        for (int c = 0; c < C; ++c) {
+            const float go = g[c * plane];
+            float* dc = dst + c * plane;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (wgt[k] != 0.0f)
+                    __hip_atomic_fetch_add(dc + off[k], wgt[k] * go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // forward_3d2d (modules/modules.py:112-124) on materialised volumes [M][16][8][8][8].
 // Same wave-per-item MFMA contraction as the fused scorer; the quarter buffers are
 // filled from HBM instead of by the trilinear gather.  32 KiB in + 8 KiB out per item.
@@ -537,6 +589,18 @@ hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, cons
         hipLaunchKernelGGL(rotate_volume_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, vol,
                            (long)vol_batch_stride, R, (long)N, C, D, H, W, out);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_rotate_volume_backward(const float* grad_out, int64_t vol_batch_stride, const float* R, int64_t N,
+                                         int C, int D, int H, int W, float* grad_vol, int num_cu, hipStream_t stream)
+{
+    const long total = (long)N * D * H * W;
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rotate_volume_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, grad_out,
+                       (long)vol_batch_stride, R, (long)N, C, D, H, W, grad_vol);
     return hipGetLastError();
 }
 

@@ -113,13 +113,16 @@ class _EstimatorBase(nn.Module):
         return scores, best, idx, proposals[idx]
 
     @classmethod
-    def load_from_checkpoint(cls, checkpoint_path, cfg=None, map_location="cpu", strict: bool = True, **kw):
+    def load_from_checkpoint(cls, checkpoint_path, cfg=None, map_location="cpu", strict: bool = True,
+                             trusted: bool = False, **kw):
         """Reads a Lightning ``.ckpt`` written by the reference (``state_dict`` with prefixes
-        ``feature_aligner.*`` / ``feature_extractor.*``).  ``cfg`` is required, as in test_co3d.py:218."""
+        ``feature_aligner.*`` / ``feature_extractor.*``).  ``cfg`` is required, as in test_co3d.py:218.
+        ``trusted=True`` allows full unpickling (Lightning files that carry non-tensor objects) -- only for files
+        whose origin you trust."""
         if cfg is None:
             raise TypeError("load_from_checkpoint() missing cfg (the reference passes cfg=cfg, test_co3d.py:218)")
         model = cls(cfg, **kw)
-        sd = _ckpt.read_state_dict(checkpoint_path, map_location=map_location)
+        sd = _ckpt.read_state_dict(checkpoint_path, map_location=map_location, trusted=trusted)
         _ckpt.load_into(model, sd, strict=strict)
         return model
 

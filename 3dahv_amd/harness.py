@@ -220,29 +220,75 @@ class SyntheticTrainingPairs:
                    "relative_rotation": random_rotations(self.batch_size, generator=g)[:, None]}
 
 
-def fit(cfg, model, loader: Iterable[dict], device=None, max_steps: Optional[int] = None, group=None):
-    """Plain-loop counterpart of ``trainer.fit(model, train_dataloader)`` (modules/model_co3d.py:141-145): per
-    batch ``training_step`` -> ``backward`` -> data-parallel gradient averaging (when a process group exists)
-    -> AdamW step; StepLR once per epoch (= one pass over ``loader``).  Returns the list of losses."""
-    from . import dist as adist
+class FitResult(list):
+    """The per-step losses of ``fit`` (a plain list) plus the training state to continue from."""
+    optimizer = None
+    scheduler = None
+    epoch = 0
+    global_step = 0
+
+
+def save_training_checkpoint(path: str, model, optimizer, scheduler, epoch: int, global_step: int) -> None:
+    """Lightning-shaped checkpoint: ``state_dict`` with the reference's prefixes (readable by ``checkpoint`` and by
+    the reference's ``load_from_checkpoint``) plus optimizer / scheduler state for ``fit(..., ckpt_path=)``."""
+    from . import checkpoint
+    checkpoint.save_lightning_style(path, model, extra={
+        "epoch": epoch, "global_step": global_step, "optimizer_states": [optimizer.state_dict()],
+        "lr_schedulers": [scheduler.state_dict()]})
+
+
+def fit(cfg, model, loader: Iterable[dict], device=None, max_steps: Optional[int] = None, group=None,
+        epochs: int = 1, optimizer=None, scheduler=None, ckpt_path: Optional[str] = None,
+        save_path: Optional[str] = None) -> FitResult:
+    """Plain-loop counterpart of ``trainer.fit(model, train_dataloader, ckpt_path=...)``
+    (modules/model_co3d.py:130-145; ``max_epochs`` = 250 in the reference): ONE AdamW and ONE StepLR for the whole
+    run (``configure_optimizers``, or the pair passed in to continue a run); per batch ``training_step`` ->
+    ``backward`` -> data-parallel gradient averaging (when a process group exists) -> optimizer step; the
+    scheduler steps once per epoch (= one pass over ``loader``).  ``ckpt_path``: resume model, optimizer,
+    scheduler and epoch counter from a checkpoint written by ``save_path`` (skipped when the file does not
+    exist, like the reference's ``os.path.exists`` guard); ``save_path``: written after every epoch.
+    ``max_steps`` bounds the total number of optimizer steps.  Returns the losses (``FitResult``: a list with
+    ``.optimizer``, ``.scheduler``, ``.epoch``, ``.global_step``)."""
     if device is None:
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    (opt,), (sched,) = model.configure_optimizers()
+    if optimizer is None:
+        (optimizer,), (sched_new,) = model.configure_optimizers()
+        scheduler = sched_new if scheduler is None else scheduler
+    elif scheduler is None:
+        raise ValueError("pass the scheduler that belongs to the optimizer (or neither)")
+    start_epoch, global_step = 0, 0
+    if ckpt_path is not None and os.path.exists(ckpt_path):
+        from . import checkpoint
+        blob = torch.load(ckpt_path, map_location="cpu", weights_only=True)  # tensors and plain containers only
+        checkpoint.load_into(model, blob["state_dict"])
+        optimizer.load_state_dict(blob["optimizer_states"][0])
+        scheduler.load_state_dict(blob["lr_schedulers"][0])
+        start_epoch, global_step = int(blob["epoch"]), int(blob["global_step"])
     model.train()
-    losses = []
+    out = FitResult()
     # The encoder's skinny fp32 GEMMs (M = 64*B rows) run ~25 % faster through rocBLAS than through hipBLASLt's
     # default picks on gfx950 (18.6 vs 24.3 ms per encoder forward+backward at B = 12): prefer it while training.
     prev_blas = None
     if torch.device(device).type == "cuda" and hasattr(torch.backends.cuda, "preferred_blas_library"):
         prev_blas = torch.backends.cuda.preferred_blas_library()
         torch.backends.cuda.preferred_blas_library("cublas")  # = rocBLAS on ROCm
+    epoch = start_epoch
     try:
-        losses = _fit_loop(model, loader, opt, device, max_steps, group)
+        for epoch in range(start_epoch, start_epoch + epochs):
+            left = None if max_steps is None else max_steps - len(out)
+            if left is not None and left <= 0:
+                break
+            out.extend(_fit_loop(model, loader, optimizer, device, left, group))
+            scheduler.step()
+            if save_path is not None:
+                save_training_checkpoint(save_path, model, optimizer, scheduler, epoch + 1, global_step + len(out))
+        else:
+            epoch = start_epoch + epochs
     finally:
         if prev_blas is not None:
             torch.backends.cuda.preferred_blas_library(prev_blas)
-    sched.step()
-    return losses
+    out.optimizer, out.scheduler, out.epoch, out.global_step = optimizer, scheduler, epoch, global_step + len(out)
+    return out
 
 
 def _fit_loop(model, loader, opt, device, max_steps, group):
@@ -271,11 +317,26 @@ class GraphedTrainStep:
     0 + fresh Haar samples, modules/model_co3d.py:84-86) is written into a fixed ``(B, num_rota, 3, 3)`` buffer
     just before each replay.  ``random_masking`` draws from torch's graph-safe Philox state, so every replay masks
     differently.  The learning rate is a device scalar (``set_lr``) because a captured AdamW cannot see Python
-    floats change."""
+    floats change.
 
-    def __init__(self, model, batch_size: int, image_size: int = 256, device=None, warmup: int = 3):
-        from . import ops
+    The warm-up iterations that must precede a capture (lazy initialisation of libraries and of the optimizer
+    state) run on placeholder data; parameters, buffers and the optimizer state (moments, step counts) are put
+    back IN PLACE afterwards, so the first replay starts from exactly the model and the fresh AdamW it was given.
+    With a process group of more than one rank the bucketed gradient all-reduce (``dist.all_reduce_gradients``)
+    is captured between backward and the optimizer step -- RCCL collectives are stream operations; a backend that
+    cannot be captured (gloo) is refused instead of silently training diverging replicas."""
+
+    def __init__(self, model, batch_size: int, image_size: int = 256, device=None, warmup: int = 3, group=None):
+        from . import dist as adist, ops
+        import torch.distributed as tdist
         self.model, self.ops = model, ops
+        self.group = group
+        self.world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
+        if self.world > 1 and tdist.get_backend(group) != "nccl":
+            raise RuntimeError("GraphedTrainStep with %d ranks needs the nccl (RCCL) backend: %s collectives cannot be "
+                               "captured in a hipGraph; use harness.fit" % (self.world, tdist.get_backend(group)))
+        self._all_reduce = (lambda: adist.all_reduce_gradients(model.parameters(), group=group)) if self.world > 1 \
+            else (lambda: None)
         dev = torch.device(device if device is not None else "cuda")
         self.images = torch.zeros(batch_size, 2, 3, image_size, image_size, device=dev)
         self.gt = torch.eye(3, device=dev).repeat(batch_size, 1, 1)
@@ -290,6 +351,9 @@ class GraphedTrainStep:
         prev_blas = torch.backends.cuda.preferred_blas_library()
         torch.backends.cuda.preferred_blas_library("cublas")  # rocBLAS: see fit()
         try:
+            # what the placeholder warm-up must not leave behind
+            saved = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
+            rng = torch.cuda.get_rng_state(dev)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -297,13 +361,25 @@ class GraphedTrainStep:
                     self._fill_rotations()
                     self.optimizer.zero_grad(set_to_none=True)
                     self._loss().backward()
+                    self._all_reduce()
                     self.optimizer.step()
+                with torch.no_grad():
+                    for t, s0 in zip(list(model.parameters()) + list(model.buffers()), saved):
+                        t.copy_(s0)
+                    for st in self.optimizer.state.values():  # fresh AdamW: zero moments and step counts, in place
+                        for v in st.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
             torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.set_rng_state(rng, dev)
+            self._draws = 0
+            del saved
             self.graph = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(self.graph):
                 self.loss = self._loss()
                 self.loss.backward()
+                self._all_reduce()
                 self.optimizer.step()
         finally:
             torch.backends.cuda.preferred_blas_library(prev_blas)

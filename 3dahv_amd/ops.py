@@ -14,6 +14,8 @@ to torch's current stream.  The plain ops carry no autograd graph; the ``*_autog
 """
 from __future__ import annotations
 
+import contextvars
+
 import torch
 
 from . import _lib
@@ -21,27 +23,43 @@ from . import _lib
 _VOL = (16, 8, 8, 8)
 
 
-class score_variant:
-    """Select the fused-scorer kernel: ``ops.score_variant(4)`` as a statement switches for the process,
-    ``with ops.score_variant(4): ...`` for a block.  3 = all-fp32 (default); 4 = GEMM1 as split-f16 MFMA
-    products with fp32 accumulation (1.85x faster, scores as close to the fp64 truth as the fp32 kernel's --
-    DESIGN.md section 4.1); 0-2 = earlier fp32 kernels kept for A/B runs."""
+_SPLIT_F16 = contextvars.ContextVar("ahv_split_f16", default=False)
 
-    def __init__(self, variant: int):
-        self.prev = _lib.load().ahv_set_option(b"score_variant", int(variant))
-        if self.prev < 0:
-            _lib.check(self.prev, "ahv_set_option")
+
+class split_f16_scorer:
+    """``with ops.split_f16_scorer(): ...`` -- inside the block (this thread / context only) ``score_hypotheses``
+    passes ``AHV_SCORE_SPLIT_F16``: GEMM1 as split-f16 MFMA products with fp32 accumulation (1.8x faster, scores as
+    close to the fp64 truth as the fp32 kernel's -- DESIGN.md section 4.1).  Opt-in; the default is the all-fp32
+    kernel.  The choice travels with each call as a flag bit: the library keeps no process-wide selector, so
+    concurrent threads / streams cannot disturb each other.  ``score_hypotheses(..., split_f16=True)`` selects
+    it for one call."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+        self._token = None
 
     def __enter__(self):
+        self._token = _SPLIT_F16.set(self.enabled)
         return self
 
     def __exit__(self, *exc):
-        _lib.load().ahv_set_option(b"score_variant", self.prev)
+        _SPLIT_F16.reset(self._token)
         return False
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(dev=None) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _call(dev: torch.device, name: str, *args) -> None:
+    """Run entry point ``name`` with ``dev`` as the current HIP device (the C side sizes its grids from
+    hipGetDevice) on torch's current stream OF THAT DEVICE, so that tensors on cuda:1 are never processed on
+    cuda:0's stream while cuda:0 happens to be current.  The stream is the last argument of every entry point."""
+    lib = _lib.load()
+    if dev.type != "cuda":
+        raise RuntimeError("3dahv_amd ops run on the GPU only (no CPU fallback); got a tensor on %s" % dev)
+    with torch.cuda.device(dev):
+        _lib.check(getattr(lib, name)(*args, torch.cuda.current_stream(dev).cuda_stream), name)
 
 
 def _need_gpu(*tensors: torch.Tensor) -> torch.device:
@@ -57,19 +75,39 @@ def _need_gpu(*tensors: torch.Tensor) -> torch.device:
     return dev
 
 
+def _refuse_grad(name: str, *tensors: torch.Tensor) -> None:
+    """Ops without an autograd edge must not swallow a gradient silently."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError("%s has no autograd edge: call it under torch.no_grad() / on detached tensors, or use "
+                           "score_hypotheses_autograd / rotate_volume / forward_3d2d, which are differentiable" % name)
+
+
 def _head(W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor):
     if W1.numel() != 32 * 384 or W2.numel() != 32 * 32 or b2.numel() != 32:
         raise RuntimeError("head weights must be (32,384[,1,1]), (32,32[,1,1]), (32,)")
     return W1.detach().reshape(32, 384).contiguous(), W2.detach().reshape(32, 32).contiguous(), b2.detach().contiguous()
 
 
-@torch.no_grad()
 def rotate_volume(volume: torch.Tensor, rotation_matrix: torch.Tensor, padding_mode: str = "zeros") -> torch.Tensor:
     """Rotate ``volume (N,C,D,H,W)`` by ``rotation_matrix (N,3,3)``; returns a new contiguous tensor.
 
     The batch dimension of ``volume`` may be a stride-0 expand of one volume (what the
-    reference passes): it is read once, never materialised.
+    reference passes): it is read once, never materialised.  Differentiable w.r.t. ``volume`` like the
+    reference's (utils.py:113-131; infoNCE_loss back-propagates through it, modules/model_co3d.py:49-54): when
+    autograd is recording and ``volume`` requires grad the call goes through ``_RotateVolumeFn`` (HIP forward, HIP
+    adjoint).  A rotation matrix that requires grad is refused loudly (the reference samples its rotations).
     """
+    if torch.is_grad_enabled():
+        if rotation_matrix.requires_grad:
+            raise NotImplementedError("rotate_volume: no gradient w.r.t. rotation_matrix is implemented (the "
+                                      "reference samples its rotations); detach it")
+        if volume.requires_grad:
+            return _RotateVolumeFn.apply(volume, rotation_matrix)
+    return _rotate_volume_nograd(volume, rotation_matrix, padding_mode)
+
+
+@torch.no_grad()
+def _rotate_volume_nograd(volume: torch.Tensor, rotation_matrix: torch.Tensor, padding_mode: str = "zeros") -> torch.Tensor:
     if padding_mode != "zeros":
         raise NotImplementedError("only padding_mode='zeros' (the only mode the reference uses) is implemented")
     if volume.dim() != 5:
@@ -89,15 +127,21 @@ def rotate_volume(volume: torch.Tensor, rotation_matrix: torch.Tensor, padding_m
         stride = C * D * H * W
     R = rotation_matrix.detach().contiguous()
     out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=volume.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_rotate_volume_f32(src.data_ptr(), stride, R.data_ptr(), N, C, D, H, W, out.data_ptr(),
-                                         _stream()), "ahv_rotate_volume_f32")
+    _call(out.device, "ahv_rotate_volume_f32", src.data_ptr(), stride, R.data_ptr(), N, C, D, H, W, out.data_ptr())
     return out
 
 
-@torch.no_grad()
 def forward_3d2d(img_feat: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
-    """``(M,16,8,8,8) -> (M,32,64)``: slabs -> conv1x1 -> ReLU -> conv1x1+bias -> L2-normalise."""
+    """``(M,16,8,8,8) -> (M,32,64)``: slabs -> conv1x1 -> ReLU -> conv1x1+bias -> L2-normalise.
+    When autograd is recording and an input requires grad, the call carries an autograd edge (HIP backward,
+    ``_Forward3d2dFn``) -- it never silently drops a gradient."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (img_feat, W1, W2, b2)):
+        return _Forward3d2dFn.apply(img_feat, W1, W2, b2)
+    return _forward_3d2d_nograd(img_feat, W1, W2, b2)
+
+
+@torch.no_grad()
+def _forward_3d2d_nograd(img_feat: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
     if img_feat.dim() != 5 or tuple(img_feat.shape[1:]) != _VOL:
         raise RuntimeError("img_feat must be (M,16,8,8,8), got %s" % (tuple(img_feat.shape),))
     _need_gpu(img_feat, W1, W2, b2)
@@ -105,24 +149,21 @@ def forward_3d2d(img_feat: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, b2:
     x = img_feat.detach().contiguous()
     M = x.shape[0]
     out = torch.empty((M, 32, 64), dtype=torch.float32, device=x.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_forward_3d2d_f32(x.data_ptr(), W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), M,
-                                        out.data_ptr(), _stream()), "ahv_forward_3d2d_f32")
+    _call(out.device, "ahv_forward_3d2d_f32", x.data_ptr(), W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), M,
+          out.data_ptr())
     return out
 
 
-@torch.no_grad()
 def score_features(f_src: torch.Tensor, f_tgt: torch.Tensor) -> torch.Tensor:
-    """``(f_src * f_tgt[:, None]).sum(dim=2).mean(dim=-1)``: (B,N,32,64),(B,32,64) -> (B,N)."""
+    """``(f_src * f_tgt[:, None]).sum(dim=2).mean(dim=-1)``: (B,N,32,64),(B,32,64) -> (B,N).  Inference only."""
+    _refuse_grad("score_features", f_src, f_tgt)
     if f_src.dim() != 4 or tuple(f_src.shape[2:]) != (32, 64) or tuple(f_tgt.shape) != (f_src.shape[0], 32, 64):
         raise RuntimeError("expected f_src (B,N,32,64) and f_tgt (B,32,64)")
     _need_gpu(f_src, f_tgt)
     B, N = f_src.shape[:2]
     a, t = f_src.detach().contiguous(), f_tgt.detach().contiguous()
     out = torch.empty((B, N), dtype=torch.float32, device=a.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_score_features_f32(a.data_ptr(), t.data_ptr(), B, N, out.data_ptr(), _stream()),
-               "ahv_score_features_f32")
+    _call(out.device, "ahv_score_features_f32", a.data_ptr(), t.data_ptr(), B, N, out.data_ptr())
     return out
 
 
@@ -132,9 +173,7 @@ def unpack_best(best_key: torch.Tensor):
     B = best_key.numel()
     score = torch.empty((B,), dtype=torch.float32, device=best_key.device)
     idx = torch.empty((B,), dtype=torch.int64, device=best_key.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_unpack_best(best_key.data_ptr(), B, score.data_ptr(), idx.data_ptr(), _stream()),
-               "ahv_unpack_best")
+    _call(best_key.device, "ahv_unpack_best", best_key.data_ptr(), B, score.data_ptr(), idx.data_ptr())
     return score, idx
 
 
@@ -149,18 +188,16 @@ def argmax(scores: torch.Tensor, n_offset: int = 0, return_key: bool = False):
         raise RuntimeError("max(): Expected reduction dim 1 to have non-zero size.")
     s = scores.detach().contiguous()
     key = torch.empty((B,), dtype=torch.int64, device=s.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_argmax_f32(s.data_ptr(), B, N, n_offset, key.data_ptr(), _lib.AHV_SCORE_RESET_BEST,
-                                  _stream()), "ahv_argmax_f32")
+    _call(key.device, "ahv_argmax_f32", s.data_ptr(), B, N, n_offset, key.data_ptr(), _lib.AHV_SCORE_RESET_BEST)
     if return_key:
         return key
     return unpack_best(key)
 
 
-@torch.no_grad()
 def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
                      W2: torch.Tensor, b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True,
-                     best_key: torch.Tensor | None = None, reset_best: bool | None = None):
+                     best_key: torch.Tensor | None = None, reset_best: bool | None = None,
+                     split_f16: bool | None = None, clock_stamps: torch.Tensor | None = None):
     """Fused hot loop (one launch): returns ``(scores (B,N) or None, best_key (B,) int64)``.
 
     vol_src (B,16,8,8,8); feat_tgt (B,32,64) = forward_3d2d(vol_tgt); R (N,3,3) shared by the
@@ -168,7 +205,21 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
     given: merge into it (chunked / multi-call N) unless ``reset_best``; else a fresh key tensor
     is reset and returned.
     Decode with ``unpack_best``; ``n_offset`` is the global index of R[0] when N is sharded.
+    ``split_f16``: opt-in kernel for this call (None: the enclosing ``split_f16_scorer`` block, else fp32).
+    ``clock_stamps`` (int64, 4 * CU count, zeroed): diagnostic launch that also records the shader clock.
+    With autograd recording and an input that requires grad, the returned scores carry the autograd edge of
+    ``score_hypotheses_autograd`` (HIP backward) -- like the reference's op sequence, nothing is silently detached.
     """
+    if (want_scores and clock_stamps is None and torch.is_grad_enabled()
+            and any(t.requires_grad for t in (vol_src, feat_tgt, W1, W2, b2))):
+        return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2, n_offset, best_key, reset_best, split_f16)
+    with torch.no_grad():
+        return _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best,
+                                        split_f16, clock_stamps)
+
+
+def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best, split_f16,
+                             clock_stamps):
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
         raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
     B = vol_src.shape[0]
@@ -190,11 +241,20 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
     elif best_key.dtype != torch.int64 or best_key.numel() != B or not best_key.is_cuda:
         raise RuntimeError("best_key must be a GPU int64 tensor of B elements")
     flags = _lib.AHV_SCORE_RESET_BEST if reset_best else 0
+    if _SPLIT_F16.get() if split_f16 is None else split_f16:
+        flags |= _lib.AHV_SCORE_SPLIT_F16
     lib = _lib.load()
-    _lib.check(lib.ahv_score_hypotheses_f32(vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset,
-                                            W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), B, N,
-                                            scores.data_ptr() if scores is not None else None,
-                                            best_key.data_ptr(), flags, _stream()), "ahv_score_hypotheses_f32")
+    args = (vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset, W1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+            B, N, scores.data_ptr() if scores is not None else None, best_key.data_ptr(), flags)
+    with torch.cuda.device(dev):
+        if clock_stamps is None:
+            _lib.check(lib.ahv_score_hypotheses_f32(*args, _stream(dev)), "ahv_score_hypotheses_f32")
+        else:
+            if clock_stamps.dtype != torch.int64 or clock_stamps.device != dev or \
+                    clock_stamps.numel() < 4 * lib.ahv_device_cu_count():
+                raise RuntimeError("clock_stamps must be an int64 tensor of 4 * CU-count elements on %s" % dev)
+            _lib.check(lib.ahv_score_hypotheses_clocked_f32(*args, clock_stamps.data_ptr(), _stream(dev)),
+                       "ahv_score_hypotheses_clocked_f32")
     return scores, best_key
 
 
@@ -222,34 +282,69 @@ def score_hypotheses_backward(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: 
     g_W1 = torch.empty((32, 384), dtype=torch.float32, device=dev)
     g_W2 = torch.empty((32, 32), dtype=torch.float32, device=dev)
     g_b2 = torch.empty((32,), dtype=torch.float32, device=dev)
-    _lib.check(lib.ahv_score_hypotheses_backward_f32(vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride,
-                                                     W1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), B, N,
-                                                     gs.data_ptr(), ws.data_ptr(), ws.numel() * 4, g_vol.data_ptr(),
-                                                     g_ft.data_ptr(), g_W1.data_ptr(), g_W2.data_ptr(),
-                                                     g_b2.data_ptr(), _stream()),
-               "ahv_score_hypotheses_backward_f32")
+    _call(dev, "ahv_score_hypotheses_backward_f32", vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride,
+          W1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), B, N, gs.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+          g_vol.data_ptr(), g_ft.data_ptr(), g_W1.data_ptr(), g_W2.data_ptr(), g_b2.data_ptr())
     return g_vol, g_ft, g_W1, g_W2, g_b2
+
+
+class _RotateVolumeFn(torch.autograd.Function):
+    """Differentiable ``rotate_volume`` (w.r.t. the volume): HIP gather forward, HIP scatter adjoint.  A stride-0
+    batch (``v[None].expand(N, ...)``) is read once in the forward; its gradient is accumulated into ONE volume on
+    the device.  Autograd's expand-backward then sums the N rows of what this function returns, so row 0 carries
+    that volume and the other rows are zero (exact; no division by N)."""
+
+    @staticmethod
+    def forward(ctx, volume, rotation_matrix):
+        out = _rotate_volume_nograd(volume, rotation_matrix)
+        N = volume.shape[0]
+        ctx.shared = bool(N > 1 and volume.stride(0) == 0 and volume[0].is_contiguous())
+        ctx.vshape = tuple(volume.shape)
+        ctx.save_for_backward(rotation_matrix.detach().contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (R,) = ctx.saved_tensors
+        N, C, D, H, W = ctx.vshape
+        g = grad_out.contiguous()
+        dev = g.device
+        if ctx.shared:
+            gv = torch.empty((1, C, D, H, W), dtype=torch.float32, device=dev)
+            _call(dev, "ahv_rotate_volume_backward_f32", g.data_ptr(), 0, R.data_ptr(), N, C, D, H, W, gv.data_ptr())
+            # the expand's backward sums over the batch: put the whole sum in row 0
+            full = torch.zeros((N, C, D, H, W), dtype=torch.float32, device=dev)
+            full[0] = gv[0]
+            return full, None
+        gv = torch.empty((N, C, D, H, W), dtype=torch.float32, device=dev)
+        _call(dev, "ahv_rotate_volume_backward_f32", g.data_ptr(), C * D * H * W, R.data_ptr(), N, C, D, H, W,
+              gv.data_ptr())
+        return gv, None
 
 
 class _ScoreFn(torch.autograd.Function):
     """Differentiable fused scorer: forward = one fused launch, backward = ``score_hypotheses_backward``."""
 
     @staticmethod
-    def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2):
-        scores, _ = score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2)
+    def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2, n_offset=0, best_key=None, reset_best=None, split_f16=None):
+        scores, key = _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, True, best_key, reset_best,
+                                               split_f16, None)
         ctx.save_for_backward(vol_src, feat_tgt, R, W1, W2, b2)
-        return scores
+        ctx.mark_non_differentiable(key)
+        return scores, key
 
     @staticmethod
-    def backward(ctx, grad_scores):
+    def backward(ctx, grad_scores, _grad_key):
         vol_src, feat_tgt, R, W1, W2, b2 = ctx.saved_tensors
-        g_vol, g_ft, g_W1, g_W2, g_b2 = score_hypotheses_backward(vol_src, feat_tgt, R, W1, W2, b2, grad_scores)
-        return g_vol, g_ft, None, g_W1.reshape(W1.shape), g_W2.reshape(W2.shape), g_b2.reshape(b2.shape)
+        g_vol, g_ft, g_W1, g_W2, g_b2 = score_hypotheses_backward(vol_src, feat_tgt, R, W1, W2, b2,
+                                                                  grad_scores.contiguous())
+        return (g_vol, g_ft, None, g_W1.reshape(W1.shape), g_W2.reshape(W2.shape), g_b2.reshape(b2.shape),
+                None, None, None, None)
 
 
 def score_hypotheses_autograd(vol_src, feat_tgt, R, W1, W2, b2) -> torch.Tensor:
     """``scores (B,N)`` with autograd support for vol_src, feat_tgt and the head weights (training path)."""
-    return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2)
+    return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2)[0]
 
 
 class _Forward3d2dFn(torch.autograd.Function):
@@ -261,7 +356,7 @@ class _Forward3d2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, W1, W2, b2):
         ctx.save_for_backward(vol, W1, W2, b2)
-        return forward_3d2d(vol, W1, W2, b2)
+        return _forward_3d2d_nograd(vol, W1, W2, b2)
 
     @staticmethod
     def backward(ctx, dF):
@@ -298,10 +393,8 @@ def select_rotation(best_key: torch.Tensor, R: torch.Tensor, n_offset: int = 0):
     score = torch.empty((B,), dtype=torch.float32, device=dev)
     idx = torch.empty((B,), dtype=torch.int64, device=dev)
     R_out = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
-    lib = _lib.load()
-    _lib.check(lib.ahv_select_rotation_f32(best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, B,
-                                           R_out.data_ptr(), score.data_ptr(), idx.data_ptr(), _stream()),
-               "ahv_select_rotation_f32")
+    _call(dev, "ahv_select_rotation_f32", best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, B,
+          R_out.data_ptr(), score.data_ptr(), idx.data_ptr())
     return score, idx, R_out
 
 
@@ -319,9 +412,8 @@ def compose_rotations(best_key: torch.Tensor, R: torch.Tensor, D: torch.Tensor, 
     Rc, Dc = R.detach().contiguous(), D.detach().contiguous()
     if out is None:
         out = torch.empty((B, N2, 3, 3), dtype=torch.float32, device=Rc.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_compose_rotations_f32(best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, Dc.data_ptr(),
-                                             N2, B, out.data_ptr(), _stream()), "ahv_compose_rotations_f32")
+    _call(out.device, "ahv_compose_rotations_f32", best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N,
+          Dc.data_ptr(), N2, B, out.data_ptr())
     return out
 
 
@@ -333,8 +425,7 @@ def so3_grid(n_total: int, device, offset: int = 0, n: int | None = None) -> tor
     out = torch.empty((n, 3, 3), dtype=torch.float32, device=device)
     if out.device.type != "cuda":
         raise RuntimeError("3dahv_amd ops run on the GPU only (no CPU fallback); got device %s" % out.device)
-    lib = _lib.load()
-    _lib.check(lib.ahv_so3_grid_f32(n_total, offset, n, out.data_ptr(), _stream()), "ahv_so3_grid_f32")
+    _call(out.device, "ahv_so3_grid_f32", n_total, offset, n, out.data_ptr())
     return out
 
 
@@ -347,7 +438,5 @@ def random_rotations(n: int, seed: int = 0, offset: int = 0, device=None, out: t
         out = torch.empty((n, 3, 3), dtype=torch.float32, device=device if device is not None else "cuda")
     if not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * 9:
         raise RuntimeError("out must be a contiguous float32 GPU tensor of n*9 elements")
-    lib = _lib.load()
-    _lib.check(lib.ahv_random_rotations_f32(seed & (2**64 - 1), offset, n, out.data_ptr(), _stream()),
-               "ahv_random_rotations_f32")
+    _call(out.device, "ahv_random_rotations_f32", seed & (2**64 - 1), offset, n, out.data_ptr())
     return out

@@ -10,6 +10,12 @@ pair with N_hyp = 50 000 hypotheses on each GPU (BASELINE.json configs[1]):
 Inputs are resident in HBM before the timed region.  N > 1 shards the hypothesis axis: every
 rank scores its own 50 000 (weak scaling), the only exchange is the 8-byte key all-reduce.
 
+Launching: `python3 bench.py --gpus N` starts its own N worker processes (one per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE anything touches a GPU and relays rank 0's JSON
+line; under an external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`,
+which sets RANK / WORLD_SIZE) the process is a worker itself.  `--backend gloo` lets more ranks than GPUs
+share the visible device(s): a rehearsal of the multi-rank logic on a 1-GPU box, never a measurement.
+
 Prints ONE JSON line on rank 0 (see the task contract), with `roofline` for the fused kernel
 (fp32 MFMA bound) and `cpu_baseline` (the reference's torch-CPU op sequence on the host cores).
 """
@@ -17,23 +23,82 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 N_HYP = 50_000
 FLOPS_PER_HYP = 1_839_104      # trilinear 131072 + GEMM1 1572864 + GEMM2 131072 + dot 4096
-HBM_BYTES_PER_HYP = 40         # 36 B of R in + 4 B of score out (fused kernel)
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_BYTES_PER_HYP = 36         # the timed launch keeps only the arg-max (want_scores=False): 36 B of R in
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (at the 2.4 GHz maximum clock)
+MAX_CLOCK_GHZ = 2.4
+TRAFFIC_JSON = os.path.join("profiles", "traffic.json")
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-f16", action="store_true",
+                    help="time the opt-in split-f16 kernel (AHV_SCORE_SPLIT_F16) instead of the all-fp32 default; "
+                         "by default it is only reported beside the fp32 headline")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank logic on a box with fewer GPUs than ranks)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ parent
+def launch_workers(args) -> int:
+    """Spawn one fresh worker process per rank (this process has not touched a GPU and never will), relay rank 0's
+    stdout (the JSON line), pass stderr through, return the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AHV_BENCH_WORKER="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    import threading
+    box = {}
+    reader = threading.Thread(target=lambda: box.update(out=procs[0].stdout.read().decode()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    try:
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes):  # a rank failed: the others would wait in a collective forever
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:  # exact PIDs we started, only if still alive
+            if p.poll() is None:
+                p.kill()
+        codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = box.get("out", "")
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    return bad[0] if bad else 0
+
+
+# ------------------------------------------------------------------------------------------------ worker
 def synth_inputs(ahv, dev, rank):
     """SURVEY.md 8(d) cfg 2: vol ~ N(0, 1.15^2); torch-default conv init for the head; Haar R."""
+    import numpy as np
+    import torch
     g = torch.Generator().manual_seed(0)
     vol_src = torch.randn(1, 16, 8, 8, 8, generator=g) * 1.15
     vol_tgt = torch.randn(1, 16, 8, 8, 8, generator=g) * 1.15
@@ -44,53 +109,97 @@ def synth_inputs(ahv, dev, rank):
     return [t.to(dev).contiguous() for t in (vol_src, vol_tgt, W1, W2, b2, R)]
 
 
-def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R, budget_s=20.0):
-    """The reference's op sequence with stock torch CPU ops (oracle/torch_ref.py) on the host cores:
-    the same workload in chunks of 1 000 hypotheses (fastest variant found in the survey, BASELINE.md
-    section 2), stopped after ~budget_s seconds of CPU work.  Threads = the box's CPU share for one
-    GPU (16) or fewer; override with AHV_CPU_THREADS."""
+def cpu_model_string() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def host_memory_gib() -> float:
+    """Memory this process may use: min(MemAvailable, cgroup limit)."""
+    avail = float("inf")
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(path).read().strip()
+            if v != "max":
+                avail = min(avail, int(v) / 2 ** 30)
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
+    """the reference's op sequence with stock torch CPU operators (oracle/torch_ref.py) on
+    the host cores, same inputs as the GPU run, fp32, no_grad, all host threads of this box's CPU share;
+    1 warm-up + best of 3, for BOTH the unchunked call (what the reference does, test_co3d.py:137-140: every
+    temporary of all N hypotheses materialised at once, ~130 KB each) and chunks of 1 000 (the fastest variant
+    found in the survey).  The unchunked pass needs ~8 GB of host memory at N = 50 000: if the box offers less than
+    24 GiB it runs on the first 10 000 hypotheses and says so.  `value` is the faster of the two."""
+    import torch
     from oracle import torch_ref
     cores = int(os.environ.get("AHV_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
     vs, vt, Rc, w1, w2, bb = [t.cpu() for t in (vol_src, vol_tgt, R, W1, W2, b2)]
-    torch_ref.score_hypotheses(vs, vt, Rc[:2000], w1, w2, bb, chunk=1000)  # warm-up
-    parts, done = [], 0
-    t0 = time.perf_counter()
-    while done < N_HYP and time.perf_counter() - t0 < budget_s:
-        s, _, _ = torch_ref.score_hypotheses(vs, vt, Rc[done:done + 1000], w1, w2, bb)
-        parts.append(s)
-        done += s.shape[1]
-    dt = time.perf_counter() - t0
-    scores = torch.cat(parts, dim=1)
-    return {"value": done / dt, "unit": "hypotheses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "first %d of the %d hypotheses of the same workload (B=1), chunks of 1000, torch %s CPU "
-                      "ops, %.1f s" % (done, N_HYP, torch.__version__, dt)}, scores
+    torch_ref.score_hypotheses(vs, vt, Rc[:2000], w1, w2, bb, chunk=1000)  # warm-up (thread pool, oneDNN primitives)
+
+    def best_of(n_hyp, chunk, reps=3, budget_s=25.0):
+        times, scores, t_all = [], None, time.perf_counter()
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            scores, _, _ = torch_ref.score_hypotheses(vs, vt, Rc[:n_hyp], w1, w2, bb, chunk=chunk)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget_s:
+                break
+        return min(times), len(times), scores
+
+    t_c, reps_c, scores = best_of(N_HYP, 1000)
+    n_un = N_HYP if host_memory_gib() >= 24.0 else 10_000
+    t_u, reps_u, scores_u = best_of(n_un, None)
+    chunked, unchunked = N_HYP / t_c, n_un / t_u
+    res = {"value": max(chunked, unchunked), "unit": "hypotheses/s", "cores": torch.get_num_threads(),
+           "kind": "port", "cpu_model": cpu_model_string(),
+           "chunk_1000": {"value": chunked, "seconds": t_c, "n_hyp": N_HYP, "best_of": reps_c},
+           "unchunked": {"value": unchunked, "seconds": t_u, "n_hyp": n_un, "best_of": reps_u,
+                         "note": "reference-shaped call: all hypotheses materialised at once"},
+           "sample": "all %d hypotheses of the same workload (B=1, same tensors as the GPU run), torch %s CPU "
+                     "operators, fp32, no_grad, %d threads, 1 warm-up + best of %d: chunks of 1000 %.2f s; "
+                     "unchunked (%d hypotheses) %.2f s" % (N_HYP, torch.__version__, torch.get_num_threads(), reps_c,
+                                                         t_c, n_un, t_u)}
+    assert torch.equal(scores[:, :n_un], scores_u) or (scores[:, :n_un] - scores_u).abs().max().item() < 1e-6
+    return res, scores
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--score-variant", type=int, default=3, help="fused-kernel variant to time (3 = all-fp32 dual, "
-                    "the default and the headline; 4 = split-f16 GEMM1, opt-in, reported beside it)")
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
-                                                      "the multi-rank logic on a box with fewer GPUs than ranks)")
-    args = ap.parse_args()
+def worker(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     if args.backend == "nccl" and local_rank >= ndev:
-        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
-    dev = torch.device("cuda", local_rank % max(ndev, 1))  # ranks share a GPU only in a gloo rehearsal
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible (RCCL needs one GPU per rank; --backend gloo "
+                         "rehearses more ranks than GPUs)" % (local_rank, ndev))
+    dev = torch.device("cuda", local_rank % ndev)  # ranks share a GPU only in a gloo rehearsal
     torch.cuda.set_device(dev)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -101,7 +210,7 @@ def main():
     ahv = importlib.import_module("3dahv_amd")
     ops, adist = ahv.ops, ahv.dist
     lib = ahv._lib.load()  # fails loudly without the HIP library
-    lib.ahv_set_option(b"score_variant", args.score_variant)
+    split = bool(args.split_f16)
 
     vol_src, vol_tgt, W1, W2, b2, R = synth_inputs(ahv, dev, rank)
     n_offset = rank * N_HYP
@@ -126,7 +235,7 @@ def main():
         if ev is not None:
             ev[0].record()
         ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset, want_scores=False, best_key=key,
-                             reset_best=True)
+                             reset_best=True, split_f16=split)
         if ev is not None:
             ev[1].record()
         if world > 1:
@@ -139,51 +248,71 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
-    if args.warmup:
-        finalize(args.warmup - 1)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events[i])
-    finalize(args.steps - 1)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        if args.warmup:
+            finalize(args.warmup - 1)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, events[i])
+        finalize(args.steps - 1)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # fused kernel, HIP events on its stream
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # fused kernel, HIP events on its stream
 
-    # correctness of what was timed: the key equals torch.max over the materialised scores (all ranks)
-    feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
-    scores, key = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset)
-    lv, li = torch.max(scores, dim=1)
-    cand = torch.stack([lv.double(), (li + n_offset).double()], dim=1)
-    if world > 1:
-        allc = [torch.zeros_like(cand) for _ in range(world)]
-        dist.all_gather(allc, cand)
-        cand = torch.cat(allc)
-    gbest = cand[torch.argmax(cand[:, 0])]
-    assert int(out["idx"].item()) == int(gbest[1].item()), (out["idx"], gbest)
-    assert float(out["best"].item()) == float(gbest[0].item())
+        # correctness of what was timed: the key equals torch.max over the materialised scores (all ranks)
+        feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
+        scores, key = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset, split_f16=split)
+        lv, li = torch.max(scores, dim=1)
+        cand = torch.stack([lv.double(), (li + n_offset).double()], dim=1)
+        if world > 1:
+            allc = [torch.zeros_like(cand) for _ in range(world)]
+            dist.all_gather(allc, cand)
+            cand = torch.cat(allc)
+        gbest = cand[torch.argmax(cand[:, 0])]
+        assert int(out["idx"].item()) == int(gbest[1].item()), (out["idx"], gbest)
+        assert float(out["best"].item()) == float(gbest[0].item())
+
+        # Shader clock the chip held under THIS kernel (diagnostic entry point, same launch + per-workgroup
+        # s_memtime / s_memrealtime stamps; MI355X_MICROARCH.md "DVFS give-back" item 6): after the timed region.
+        clock_ghz = None
+        if rank == 0:
+            stamps = torch.zeros(4 * lib.ahv_device_cu_count(), dtype=torch.int64, device=dev)
+            for _ in range(20):
+                ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=keys[0],
+                                     reset_best=True, split_f16=split, clock_stamps=stamps)
+            torch.cuda.synchronize()
+            st = stamps.cpu().numpy().reshape(-1, 4)
+            st = st[st[:, 3] > st[:, 1]]
+            if len(st):
+                clock_ghz = float(np.median((st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]))) * 0.1
 
     if rank == 0:
         total_hyp = N_HYP * world * args.steps
         value = total_hyp / dt
         achieved = FLOPS_PER_HYP * N_HYP / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc (see profiles/README.md)
+        # HBM bytes per launch: NOT measured in this run (PMC passes need rocprofv3); replayed from the committed
+        # summary of tools/profile_bench.sh on the same command, with its source named.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, TRAFFIC_JSON)
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("fused_hbm_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get("fused_hbm_bytes_per_launch")
+            traffic_src = "%s (rocprofv3 --pmc passes of %s; not measured in this run)" % (
+                TRAFFIC_JSON, tj.get("source", "an earlier bench.py run"))
         res = {
             "metric": "rotation hypotheses scored/sec (B=1)", "value": value, "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -193,50 +322,65 @@ def main():
                                    "source volume 16x8x8x8 (P=512 voxel sites x 16 ch), head 384->32->32, 64 positions",
                        "n_hyp_per_gpu": N_HYP, "n_hyp_total": N_HYP * world,
                        "parallelism": "hypothesis axis sharded x%d, 8-byte key all-reduce(max)" % world,
+                       "backend": "single process" if world == 1 else ("rccl" if args.backend == "nccl" else args.backend),
                        "step": "forward_3d2d(tgt) + fused score/argmax + select (unpack + gather R_pred)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "score_hypotheses_dual_kernel", "kernel_ms": kern_ms,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "score_hypotheses_dual_kernel<false>", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
-                         "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP},
+                         "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP,
+                         "shader_clock_ghz": clock_ghz,
+                         "frac_at_delivered_clock": (achieved / (PEAK_F32_MFMA_TFLOPS * clock_ghz / MAX_CLOCK_GHZ)
+                                                     if clock_ghz else None)},
         }
-        if args.score_variant != 3:
-            res["roofline"]["kernel"] = "score_variant %d" % args.score_variant
-        if args.score_variant == 4:  # opt-in kernel: priced against the f16 matrix peak (16 x the fp32 one)
+        if split:  # opt-in kernel: priced against the f16 matrix peak (16 x the fp32 one)
             res["dtype"] = "f16 hi/lo split products, f32 accumulate"
-            res["roofline"].update(peak=16 * PEAK_F32_MFMA_TFLOPS, frac=achieved / (16 * PEAK_F32_MFMA_TFLOPS),
+            res["roofline"].update(kernel="score_hypotheses_dual_kernel<true>", peak=16 * PEAK_F32_MFMA_TFLOPS,
+                                   frac=achieved / (16 * PEAK_F32_MFMA_TFLOPS), frac_at_delivered_clock=None,
+                                   traffic=None, traffic_source=None,
                                    note="GEMM1 runs 3 f16 MFMA products per algorithmic MAC; the kernel is bound by "
                                         "LDS bandwidth (trilinear gather), not by the matrix pipe")
-        if world == 1 and args.score_variant == 3:
+        if world == 1 and not split:
             # The opt-in split-f16 kernel on the same inputs, reported beside the fp32 headline (never as `value`).
-            lib.ahv_set_option(b"score_variant", 4)
-            s4, k4 = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2)
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-            for a, b in ev:
-                a.record()
-                ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=keys[0], reset_best=True)
-                b.record()
-            torch.cuda.synchronize()
-            lib.ahv_set_option(b"score_variant", 3)
+            with torch.no_grad():
+                s4, k4 = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, split_f16=True)
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+                for a, b in ev:
+                    a.record()
+                    ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=keys[0],
+                                         reset_best=True, split_f16=True)
+                    b.record()
+                torch.cuda.synchronize()
             ms4 = float(np.mean([a.elapsed_time(b) for a, b in ev]))
             res["split_f16_kernel"] = {
-                "note": "score_variant 4 (opt-in): GEMM1 as 3 f16 MFMA products of hi/lo split operands, f32 accumulate",
+                "note": "AHV_SCORE_SPLIT_F16 (opt-in, per-call flag): GEMM1 as 3 f16 MFMA products of hi/lo split "
+                        "operands, f32 accumulate",
                 "kernel_ms": ms4, "hypotheses_per_s_kernel_only": N_HYP / (ms4 * 1e-3),
                 "max_abs_score_diff_vs_f32_kernel": float((s4 - scores).abs().max().item()),
                 "same_argmax": bool(torch.equal(ops.unpack_best(k4)[1], ops.unpack_best(key)[1]))}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_scores = cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R)
             res["cpu_baseline"] = cb
-            # same inputs, same answers on the sampled part: scores <= 1e-4 relative, arg-max exact
-            n = cpu_scores.shape[1]
-            gpu_part = scores[:, :n].cpu()
-            rel = ((gpu_part - cpu_scores).abs() / cpu_scores.abs().clamp_min(1e-2)).max().item()
+            # same inputs, same answers: scores <= 1e-4 relative, arg-max exact
+            gpu_scores = scores.cpu()
+            rel = ((gpu_scores - cpu_scores).abs() / cpu_scores.abs().clamp_min(1e-2)).max().item()
             assert rel < 1e-4, rel
-            assert int(torch.argmax(cpu_scores, dim=1).item()) == int(torch.argmax(gpu_part, dim=1).item())
+            assert int(torch.argmax(cpu_scores, dim=1).item()) == int(torch.argmax(gpu_scores, dim=1).item())
             res["cpu_baseline"]["gpu_vs_cpu_max_rel_err"] = rel
+            res["cpu_baseline"]["gpu_speedup_over_chunk_1000"] = value / cb["chunk_1000"]["value"]
+            res["cpu_baseline"]["gpu_speedup_over_unchunked"] = value / cb["unchunked"]["value"]
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    external = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torch.distributed.run or our own parent
+    if args.gpus > 1 and not external:
+        sys.exit(launch_workers(args))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,8 @@
  *    contain no host synchronisation, so they can be captured in a hipGraph.
  *  - Return value: AHV_OK (0) or a negative AHV_E* code; ahv_last_error()
  *    returns a thread-local description of the last failure on this thread.
- *    No C++ exception crosses the ABI.  Entry points are re-entrant.
+ *    No C++ exception crosses the ABI.  Entry points are re-entrant and thread-safe:
+ *    the library has no mutable process-wide state (kernel choices are per-call flags).
  *  - Fixed geometry of the reference: volume channels Cv=16, side S=8
  *    (modules/modules.py:64,97), head width O=32, K=3*Cv*S=384
  *    (modules/modules.py:66-70), P=S*S=64 output positions.
@@ -47,21 +48,19 @@ extern "C" {
 
 /* flags of ahv_score_hypotheses_f32 */
 #define AHV_SCORE_RESET_BEST 1u /* zero best_key[0..B) on the stream before scoring */
+#define AHV_SCORE_SPLIT_F16 2u  /* opt-in kernel for THIS call: GEMM1 (the 384 -> 32 projection) as three f16 MFMA
+                                 * products of hi/lo-split operands with fp32 accumulation (the dropped lo*lo term is
+                                 * 2^-22 relative; power-of-two prescales chosen on the device keep every finite fp32
+                                 * input exact in range).  Scores are as close to the fp64 truth as the default
+                                 * kernel's (~7e-8), the arithmetic is not IEEE fp32 operation by operation, hence
+                                 * opt-in.  GEMM2, normalisation and score stay fp32.  1.8x faster.  The selector is
+                                 * per call: there is no process-wide kernel switch. */
 
 /* ABI version (major<<16 | minor). */
 int ahv_abi_version(void);
 
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ahv_last_error(void);
-
-/*
- * Tuning / diagnostic knob (not part of the reference's interface).  Known names:
- *   "score_variant"  fused-scorer kernel: 0 = 16x16x4 MFMA, W1 in registers, phase-sequential;
- *                    1 = same with a micro-step software pipeline; 2 = 32x32x2 MFMA, half-volume phases;
- *                    3 = two waves per SIMD, 16x16x4 MFMA, W1 fragments in LDS (default)
- * Returns the previous value, or AHV_EINVAL for an unknown name / value.
- */
-int ahv_set_option(const char* name, int value);
 
 /* Number of compute units of the current device (for sizing / reporting); <0 on error. */
 int ahv_device_cu_count(void);
@@ -95,12 +94,27 @@ int ahv_device_cu_count(void);
  *            scores, the LOWEST index (torch.max semantics); NaN scores order
  *            above +inf (torch.max propagates NaN).  Decode with ahv_unpack_best.
  *            Requires n_offset + N <= 2^32.
- *  flags     AHV_SCORE_RESET_BEST or 0 (0 merges into existing keys, e.g. chunked N)
+ *  flags     bit-or of AHV_SCORE_RESET_BEST (else: merge into the existing keys, e.g. chunked N) and
+ *            AHV_SCORE_SPLIT_F16 (else: the all-fp32 kernel)
  */
 int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
                              int64_t r_batch_stride, int64_t n_offset, const float* W1,
                              const float* W2, const float* b2, int B, int64_t N, float* scores,
                              uint64_t* best_key, unsigned flags, void* stream);
+
+/*
+ * Diagnostics (measurement only; not part of the reference's interface): the same launch as
+ * ahv_score_hypotheses_f32, and additionally every workgroup w of the persistent grid writes
+ *   clock_stamps[4w + 0..3] = { s_memtime, s_memrealtime (100 MHz) before its hypothesis loop, the same two after }
+ * so that the shader clock the chip actually held during THIS kernel is
+ *   (stamps[2] - stamps[0]) / (stamps[3] - stamps[1]) * 100 MHz   (median over workgroups).
+ * clock_stamps: device memory, 4 * ahv_device_cu_count() words, zeroed by the caller (the grid never exceeds
+ * one workgroup per CU; entries of unused slots stay zero).  bench.py reports roofline.shader_clock_ghz from it.
+ */
+int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                                     int64_t r_batch_stride, int64_t n_offset, const float* W1,
+                                     const float* W2, const float* b2, int B, int64_t N, float* scores,
+                                     uint64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream);
 
 /*
  * Decode packed keys: best_score[b], best_idx[b] (int64, global hypothesis index).
@@ -118,6 +132,17 @@ int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t*
  */
 int ahv_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N,
                           int C, int D, int H, int W, float* out, void* stream);
+
+/*
+ * Adjoint of ahv_rotate_volume_f32 w.r.t. the volume -- what autograd needs when the reference's differentiable
+ * rotate_volume (utils.py:113-131) sits in a training graph (infoNCE_loss, modules/model_co3d.py:49-54).
+ * grad_out [N][C][D][H][W] = dL/d(rotated volume); grad_vol is WRITTEN (zeroed on the stream first): one
+ * [C][D][H][W] volume when vol_batch_stride = 0 (all hypotheses accumulate into it: the stride-0 expand the
+ * reference passes), else volume n at grad_vol + n*vol_batch_stride.  R carries no gradient (the reference samples
+ * it).  Sums use float atomics: reproducible to rounding, not bitwise.
+ */
+int ahv_rotate_volume_backward_f32(const float* grad_out, int64_t vol_batch_stride, const float* R, int64_t N,
+                                   int C, int D, int H, int W, float* grad_vol, void* stream);
 
 /*
  * Op-level drop-in for Feature_Aligner.forward_3d2d (modules/modules.py:112-124):

@@ -22,7 +22,14 @@ def load_golden(name):
 
 @pytest.fixture(scope="session")
 def ahv():
-    return importlib.import_module("3dahv_amd")
+    """The package, with libahv_hip.so brought up to date FROM SOURCE first wherever a GPU is present (incremental
+    make: a no-op when the binary that travelled with the snapshot is newer than every source; a stale or missing
+    binary is rebuilt, and a build failure fails the session instead of testing an old library)."""
+    pkg = importlib.import_module("3dahv_amd")
+    import torch
+    if torch.cuda.is_available():
+        pkg._lib.build()
+    return pkg
 
 
 @pytest.fixture(scope="session")

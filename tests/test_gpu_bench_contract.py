@@ -29,3 +29,29 @@ def test_bench_json_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
     # value = hypotheses of all steps / wall time; consistent with ms_per_step
     assert abs(d["value"] - 50000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert r["algorithmic_hbm_bytes_per_launch"] == 36 * 50000          # want_scores=False launch: R only
+    assert r["traffic"] is None or "not measured in this run" in r["traffic_source"]
+    assert 1.0 < r["shader_clock_ghz"] <= 2.5                             # measured live under this kernel
+    assert r["frac_at_delivered_clock"] >= r["frac"] - 1e-9
+    assert "ms" not in d["config"] and d["config"]["backend"] == "single process"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2` (no external launcher) spawns its two workers before touching the GPU; on this
+    1-GPU box the ranks share the device over gloo (a rehearsal of the sharded path, not a measurement)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["n_hyp_total"] == 100000
+    assert d["config"]["backend"] == "gloo" and d["scaling"] == "weak"
+    assert abs(d["value"] - 100000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # a failing rank takes the launch down with a non-zero code instead of hanging in a collective
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "nccl",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=600, cwd=REPO, env=env)
+    assert bad.returncode != 0 and "only 1 GPU(s) visible" in bad.stderr

@@ -1,0 +1,240 @@
+"""Boundary hardening: the op-level drop-ins never drop a gradient silently, the packed
+encoder weights follow in-place parameter updates, launches are bound to the tensors' device, fit() keeps one
+optimizer / scheduler across epochs and resumes, GraphedTrainStep leaves the model as it was given."""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def ref_infonce(rotate_volume, forward_3d2d, img_feat_1, img_feat_2, sampled_R, gt_delta_R, acc_thr):
+    """The shape of the reference's loss (modules/model_co3d.py:41-61): positives within acc_thr degrees of the
+    ground truth, per-sample rotate_volume of a stride-0 expand, forward_3d2d, mean cosine, temperature 0.1."""
+    B, N = sampled_R.shape[:2]
+    cos = ((sampled_R.reshape(B, N, 9) * gt_delta_R.reshape(B, 1, 9)).sum(-1).clamp(-1, 3) - 1) / 2
+    pos = (torch.arccos(cos) * 180.0 / np.pi) <= acc_thr
+    rot = [rotate_volume(img_feat_1[b:b + 1].expand(N, -1, -1, -1, -1), sampled_R[b]) for b in range(B)]
+    f1 = forward_3d2d(torch.stack(rot).reshape(-1, 16, 8, 8, 8)).reshape(B, N, 32, 64)
+    f2 = forward_3d2d(img_feat_2)
+    sim = torch.exp((f1 * f2[:, None]).sum(dim=2).mean(dim=-1) / 0.1)
+    return (-torch.log((sim * pos).sum(1) / sim.sum(1))).mean()
+
+
+def test_patched_reference_shaped_infonce_backpropagates_on_hip(ahv, dev):
+    """patch.install() on stand-in `utils` / `modules.modules`, then a reference-shaped infoNCE_loss under autograd:
+    non-zero gradients for both volumes and the head weights, equal to fp64 autograd through the stock-operator
+    restatement (oracle/torch_ref.py).  Before round 2 the patched callables detached their inputs: every
+    gradient was silently zero."""
+    from oracle import torch_ref
+    g = load_golden("score_n128")
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+
+    class Feature_Aligner(torch.nn.Module):  # noqa: N801
+        def __init__(self):
+            super().__init__()
+            self.feature_embedding_2d = torch.nn.Sequential(torch.nn.Conv2d(384, 32, 1, bias=False), torch.nn.ReLU(),
+                                                            torch.nn.Conv2d(32, 32, 1))
+
+        def forward_3d2d(self, x):
+            raise AssertionError("not patched")
+    mm.Feature_Aligner = Feature_Aligner
+    fa = Feature_Aligner().to(dev)
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).to(dev)
+    with torch.no_grad():
+        fa.feature_embedding_2d[0].weight.copy_(T("W1").reshape(32, 384, 1, 1))
+        fa.feature_embedding_2d[2].weight.copy_(T("W2").reshape(32, 32, 1, 1))
+        fa.feature_embedding_2d[2].bias.copy_(T("b2"))
+    rng = np.random.RandomState(3)
+    B, N = 2, 24
+    v1 = torch.tensor((rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32), device=dev, requires_grad=True)
+    v2 = torch.tensor((rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32), device=dev, requires_grad=True)
+    gt = torch.from_numpy(ahv.rotations.haar_rotations_np(B, 5)).to(dev)
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(B * N, 6)).reshape(B, N, 3, 3).to(dev).clone()
+    R[:, 0] = gt
+    ahv.patch.install(um, mm)
+    try:
+        loss = ref_infonce(um.rotate_volume, fa.forward_3d2d, v1, v2, R, gt, 30.0)
+        loss.backward()
+    finally:
+        ahv.patch.uninstall()
+    W1, W2, b2 = fa.feature_embedding_2d[0].weight, fa.feature_embedding_2d[2].weight, fa.feature_embedding_2d[2].bias
+    got = [v1.grad, v2.grad, W1.grad.reshape(32, 384), W2.grad.reshape(32, 32), b2.grad]
+    # fp64 reference through stock torch operators
+    d = lambda t: t.detach().double().cpu().requires_grad_(True)
+    r1, r2, rW1, rW2, rb2 = d(v1), d(v2), d(W1.reshape(32, 384)), d(W2.reshape(32, 32)), d(b2)
+    ref_loss = ref_infonce(torch_ref.rotate_volume, lambda x: torch_ref.forward_3d2d(x, rW1, rW2, rb2), r1, r2,
+                           R.double().cpu(), gt.double().cpu(), 30.0)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    for name, a, b in zip(["vol_src", "vol_tgt", "W1", "W2", "b2"], got, [r1.grad, r2.grad, rW1.grad, rW2.grad, rb2.grad]):
+        assert a is not None and a.abs().max().item() > 0, name
+        assert rel(a.cpu(), b) < 2e-4, (name, rel(a.cpu(), b))
+
+
+@pytest.mark.parametrize("shape,shared", [((16, 8, 8, 8), True), ((16, 8, 8, 8), False), ((3, 4, 5, 6), True),
+                                          ((3, 4, 5, 6), False)])
+def test_rotate_volume_adjoint_matches_grid_sample_autograd(ahv, dev, shape, shared):
+    from oracle import torch_ref
+    N = 19
+    rng = np.random.RandomState(11)
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(N, 3)).to(dev)
+    R[3] = R[3] * 1.7   # not a rotation: corners leave the volume (zeros padding), weights no longer sum to 1
+    base = torch.tensor(rng.standard_normal(((1 if shared else N),) + shape).astype(np.float32), device=dev,
+                        requires_grad=True)
+    vol = base.expand(N, -1, -1, -1, -1) if shared else base
+    gout = torch.tensor(rng.standard_normal((N,) + shape).astype(np.float32), device=dev)
+    out = ahv.ops.rotate_volume(vol, R)
+    assert out.requires_grad
+    out.backward(gout)
+    b64 = base.detach().double().cpu().requires_grad_(True)
+    v64 = b64.expand(N, -1, -1, -1, -1) if shared else b64
+    torch_ref.rotate_volume(v64, R.double().cpu()).backward(gout.double().cpu())
+    assert base.grad.shape == base.shape and rel(base.grad.cpu(), b64.grad) < 1e-5
+    with pytest.raises(NotImplementedError):
+        ahv.ops.rotate_volume(vol, R.clone().requires_grad_(True))
+    with torch.no_grad():  # inference form unchanged: no graph
+        assert not ahv.ops.rotate_volume(vol, R).requires_grad
+
+
+def test_plain_ops_never_drop_a_gradient(ahv, dev):
+    g = load_golden("score_n128")
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).to(dev)
+    vs, vt, R = T("vol_src").requires_grad_(True), T("vol_tgt"), T("R")[:16]
+    W1, W2, b2 = T("W1").requires_grad_(True), T("W2"), T("b2")
+    ft = ahv.ops.forward_3d2d(vt, W1, W2, b2)          # W1 requires grad -> autograd edge
+    assert ft.requires_grad
+    scores, key = ahv.ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    assert scores.requires_grad and not key.requires_grad
+    scores.sum().backward()
+    ref = ahv.ops.score_hypotheses_autograd(vs.detach().requires_grad_(True), ft.detach(), R, W1.detach(), W2, b2)
+    assert vs.grad.abs().max().item() > 0 and W1.grad.abs().max().item() > 0
+    assert torch.equal(scores.detach(), ref.detach())
+    with pytest.raises(RuntimeError, match="autograd"):
+        ahv.ops.score_features(torch.zeros(1, 2, 32, 64, device=dev, requires_grad=True), torch.zeros(1, 32, 64, device=dev))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ahv.ops.unpack_best(torch.zeros(1, dtype=torch.int64))
+    _, key2 = ahv.ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False)   # nothing differentiable requested
+    assert torch.equal(key2, key)
+
+
+def test_packed_encoder_weights_follow_inplace_updates(ahv, dev):
+    """pack -> optimizer.step() -> the no_grad HIP encoder must see the NEW weights everywhere
+    (q|k|v concatenation, tap-major conv copies, padded 3-D conv copies are copies, not aliases)."""
+    torch.manual_seed(3)
+    m = ahv.aligner.Feature_Aligner(768, 256, 32, 4, 4).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(1, 768, 8, 8, generator=g).to(dev), torch.randn(1, 768, 8, 8, generator=g).to(dev)
+
+    def both():
+        with torch.no_grad():
+            m.use_hip_encoder = m.att.use_hip = True
+            hip = m.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+            m.use_hip_encoder = m.att.use_hip = False
+            ref = m.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0)
+            m.use_hip_encoder = m.att.use_hip = True
+        return hip, ref
+    hip0, ref0 = both()
+    assert rel(hip0[0], ref0[0]) < 2e-5
+    run = m.graphed_forward_2d3d(batch=1)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    gg = torch.Generator(device="cpu").manual_seed(2)
+    for p in m.parameters():
+        p.grad = (torch.randn(p.shape, generator=gg) * p.detach().abs().mean().cpu()).to(dev)
+    opt.step()                                          # in-place update of every parameter
+    hip1, ref1 = both()
+    assert rel(ref1[0], ref0[0]) > 1e-3                 # the step really changed the function
+    assert rel(hip1[0], ref1[0]) < 2e-5 and rel(hip1[1], ref1[1]) < 2e-5
+    out = run(a, b)                                     # captured graph: packed copies refilled at their addresses
+    assert rel(out[0], ref1[0]) < 2e-5 and rel(out[1], ref1[1]) < 2e-5
+    with torch.no_grad():                               # token stage alone (its own table)
+        x = torch.randn(1, 256, 8, 8, device=dev)
+        y_hip, _ = m.att(x, x)
+        m.att.use_hip = False
+        y_ref, _ = m.att(x, x)
+        m.att.use_hip = True
+    assert rel(y_hip, y_ref) < 2e-5
+    # storage replaced (not in place): new pointers, the graph is captured again
+    with torch.no_grad():
+        m.att.proj_in.bias.data = m.att.proj_in.bias.data.clone() + 0.5
+    _, ref2 = both()
+    out2 = run(a, b)
+    assert rel(out2[0], ref2[0]) < 2e-5 and rel(ref2[0], ref1[0]) > 1e-4
+
+
+def tiny_cfg(num_rota=32):
+    return {"RUN_NAME": "t", "DATA": {"NUM_ROTA": num_rota, "BG": True, "SIZE_THR": 25, "OBJ_SIZE": 256, "ACC_THR": 30,
+                                      "VIEW_THR": 90},
+            "TRAIN": {"MASK": False, "MASK_RATIO": 0.0, "LR": 1e-4, "STEP_SIZE": 1, "GAMMA": 0.5}}
+
+
+def test_fit_keeps_one_optimizer_and_scheduler_across_epochs_and_resumes(ahv, dev, tmp_path):
+    """the reference trains many epochs with ONE AdamW and ONE StepLR (modules/model_co3d.py:95-99,
+    130-145); fit(epochs=k) must do the same, and fit(ckpt_path=) must continue moments, step counts and the LR
+    schedule."""
+    cfg = tiny_cfg()
+    torch.manual_seed(0)
+    m = ahv.estimator.EstimatorCo3d(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1)).to(dev)
+    loader = ahv.harness.SyntheticTrainingPairs(batch_size=1, steps=2, seed=3)
+
+    def opt_sched(model):  # the reference's AdamW; a fast StepLR so that three epochs show the decay
+        (o,), _ = model.configure_optimizers()
+        return o, torch.optim.lr_scheduler.StepLR(o, step_size=1, gamma=0.5)
+    opt0, sch0 = opt_sched(m)
+    lr0 = opt0.param_groups[0]["lr"]
+    ck = str(tmp_path / "last.ckpt")
+    res = ahv.harness.fit(cfg, m, loader, device=dev, epochs=3, save_path=ck, optimizer=opt0, scheduler=sch0)
+    assert len(res) == 6 and res.epoch == 3 and res.global_step == 6 and res.optimizer is opt0
+    steps = {int(st["step"]) for st in res.optimizer.state.values() if "step" in st}
+    assert steps == {6}                                              # one optimizer saw all six steps
+    assert res.scheduler.last_epoch == 3
+    assert abs(res.optimizer.param_groups[0]["lr"] - lr0 * 0.5 ** 3) < 1e-12      # the decay took effect
+    # default path: configure_optimizers() once per fit call, StepLR(200, 0.1) as in modules/model_co3d.py:93-99
+    torch.manual_seed(0)
+    m1 = ahv.estimator.EstimatorCo3d(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1)).to(dev)
+    r1 = ahv.harness.fit(cfg, m1, loader, device=dev, epochs=2, max_steps=3)
+    assert len(r1) == 3 and r1.scheduler.step_size == 200 and r1.scheduler.last_epoch == 2
+    # resume into a fresh model + fresh optimizer: state comes from the checkpoint
+    torch.manual_seed(0)
+    m2 = ahv.estimator.EstimatorCo3d(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1)).to(dev)
+    opt2, sch2 = opt_sched(m2)
+    res2 = ahv.harness.fit(cfg, m2, loader, device=dev, epochs=1, ckpt_path=ck, optimizer=opt2, scheduler=sch2)
+    assert res2.epoch == 4 and res2.global_step == 8 and res2.scheduler.last_epoch == 4
+    assert {int(st["step"]) for st in res2.optimizer.state.values() if "step" in st} == {8}
+    assert abs(res2.optimizer.param_groups[0]["lr"] - lr0 * 0.5 ** 4) < 1e-12
+    # continuing with the returned pair is the same thing
+    res3 = ahv.harness.fit(cfg, m, loader, device=dev, epochs=1, optimizer=res.optimizer, scheduler=res.scheduler)
+    assert res3.scheduler.last_epoch == 4 and res3.optimizer is res.optimizer
+    assert np.allclose(res2, res3, rtol=5e-3, atol=1e-4), (list(res2), list(res3))
+
+
+def test_graphed_train_step_leaves_the_model_as_given(ahv, dev):
+    """the capture warm-up must not train the model on placeholder data."""
+    cfg = tiny_cfg(24)
+    torch.manual_seed(0)
+    m = ahv.estimator.EstimatorCo3d(cfg, feature_extractor=ahv.estimator.PatchifyBackbone(seed=1)).to(dev).train()
+    state0 = copy.deepcopy(m.state_dict())
+    step = ahv.harness.GraphedTrainStep(m, batch_size=1, device=dev, warmup=2)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, state0[k]), k
+    for st in step.optimizer.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                assert float(v.abs().max()) == 0.0
+    assert step._draws == 0

@@ -317,22 +317,18 @@ def test_fused_argument_errors(ops, ahv, G):
         ahv._lib.check(rc, "ahv_score_hypotheses_f32")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-def test_fused_kernel_variants_agree(ops, ahv, G, g128, variant):
-    """All fused-kernel variants (diagnostic knob) meet the same parity bar."""
-    lib = ahv._lib.load()
-    prev = lib.ahv_set_option(b"score_variant", variant)
-    try:
+@pytest.mark.parametrize("split", [False, True])
+def test_fused_kernels_agree(ops, ahv, G, g128, split):
+    """Both fused kernels (all-fp32 default; opt-in split-f16 via the per-call flag) meet the same parity bar."""
+    with ops.split_f16_scorer(split):
         scores, val, idx = fused(ops, G, G["R"])
         assert score_relerr(scores.cpu().numpy(), g128["scores"]) < SCORE_RTOL
         assert idx.item() == int(g128["best_idx"][0])
-        g = load_golden("batched")  # B > 1 and per-sample R through every variant
+        g = load_golden("batched")  # B > 1 and per-sample R through both kernels
         vs, vt = to_dev(g["vol_src"], G["R"].device), to_dev(g["vol_tgt"], G["R"].device)
         ft = ops.forward_3d2d(vt, G["W1"], G["W2"], G["b2"])
         s2, _ = ops.score_hypotheses(vs, ft, to_dev(g["R_per"], G["R"].device), G["W1"], G["W2"], G["b2"])
         assert score_relerr(s2.cpu().numpy(), g["scores_per"]) < SCORE_RTOL
-    finally:
-        lib.ahv_set_option(b"score_variant", prev)
 
 
 def test_device_haar_sampler(ops, dev):
@@ -366,12 +362,10 @@ def test_forward_3d2d_throughput_path_matches_small_paths(ops, oracle, G, g128, 
     assert tensor_relerr(big[4990:].cpu().numpy(), ref) < TENSOR_RTOL
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4])
-def test_fused_many_samples_few_hypotheses(ops, ahv, oracle, g128, dev, variant):
+@pytest.mark.parametrize("split", [False, True])
+def test_fused_many_samples_few_hypotheses(ops, ahv, oracle, g128, dev, split):
     """B larger than the number of CUs (each workgroup loops over several samples) and N smaller than a workgroup."""
-    lib = ahv._lib.load()
-    prev = lib.ahv_set_option(b"score_variant", variant)
-    try:
+    with ops.split_f16_scorer(split):
         rng = np.random.RandomState(3)
         B, N = 300, 5
         vs = (rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32)
@@ -383,8 +377,6 @@ def test_fused_many_samples_few_hypotheses(ops, ahv, oracle, g128, dev, variant)
         ref, _, ref_idx = oracle.score_hypotheses(vs, vt, R, g128["W1"], g128["W2"], g128["b2"])
         assert score_relerr(s.cpu().numpy(), ref) < SCORE_RTOL
         assert ops.unpack_best(key)[1].cpu().tolist() == ref_idx.tolist()
-    finally:
-        lib.ahv_set_option(b"score_variant", prev)
 
 
 def test_planted_rotation_recovered_at_full_size(ops, ahv, G, dev):

@@ -1,4 +1,4 @@
-"""score_variant 4 ("split"): GEMM1 on the f16 matrix pipe with hi/lo split operands, fp32 accumulation.
+"""AHV_SCORE_SPLIT_F16 ("split"): GEMM1 on the f16 matrix pipe with hi/lo split operands, fp32 accumulation.
 
 Opt-in (the default kernel is all-fp32).  These tests pin what makes it usable as an fp32 stand-in:
 the same parity bar as the fp32 kernels against the golden vectors, an error against an fp64 evaluation
@@ -27,20 +27,14 @@ def ops(ahv):
 
 
 @pytest.fixture()
-def variant(ahv):
-    lib = ahv._lib.load()
-
-    def use(v):
-        return lib.ahv_set_option(b"score_variant", v)
-    prev = use(4)
-    yield use
-    use(prev)
+def variant():
+    """Kept for the call sites below: variant 4 = the split-f16 kernel, 3 = all-fp32, chosen PER CALL."""
+    return None
 
 
 def scores_with(ops, use, v, vs, vt, R, W1, W2, b2):
-    use(v)
     ft = ops.forward_3d2d(vt, W1, W2, b2)
-    s, key = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    s, key = ops.score_hypotheses(vs, ft, R, W1, W2, b2, split_f16=(v == 4))
     return s, ops.unpack_best(key)[1]
 
 
@@ -124,11 +118,33 @@ def test_split_soak_against_fp32_kernel(ops, ahv, variant, dev):
         assert torch.equal(i4[clear], i32[clear])
 
 
-def test_score_variant_context_manager(ops, ahv, dev):
+def test_split_selector_is_per_call_and_per_context(ops, ahv, dev):
+    """No process-wide kernel switch: the flag travels with the call; the context manager is scoped to the
+    current thread / context; an unknown flag bit is refused by the C ABI."""
+    import threading
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    vs, vt, R, W1, W2, b2 = (t(g128[k]) for k in ["vol_src", "vol_tgt", "R", "W1", "W2", "b2"])
+    ft = ops.forward_3d2d(vt, W1, W2, b2)
+    s32, _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    s16, _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2, split_f16=True)
+    assert not torch.equal(s32, s16) and (s32 - s16).abs().max().item() < 5e-7
+    seen = {}
+    with ops.split_f16_scorer():
+        inside, _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+        forced, _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2, split_f16=False)
+
+        def other_thread():  # a thread started inside the block does not inherit the selection
+            seen["s"], _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+        th = threading.Thread(target=other_thread)
+        th.start()
+        th.join()
+    after, _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    assert torch.equal(inside, s16) and torch.equal(forced, s32) and torch.equal(after, s32)
+    assert torch.equal(seen["s"], s32)
     lib = ahv._lib.load()
-    assert lib.ahv_set_option(b"score_variant", 3) >= 0
-    with ops.score_variant(4):
-        assert lib.ahv_set_option(b"score_variant", 4) == 4      # reads back the variant in force
-    assert lib.ahv_set_option(b"score_variant", 3) == 3          # restored on exit
-    with pytest.raises(RuntimeError):
-        ops.score_variant(9)
+    assert not hasattr(lib, "ahv_set_option")
+    key = torch.zeros(1, dtype=torch.int64, device=dev)
+    rc = lib.ahv_score_hypotheses_f32(vs.data_ptr(), ft.data_ptr(), R.data_ptr(), 0, 0, W1.data_ptr(), W2.data_ptr(),
+                                      b2.data_ptr(), 1, 128, None, key.data_ptr(), 4, None)
+    assert rc == -1 and b"unknown flags" in lib.ahv_last_error()

@@ -214,7 +214,7 @@ if not only or "pairs" in only:
         dt = time.perf_counter() - t0
         print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": name, "pairs": len(e),
                           "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))
-    with ops.score_variant(4):  # opt-in split-f16 scorer
+    with ops.split_f16_scorer():  # opt-in split-f16 scorer (per-call flag)
         seqs = list(ahv.harness.SyntheticSequences(40, 2, seed=1))
         np.random.seed(0)
         ahv.harness.evaluate_category(cfgp, mp_, seqs[:4], device=dev, proposals=P, batch_sequences=16)
@@ -223,5 +223,5 @@ if not only or "pairs" in only:
         e = ahv.harness.evaluate_category(cfgp, mp_, seqs, device=dev, proposals=P, batch_sequences=16)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": "16 sequences per batch, score_variant 4 (split-f16, opt-in)",
+        print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": "16 sequences per batch, AHV_SCORE_SPLIT_F16 (split-f16, opt-in)",
                           "pairs": len(e), "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))

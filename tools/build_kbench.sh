@@ -2,6 +2,6 @@
 # Builds the developer micro-benchmarks (plain and with in-kernel stamps) next to their source.
 set -e
 cd "$(dirname "$0")/.."
-F="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I3dahv_amd/csrc -Iinclude"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I3dahv_amd/csrc -Iinclude -Itools"
 timeout 900 hipcc $F tools/kbench.cpp -o tools/kbench
 timeout 900 hipcc $F -DAHV_STAMPS tools/kbench.cpp -o tools/kbench_stamps

@@ -4,6 +4,7 @@
 //                                   -I3dahv_amd/csrc tools/kbench.cpp -o tools/kbench
 // Run (on the GPU box):  tools/kbench [N] [iters]
 #include "../3dahv_amd/csrc/ahv_score.hip"
+#include "legacy/ahv_score_legacy.h"  // variants 0-2: A/B only, not in libahv_hip.so
 
 #include <cstdio>
 #include <cstdlib>
@@ -51,13 +52,18 @@ int main(int argc, char** argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ref(N);
     for (int variant = (argc > 3 ? atoi(argv[3]) : 0); variant < (argc > 3 ? atoi(argv[3]) + 1 : 5); ++variant) {
-        ahv::g_score_variant = variant;
+        // 0-2 = legacy formulations (tools/legacy), 3 = the product's fp32 kernel, 4 = its opt-in split-f16 sibling
+        auto launch = [&]() {
+            return variant < 3 ? ahv::launch_score_legacy(variant, dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, 0)
+                               : ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu,
+                                                              variant == 4, nullptr, 0);
+        };
         for (int rep = 0; rep < 3; ++rep) {
             for (int w = 0; w < 3; ++w)
-                CK(ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, 0));
+                CK(launch());
             CK(hipEventRecord(e0, 0));
             for (int it = 0; it < iters; ++it)
-                CK(ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, 0));
+                CK(launch());
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms = 0;

@@ -15,7 +15,7 @@
 //                                                                           16 FMAs of corner j-1 (j>0)
 //                                                                i = 11     16x ds_write_b32 into the other buffer
 #pragma once
-#include "ahv_device.h"
+#include "../../3dahv_amd/csrc/ahv_device.h"
 
 namespace ahv {
 

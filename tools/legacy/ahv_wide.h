@@ -15,7 +15,7 @@
 // Rows of every MFMA = the 32 head channels (A = W1 fragments, 192 VGPRs resident),
 // columns = 32 positions (tile T: i in 4T..4T+3, j < 8).
 #pragma once
-#include "ahv_device.h"
+#include "../../3dahv_amd/csrc/ahv_device.h"
 
 namespace ahv {
 
@@ -199,18 +199,6 @@ __device__ __forceinline__ void gemm2_wide(f32x16 (&v)[2], const f32x16 (&acc)[2
             const float u = __builtin_amdgcn_fmed3f(acc[t][r], 0.0f, __builtin_inff());
             v[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a2[r], u, v[t], 0, 0, 0);
         }
-}
-
-// sum over the 64 lanes with DPP row operations (no LDS round trips); result valid in lane 63
-__device__ __forceinline__ float wave_sum_dpp(float x)
-{
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));  // row_shr:1
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true));  // row_shr:2
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xE, true));  // row_shr:4
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xC, true));  // row_shr:8
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, true));  // row_bcast:15
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, true));  // row_bcast:31
-    return x;
 }
 
 // F.normalize over channels, dot with the unit-norm target, mean over the 64 positions.
