@@ -60,16 +60,17 @@ class _Packed:
         self.entries.append((setter, build))
         setter(t.data_ptr())
 
-    def refresh(self):
+    def refresh(self, module):
         """Re-evaluate every entry after a parameter change; returns True when any pointer changed."""
+        live = {p.untyped_storage().data_ptr() for p in module.parameters()}
         moved = False
         for i, (setter, build) in enumerate(self.entries):
             new, old = build(), self.keep[i]
             if new.data_ptr() == old.data_ptr():
-                continue  # alias of a live parameter: already current
-            if new.shape == old.shape and not _is_alias(new):
-                old.copy_(new)  # a copy: refill in place, address unchanged
-            else:  # the parameter's own storage moved (.to(), .data = ...)
+                continue  # alias of a live parameter (or a constant): already current
+            if new.untyped_storage().data_ptr() not in live and new.shape == old.shape:
+                old.copy_(new)  # a derived copy: refill in place, address unchanged
+            else:  # an alias whose parameter storage itself moved (.to(), .data = ...)
                 self.keep[i] = new
                 setter(new.data_ptr())
                 moved = True
@@ -78,18 +79,9 @@ class _Packed:
         return moved
 
 
-def _is_alias(t):
-    return getattr(t, "_ahv_alias", False)
-
-
 def _entry(param_fn, device):
     """build() for one packed tensor: param_fn() gives the (possibly derived) tensor from the live parameters."""
-    def build():
-        src = param_fn()
-        out = _f32(src, device)
-        out._ahv_alias = out.data_ptr() == src.data_ptr()
-        return out
-    return build
+    return lambda: _f32(param_fn(), device)
 
 
 def _struct_setter(struct, name, index=None):
@@ -143,7 +135,7 @@ def _packed_transformer(att, device):
         return pack_transformer(att, device)
     key = _version_key(att)
     if key != pk.key:
-        pk.refresh()
+        pk.refresh(att)
         pk.key = key
     return pk
 
@@ -199,7 +191,7 @@ def _packed_aligner(fa, device):
     key = _version_key(fa)
     if key != pk.key:
         _packed_transformer(fa.att, device)  # shares fa.att's parameters: refresh its table first
-        pk.refresh()
+        pk.refresh(fa)
         pk.key = key
     return pk
 
@@ -554,6 +546,7 @@ class Feature_Aligner(nn.Module):
 
         capture()
 
+        @torch.no_grad()
         def run(layer4_src, layer4_tgt):
             # Parameters updated in place since the capture (optimizer.step()): refill the packed copies at their
             # captured addresses; parameters whose storage moved: capture again.
