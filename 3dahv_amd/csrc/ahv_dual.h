@@ -121,4 +121,321 @@ __device__ __forceinline__ void gemm2_dual(f32x4 (&v)[2][4], const f32x4 (&acc)[
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Gather, second formulation (fused fp32 scorer).  Same sampling semantics as tri_coef_ptr / tri_blend_ptr
+// (F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=False), utils.py:123-129), restated so that the
+// per-voxel VALU work outside the blend drops from ~100 to ~40 instructions (fp32 MFMA and VALU share the
+// issue slots on gfx950, so every instruction removed here is time returned to the matrix pipe):
+//
+//  * affine coordinates: the sample coordinate along axis A is  i_A = 4 g_A + 3.5,  g = R p, and a lane's eight
+//    voxels differ only by p.y += 1 (pass) and p.z += 1/2 (quarter), so  i_A(pass, Q) = i_A(0,0) + pass * 4 R[A][1]
+//    + Q * 2 R[A][2]:  nine FMAs per HYPOTHESIS plus three per voxel instead of nine + six per voxel;
+//  * "hat" weights on a base clamped to [0, 6]: with j = clamp(floor(i), 0, 6) the two neighbours j, j+1 are
+//    ALWAYS inside the volume and their weights are the hat function  max(0, 1 - |i - j|), max(0, 1 - |i - j - 1|)
+//    -- exactly grid_sample's weights where a neighbour is inside, and exactly 0 for what zeros-padding drops
+//    (i in [-1,0): j = 0 gets 1 + i, j+1 gets 0;  i in [7,8): j = 6 gets 0, j+1 = 7 gets 8 - i;  beyond: both 0).
+//    No range compares, no selects, no index clamps;  max(0, .) is the free VOP3 clamp modifier;
+//  * one base address: because j+1 is always valid the eight corner rows sit at CONSTANT byte offsets
+//    {0,80} + {0,640} + {0,5920} from the row of (jz, jy, jx) -- one address register and immediate offsets
+//    instead of eight computed pointers;
+//  * the blend runs on v_pk_fma_f32 (two channels per lane and instruction, the corner weight broadcast
+//    through op_sel): half the blend instructions, same FMA order per channel, bit-identical sums.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Wave priority during the gather (A/B knob of tools/kbench; 1 = shipped).  The two waves of a SIMD run the same
+// program with no barrier; the one that is gathering is latency-bound (LDS round trips, short VALU bursts)
+// while its partner streams MFMAs, so letting the gathering wave issue FIRST whenever it is ready shortens
+// its critical path at no cost to the matrix pipe: measured -3.4 % kernel time (0 / 1 / GEMM-high / all-but-GEMM
+// high: 0.743 / 0.718 / 0.734 / 0.727 ms per 50 000 hypotheses).
+#ifndef AHV_PRIO
+#define AHV_PRIO 1
+#endif
+
+struct GatherLane {
+    float x4, y4, z4;  // 4 * voxel-centre coordinate of this lane's (pass 0, quarter 0) voxel: (2 i + 1) / 2 - 4
+};
+
+__device__ __forceinline__ GatherLane gather_lane(int lane)
+{
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b = 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
+    GatherLane g;
+    g.x4 = (float)(2 * e + 1) * 0.5f - 4.0f;
+    g.y4 = (float)(2 * b + 1) * 0.5f - 4.0f;
+    g.z4 = (float)(2 * a0 + 1) * 0.5f - 4.0f;
+    return g;
+}
+
+struct GatherHyp {
+    float i0[3][2];  // [axis][pass]: coordinate of the lane's voxel in quarter 0
+    float dq[3];     // per-quarter increment 2 R[axis][2]
+};
+
+__device__ __forceinline__ void gather_hyp(GatherHyp& h, const float* Rm, const GatherLane& g)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float i = fmaf(Rm[3 * a + 0], g.x4, fmaf(Rm[3 * a + 1], g.y4, fmaf(Rm[3 * a + 2], g.z4, 3.5f)));
+        h.i0[a][0] = i;
+        h.i0[a][1] = fmaf(4.0f, Rm[3 * a + 1], i);
+        h.dq[a] = 2.0f * Rm[3 * a + 2];
+    }
+}
+
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+
+// base index (as a float, 0..6) and the hat weights of rows j, j+1 for sample coordinate i
+__device__ __forceinline__ void hat_axis(float i, float& jf, float& w0, float& w1)
+{
+    jf = __builtin_amdgcn_fmed3f(floorf(i), 0.0f, 6.0f);
+    const float u = i - jf;
+    w0 = clamp01(1.0f - fabsf(u));
+    w1 = clamp01(1.0f - fabsf(u - 1.0f));
+}
+
+// Weights and base row of one voxel (pass p of quarter Q).
+struct HatVoxel {
+    float w[8];        // corner weights, order (dz, dy, dx)
+    const char* base;  // row (jz, jy, jx) of the source image; corner n sits at base + kHatOff(n)
+};
+
+__device__ __forceinline__ constexpr int hat_off(int n)
+{
+    return ((n & 1) ? 4 * kSrcStride : 0) + ((n & 2) ? 4 * 8 * kSrcStride : 0) + ((n & 4) ? 4 * kSrcPlaneRows * kSrcStride : 0);
+}
+
+template <int Q>
+__device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const GatherHyp& h, int p)
+{
+    float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
+    hat_axis(fmaf((float)Q, h.dq[0], h.i0[0][p]), jx, wx0, wx1);
+    hat_axis(fmaf((float)Q, h.dq[1], h.i0[1][p]), jy, wy0, wy1);
+    hat_axis(fmaf((float)Q, h.dq[2], h.i0[2][p]), jz, wz0, wz1);
+    const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
+    v.w[0] = w00 * wx0; v.w[1] = w00 * wx1; v.w[2] = w01 * wx0; v.w[3] = w01 * wx1;
+    v.w[4] = w10 * wx0; v.w[5] = w10 * wx1; v.w[6] = w11 * wx0; v.w[7] = w11 * wx1;
+    // byte offset of row (jz, jy, jx): exact in fp32 (< 2^24), one conversion
+    const float af = fmaf(jz, (float)(4 * kSrcPlaneRows * kSrcStride),
+                          fmaf(jy, (float)(4 * 8 * kSrcStride), jx * (float)(4 * kSrcStride)));
+    v.base = reinterpret_cast<const char*>(srcT) + (unsigned)af;
+}
+
+// Quarter Q of the rotated volume into `buf`.  The two voxels of a lane (passes 0, 1) are blended as ONE stream
+// of 16 corner steps whose source rows are requested kHatDepth steps ahead (a ring of 4 x ds_read_b128 per
+// step): hipcc on its own keeps only 2-3 reads in flight, about a third of an LDS round trip under bank
+// conflicts, and leaves the rest to the partner wave.  The stream is cut in two so that its head can be issued
+// from inside the PREVIOUS quarter's GEMM (hat_prologue: coordinates, weights and the first kHatDepth row
+// requests, placed ahead of that GEMM's last MFMA chunk), which hides the gather's start-up round trip as well.
+#ifndef AHV_HAT_DEPTH
+#define AHV_HAT_DEPTH 6
+#endif
+constexpr int kHatDepth = AHV_HAT_DEPTH;
+static_assert(kHatDepth >= 1 && kHatDepth <= 8, "the prologue requests rows of pass 0 only");
+
+struct HatState {
+    HatVoxel vx[2];
+    f32x4 ring[kHatDepth][4];
+};
+
+template <int S>
+__device__ __forceinline__ void hat_request(HatState& st)
+{
+    const f32x4* row = reinterpret_cast<const f32x4*>(st.vx[S >> 3].base + hat_off(S & 7));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st.ring[S % kHatDepth][j] = row[j];
+}
+
+template <int S, int END>
+struct HatRequests {
+    static __device__ __forceinline__ void run(HatState& st)
+    {
+        hat_request<S>(st);
+        HatRequests<S + 1, END>::run(st);
+    }
+};
+template <int END>
+struct HatRequests<END, END> {
+    static __device__ __forceinline__ void run(HatState&) {}
+};
+
+template <int Q>
+__device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
+{
+    hat_voxel<Q>(st.vx[0], srcT, h, 0);
+    HatRequests<0, kHatDepth>::run(st);
+    hat_voxel<Q>(st.vx[1], srcT, h, 1);
+}
+
+template <int S>
+struct HatSteps {
+    static __device__ __forceinline__ void run(HatState& st, f32x2 (&o)[8], float* dst0, float* dst1)
+    {
+        constexpr int p = S >> 3, n = S & 7;
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2 wn = {st.vx[p].w[n], st.vx[p].w[n]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = st.ring[S % kHatDepth][j];
+            const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            if (n == 0) {
+                o[2 * j] = lo * wn;
+                o[2 * j + 1] = hi * wn;
+            } else {
+                o[2 * j] = __builtin_elementwise_fma(lo, wn, o[2 * j]);
+                o[2 * j + 1] = __builtin_elementwise_fma(hi, wn, o[2 * j + 1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (S + kHatDepth < 16) hat_request<(S + kHatDepth < 16 ? S + kHatDepth : 0)>(st);
+        if (n == 7) {
+            float* dst = p ? dst1 : dst0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c * 128] = o[c >> 1][c & 1];
+        }
+        HatSteps<S + 1>::run(st, o, dst0, dst1);
+    }
+};
+template <>
+struct HatSteps<16> {
+    static __device__ __forceinline__ void run(HatState&, f32x2 (&)[8], float*, float*) {}
+};
+
+// the 16 blend steps of a quarter whose prologue has been issued
+__device__ __forceinline__ void hat_body(HatState& st, float* buf, int lane)
+{
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+    f32x2 o[8];
+#if AHV_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    HatSteps<0>::run(st, o, buf + qoff(a0, 2 * b1 + b0, e), buf + qoff(a0, 4 + 2 * b1 + b0, e));
+#if AHV_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+}  // namespace ahv
+
+namespace ahv {
+
+// ---------------------------------------------------------------------------------------------------------
+// GEMM1 on quarter Q, software-pipelined by hand one chunk deep.  hipcc schedules gemm1_quarter_lds just in
+// time (fragment reads, s_waitcnt, 8 MFMAs, next reads ...): every group of MFMAs starts with an exposed LDS
+// round trip that only the partner wave can cover.  Here the 192 MFMAs are cut into 12 chunks of 16; the A
+// fragments (LDS table) and B operands (quarter image) of chunk k+1 are requested before the MFMAs of chunk k
+// are issued (512 matrix-pipe cycles, several LDS latencies), and sched_barrier keeps hipcc from sinking the
+// reads back to their uses.  Same MFMAs, same order per accumulator as gemm1_quarter_lds: bit-identical sums.
+//   chunks 0-3: x slab, channels 4k..4k+3;  4-7: y slab;  8-11: z slab, channel pairs cpp = k - 8.
+// ---------------------------------------------------------------------------------------------------------
+struct G1Chunk {
+    f32x4 a[4];
+    float b[8];
+};
+
+template <int Q, int K>
+__device__ __forceinline__ void g1_load(G1Chunk& ck, const f32x4* T, const float* buf, int i0, int j, int kq)
+{
+    if (K < 8) {
+        const int c0 = 4 * (K & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i;
+            ck.a[i] = T[((K < 4 ? 0 : 16) + c) * 64];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                ck.b[2 * i + hh] = (K < 4) ? buf[c * 128 + qoff(i0, j, 4 * hh + kq)]    // x slab: k = (c, w)
+                                           : buf[c * 128 + qoff(i0, 4 * hh + kq, j)];   // y slab: k = (c, h)
+        }
+    } else {
+        const int cpp = K - 8;
+        ck.a[0] = T[(32 + 4 * Q + cpp) * 64];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                ck.b[4 * ci + t] = buf[(2 * (2 * cpp + ci) + (kq >> 1)) * 128 + qoff(kq & 1, 2 * t + i0, j)];
+    }
+}
+
+template <int Q, int K>
+__device__ __forceinline__ void g1_mfma(f32x4 (&acc)[2][4], const G1Chunk& ck)
+{
+    if (K < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                acc[0][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[i][2 * hh + 0], ck.b[2 * i + hh], acc[0][Q], 0, 0, 0);
+                acc[1][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[i][2 * hh + 1], ck.b[2 * i + hh], acc[1][Q], 0, 0, 0);
+            }
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[0][2 * ci + 0], ck.b[4 * ci + t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[0][2 * ci + 1], ck.b[4 * ci + t], acc[1][t], 0, 0, 0);
+            }
+    }
+}
+
+// `hook` runs once, ahead of the MFMAs of chunk kG1HookChunk (the fused scorer passes the next quarter's
+// gather prologue, whose LDS round trip then elapses under the remaining MFMAs of this quarter).
+#ifndef AHV_G1_HOOK
+#define AHV_G1_HOOK 10
+#endif
+constexpr int kG1HookChunk = AHV_G1_HOOK;
+
+template <int Q, int K>
+struct G1Pipe {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[2][4], G1Chunk& cur, const f32x4* T, const float* buf,
+                                               int i0, int j, int kq, Hook& hook)
+    {
+        G1Chunk nxt;
+        if (K + 1 < 12) g1_load<Q, K + 1>(nxt, T, buf, i0, j, kq);
+        if (K == kG1HookChunk) {
+#if AHV_PRIO == 3
+            __builtin_amdgcn_s_setprio(1);
+#endif
+            hook();
+#if AHV_PRIO == 3
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        g1_mfma<Q, K>(acc, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (K + 1 < 12) G1Pipe<Q, K + 1>::run(acc, nxt, T, buf, i0, j, kq, hook);
+    }
+};
+
+template <int Q>
+struct G1Pipe<Q, 12> {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&)[2][4], G1Chunk&, const f32x4*, const float*, int, int, int, Hook&) {}
+};
+
+template <int Q, typename Hook>
+__device__ __forceinline__ void gemm1_quarter_pipe(f32x4 (&acc)[2][4], const float* table, const float* buf, int lane,
+                                                   Hook hook)
+{
+    const int n = lane & 15, kq = lane >> 4;
+    const int i0 = n >> 3, j = n & 7;
+    const f32x4* T = reinterpret_cast<const f32x4*>(table) + lane;
+    G1Chunk first;
+    g1_load<Q, 0>(first, T, buf, i0, j, kq);
+#if AHV_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#elif AHV_PRIO >= 3   // everything but GEMM1 runs at priority 1 (set once before the hypothesis loop)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    G1Pipe<Q, 0>::run(acc, first, T, buf, i0, j, kq, hook);
+#if AHV_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#elif AHV_PRIO >= 3
+    __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 }  // namespace ahv

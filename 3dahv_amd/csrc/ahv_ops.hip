@@ -260,7 +260,6 @@ __global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         f32x2 cur[16], nxt[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) cur[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(V + c * 512));
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
         }                                                                                                   \
         _Pragma("unroll") for (int c = 0; c < 16; ++c) { buf[c * 128 + o0] = cur[c][0]; buf[c * 128 + o1] = cur[c][1]; } \
         wave_lds_fence();                                                                                   \
-        gemm1_quarter_lds<Q>(acc, lds_w1, buf, lane);                                                       \
+        gemm1_quarter_pipe<Q>(acc, lds_w1, buf, lane, [] {});                                               \
         wave_lds_fence();                                                                                   \
         _Pragma("unroll") for (int c = 0; c < 16; ++c) cur[c] = nxt[c];
         AHV_F3_QUARTER(0)

@@ -18,7 +18,22 @@
 
 namespace ahv {
 
-// lane instead of four times and 6 cross-lane moves replace 20.  Result uniform (read from lane 63).
+__device__ __forceinline__ float swap_add32(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float swap_add16(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// F.normalize(dim=1), dot with the unit-norm target, mean over the 64 positions (modules/modules.py:122,
+// test_co3d.py:143) as a reduce-scatter: a lane holds 8 of the 32 channels of position (16t + lane&15) for the
+// four tiles t; after two exchange steps lane (col, kq) owns the complete sums of ONE position (tile kq, column
+// col), so the normalisation runs once per lane.  Result uniform (read from lane 63).
 __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x4 (&tg)[4][2], int lane)
 {
     float ss[4], dt[4];
@@ -35,16 +50,19 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
                 dt[t] += x * tg[t][m2][r];
             }
     }
-    const bool up = (lane & 32) != 0;  // upper half keeps tiles 2,3 and hands over 0,1
+    // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: with
+    // (first, second) = (tile i, tile i+2) every lane then holds, in the two registers, its own half-sum of the
+    // tile it keeps (i below lane 32, i+2 above) and the partner lane's half-sum of that same tile.  One VALU
+    // instruction per exchange, no LDS crossbar round trip (ds_bpermute) and no selects.
     float s2[2], d2[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        s2[i] = (up ? ss[2 + i] : ss[i]) + __shfl_xor(up ? ss[i] : ss[2 + i], 32, 64);
-        d2[i] = (up ? dt[2 + i] : dt[i]) + __shfl_xor(up ? dt[i] : dt[2 + i], 32, 64);
+        s2[i] = swap_add32(ss[i], ss[2 + i]);
+        d2[i] = swap_add32(dt[i], dt[2 + i]);
     }
-    const bool odd = (lane & 16) != 0;  // odd rows keep the second tile of their pair
-    const float s1 = (odd ? s2[1] : s2[0]) + __shfl_xor(odd ? s2[0] : s2[1], 16, 64);
-    const float d1 = (odd ? d2[1] : d2[0]) + __shfl_xor(odd ? d2[0] : d2[1], 16, 64);
+    // same one level down: rows of 16 lanes, odd rows keep the second tile of their pair
+    const float s1 = swap_add16(s2[0], s2[1]);
+    const float d1 = swap_add16(d2[0], d2[1]);
     const float c = d1 / fmaxf(sqrtf(s1), 1e-12f);
     const float tot = wave_sum_dpp(c);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63)) * (1.0f / 64.0f);
@@ -96,6 +114,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     }
     DualFrags f0;
     load_dual_frags(f0, W2, b2, lane);
+    const GatherLane glane = gather_lane(lane);
     const long hstep = (long)gridDim.x * 8;
     // Diagnostic entry point only (clk != NULL): shader-clock and 100 MHz real-time stamps around this
     // workgroup's whole hypothesis loop.  The stamps go to `clk` alone; no output depends on them.
@@ -154,6 +173,9 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#if AHV_PRIO >= 3
+        if (!SPLIT) __builtin_amdgcn_s_setprio(1);
+#endif
         for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
@@ -176,38 +198,33 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #define AHV_TS(i)
 #endif
             AHV_TS(0)
-            if (SPLIT) tri_quarter_split<0>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
-            else tri_quarter<0>(buf, srcT, Rm, lane);
-            wave_lds_fence();
-            AHV_TS(1)
-            if (SPLIT) gemm1_quarter_split<0>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
-            else gemm1_quarter_lds<0>(acc, lds_w1, buf, lane);
-            wave_lds_fence();
-            AHV_TS(2)
-            if (SPLIT) tri_quarter_split<1>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
-            else tri_quarter<1>(buf, srcT, Rm, lane);
-            wave_lds_fence();
-            AHV_TS(3)
-            if (SPLIT) gemm1_quarter_split<1>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
-            else gemm1_quarter_lds<1>(acc, lds_w1, buf, lane);
-            wave_lds_fence();
-            AHV_TS(4)
-            if (SPLIT) tri_quarter_split<2>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
-            else tri_quarter<2>(buf, srcT, Rm, lane);
-            wave_lds_fence();
-            AHV_TS(5)
-            if (SPLIT) gemm1_quarter_split<2>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
-            else gemm1_quarter_lds<2>(acc, lds_w1, buf, lane);
-            wave_lds_fence();
-            AHV_TS(6)
-            if (SPLIT) tri_quarter_split<3>(reinterpret_cast<char*>(buf), srcT, Rm, lane);
-            else tri_quarter<3>(buf, srcT, Rm, lane);
-            wave_lds_fence();
-            AHV_TS(7)
-            if (SPLIT) gemm1_quarter_split<3>(acc, reinterpret_cast<const f16x8*>(lds_w1), reinterpret_cast<const char*>(buf), lane);
-            else gemm1_quarter_lds<3>(acc, lds_w1, buf, lane);
-            wave_lds_fence();
-            AHV_TS(8)
+            if constexpr (SPLIT) {
+                char* cbuf = reinterpret_cast<char*>(buf);
+                const f16x8* w1s = reinterpret_cast<const f16x8*>(lds_w1);
+                tri_quarter_split<0>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(1)
+                gemm1_quarter_split<0>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(2)
+                tri_quarter_split<1>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(3)
+                gemm1_quarter_split<1>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(4)
+                tri_quarter_split<2>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(5)
+                gemm1_quarter_split<2>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(6)
+                tri_quarter_split<3>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(7)
+                gemm1_quarter_split<3>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(8)
+            } else {
+                // gather quarter q (16 blend steps) -> GEMM1 on it; the head of quarter q+1's gather (coordinates,
+                // weights, first row requests) is issued from inside GEMM q, ahead of its last MFMA chunks
+                GatherHyp gh;
+                gather_hyp(gh, Rm, glane);
+                HatState st;
+                hat_prologue<0>(st, srcT, gh);
+                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(1)
+                gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(2)
+                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(3)
+                gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue<2>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(4)
+                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(5)
+                gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [&] { hat_prologue<3>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(6)
+                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(7)
+                gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
+            }
 
             f32x4 v[2][4];
             gemm2_dual(v, acc, f);

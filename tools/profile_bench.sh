@@ -3,7 +3,7 @@
 # (rocprofv3 --pmc must not be combined with the tracing domains other than --kernel-trace).
 # Usage (through gpurun): bash tools/profile_bench.sh <tag>
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp; export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
