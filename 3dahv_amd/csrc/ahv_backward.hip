@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
     stage_w1_table(lds_w1, W1, tid, kBwdThreads);
     DualFrags f;
     load_dual_frags(f, W2, b2, lane);
+    const GatherLane glane = gather_lane(lane);
     float a2t[2][4][2];  // dr = W2^T dv: A[row = o][k = o2]: [m2][r2][m] = W2[16 m2 + 4 kq + r2][16 m + row]
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2)
@@ -133,14 +134,20 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tri_quarter<0>(buf, lds_src, Rm, lane); wave_lds_fence();
-            gemm1_quarter_lds<0>(acc, lds_w1, buf, lane); wave_lds_fence();
-            tri_quarter<1>(buf, lds_src, Rm, lane); wave_lds_fence();
-            gemm1_quarter_lds<1>(acc, lds_w1, buf, lane); wave_lds_fence();
-            tri_quarter<2>(buf, lds_src, Rm, lane); wave_lds_fence();
-            gemm1_quarter_lds<2>(acc, lds_w1, buf, lane); wave_lds_fence();
-            tri_quarter<3>(buf, lds_src, Rm, lane); wave_lds_fence();
-            gemm1_quarter_lds<3>(acc, lds_w1, buf, lane); wave_lds_fence();
+            {   // forward recompute: the fused scorer's pipelined gather / GEMM1 (ahv_dual.h)
+                GatherHyp gh;
+                gather_hyp(gh, Rm, glane);
+                HatState st;
+                hat_prologue<0>(st, lds_src, gh);
+                hat_body(st, buf, lane); wave_lds_fence();
+                gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, lds_src, gh); }); wave_lds_fence();
+                hat_body(st, buf, lane); wave_lds_fence();
+                gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue<2>(st, lds_src, gh); }); wave_lds_fence();
+                hat_body(st, buf, lane); wave_lds_fence();
+                gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [&] { hat_prologue<3>(st, lds_src, gh); }); wave_lds_fence();
+                hat_body(st, buf, lane); wave_lds_fence();
+                gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence();
+            }
             f32x4 v[2][4];
             gemm2_dual(v, acc, f);
 

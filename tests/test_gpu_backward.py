@@ -1,9 +1,15 @@
 """Backward of the fused scorer (ahv_score_hypotheses_backward_f32) against torch
 autograd through the reference's op sequence (oracle/torch_ref.py, stock torch operators) evaluated in fp64.
 Tolerance: gradients are sums over up to B*N hypotheses of fp32 terms -> 2e-4 of the largest entry.
-The cases are fixed (seeded): a pre-activation within fp32 rounding of zero makes fp32 and fp64 take different
-ReLU sub-gradients (about one element in 5e6), which moves d vol / d W1 by 1e-3..1e-2 at small N -- arithmetic, not
-implementation; none of the seeded cases contains such an element."""
+
+ReLU has a kink: a pre-activation within fp32 rounding of zero (about one element in 5e6; a B = 2 x N = 1100 case
+has 4.5e6 of them) makes an fp32 and an fp64 evaluation take different sub-gradients, which moves d vol / d W1 by
+1e-3..1e-2 -- arithmetic, not implementation.  The comparison is therefore made against
+the fp64 gradient for EVERY assignment of the ambiguous sub-gradients: the pre-activations the fp64 reference finds
+within KINK_TAU of zero are listed, the reference gradient is evaluated with each of them flipped (the gradient
+is affine in those indicator bits), the bits are fitted to the kernel's gradients by least squares and rounded, and
+the kernel must match that one reference within the unchanged tolerance.  Cases with no ambiguous element (or that
+already agree) reduce to the plain comparison."""
 import numpy as np
 import pytest
 import torch
@@ -40,6 +46,63 @@ def ref_scores(vs, ft, R, W1, W2, b2):
     return torch.stack(out)
 
 
+KINK_TAU = 2e-6   # |pre-activation| below this (fp64 reference; typical magnitude ~1) = ambiguous sub-gradient
+KINK_MAX = 64     # reference backward passes spent on one case
+
+
+def ref_scores_masked(vs, ft, R, W1, W2, b2, flips=None):
+    """ref_scores with the ReLU written as u * mask, mask = (u > 0) XOR flips; returns (scores, list of u)."""
+    from oracle import torch_ref
+    import torch.nn.functional as F
+    out, us = [], []
+    for b in range(vs.shape[0]):
+        Rb = R[b] if R.dim() == 4 else R
+        n = Rb.shape[0]
+        vol = torch_ref.rotate_volume(vs[b][None].expand(n, -1, -1, -1, -1), Rb)
+        m, c, d, h, w = vol.shape
+        slabs = torch.cat([vol.permute(0, 1, 4, 2, 3).reshape(m, c * w, d, h), vol.permute(0, 1, 3, 2, 4).reshape(m, c * h, d, w),
+                           vol.reshape(m, c * d, h, w)], dim=1)                       # modules/modules.py:115-118
+        u = F.conv2d(slabs, W1.reshape(32, 384, 1, 1))
+        mask = (u.detach() > 0)
+        if flips is not None:
+            mask = mask ^ flips[b]
+        v = F.conv2d(u * mask, W2.reshape(32, 32, 1, 1), b2)
+        f = F.normalize(v, p=2, dim=1).flatten(2)
+        out.append((f * ft[b][None]).sum(dim=1).mean(dim=-1))
+        us.append(u.detach())
+    return torch.stack(out), us
+
+
+def kink_aware_errors(got, vs, ft, R, W1, W2, b2, gs):
+    """max relative error of every gradient against the best assignment of the ambiguous ReLU sub-gradients."""
+    def grads(flips):
+        leaves = [x.double().requires_grad_(True) for x in (vs, ft, W1, W2, b2)]
+        s, us = ref_scores_masked(leaves[0], leaves[1], R.double(), leaves[2], leaves[3], leaves[4], flips)
+        return torch.autograd.grad(s, leaves, grad_outputs=gs.double()), us
+    base, us = grads(None)
+    amb = [(b, idx) for b, u in enumerate(us) for idx in torch.nonzero(u.abs() < KINK_TAU).tolist()]
+    errs0 = [relerr(a, r.reshape(a.shape)) for a, r in zip(got, base)]
+    if not amb or max(errs0) < GRAD_RTOL:
+        return errs0, len(amb), 0
+    assert len(amb) <= KINK_MAX, "too many near-kink pre-activations: %d" % len(amb)
+    deltas = []
+    for b, idx in amb:  # gradient change when this one sub-gradient flips
+        flips = [torch.zeros_like(u, dtype=torch.bool) for u in us]
+        flips[b][tuple(idx)] = True
+        g, _ = grads(flips)
+        deltas.append([x - y for x, y in zip(g, base)])
+    # the gradient is affine in the flip bits: least squares for the bits, rounded to {0, 1}
+    flat = lambda ts: torch.cat([t.reshape(-1).double() for t in ts])
+    A = torch.stack([flat(d) for d in deltas], dim=1)
+    rhs = flat([a.double() - r.reshape(a.shape) for a, r in zip(got, base)])
+    bits = (torch.linalg.lstsq(A, rhs[:, None]).solution[:, 0] > 0.5)
+    ref = [x.clone() for x in base]
+    for i in torch.nonzero(bits).flatten().tolist():
+        ref = [x + d for x, d in zip(ref, deltas[i])]
+    errs = [relerr(a, r.reshape(a.shape)) for a, r in zip(got, ref)]
+    return errs, len(amb), int(bits.sum())
+
+
 def make_case(ahv, dev, B, N, per_sample, seed):
     g = load_golden("score_n128")
     rng = np.random.RandomState(seed)
@@ -60,13 +123,22 @@ def relerr(got, ref):
 def test_backward_matches_fp64_autograd(ops, ahv, dev, B, N, per_sample):
     vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, B, N, per_sample, 5 + B + N)
     got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
-    leaves = [x.double().requires_grad_(True) for x in (vs, ft, W1, W2, b2)]
-    s = ref_scores(leaves[0], leaves[1], R.double(), leaves[2], leaves[3], leaves[4])
-    ref = torch.autograd.grad(s, leaves, grad_outputs=gs.double())
+    errs, n_amb, combo = kink_aware_errors(got, vs, ft, R, W1, W2, b2, gs)
     names = ["vol_src", "feat_tgt", "W1", "W2", "b2"]
-    errs = {k: relerr(a, b.reshape(a.shape)) for k, a, b in zip(names, got, ref)}
-    print(B, N, per_sample, {k: "%.1e" % v for k, v in errs.items()})
-    assert all(v < GRAD_RTOL for v in errs.values()), errs
+    errs = dict(zip(names, errs))
+    print(B, N, per_sample, {k: "%.1e" % v for k, v in errs.items()}, "near-kink pre-activations:", n_amb, "flipped:", combo)
+    assert all(v < GRAD_RTOL for v in errs.values()), (errs, n_amb)
+
+
+@pytest.mark.parametrize("seed", [1101, 1102, 1103, 1106])
+def test_backward_large_case_any_seed(ops, ahv, dev, seed):
+    """B = 2 x N = 1100 on seeds whose plain fp64 comparison trips over a ReLU kink: the kink-aware reference must
+    explain the kernel's gradients to the same tolerance (no seed picking)."""
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, 2, 1100, False, seed)
+    got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    errs, n_amb, combo = kink_aware_errors(got, vs, ft, R, W1, W2, b2, gs)
+    print(seed, ["%.1e" % e for e in errs], "near-kink:", n_amb, "flipped:", combo)
+    assert max(errs) < GRAD_RTOL, (errs, n_amb)
 
 
 def test_autograd_function_trains_like_torch(ops, ahv, dev):
