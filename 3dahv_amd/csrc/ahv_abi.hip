@@ -28,7 +28,7 @@ hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_
 hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 hipError_t launch_so3_grid(int64_t, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
-                                 const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*,
+                                 const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*, float*,
                                  float*, float*, int, hipStream_t);
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
@@ -291,8 +291,11 @@ int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, 
 size_t ahv_score_hypotheses_backward_workspace_bytes(int B, int64_t N)
 {
     if (B <= 0 || N <= 0) return 0;
-    // dL/du per hypothesis + one max|du| word per sample (rounded up to 16 bytes)
-    return sizeof(float) * (2048 * (size_t)B * (size_t)N + (((size_t)B + 3) & ~(size_t)3));
+    // dL/du per hypothesis + one max|du| word per sample (rounded up to 16 bytes) + one partial dW1 (32 x 384) per
+    // workgroup of the persistent grid (at most one per CU; 1024 covers any device if the query fails)
+    const int cu = cu_count();
+    const size_t wgs = cu > 0 ? (size_t)cu : 1024;
+    return sizeof(float) * (2048 * (size_t)B * (size_t)N + (((size_t)B + 3) & ~(size_t)3) + wgs * 32 * 384);
 }
 
 int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tgt, const float* R,
@@ -321,6 +324,7 @@ int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tg
     hipError_t e = ahv::launch_score_backward(vol_src, feat_tgt, R, r_batch_stride, W1, W2, b2, B, N, grad_scores,
                                               static_cast<float*>(workspace),
                                               reinterpret_cast<unsigned*>(static_cast<float*>(workspace) + 2048 * (size_t)B * (size_t)N),
+                                              static_cast<float*>(workspace) + 2048 * (size_t)B * (size_t)N + (((size_t)B + 3) & ~(size_t)3),
                                               grad_vol_src, grad_feat_tgt, grad_W1, grad_W2, grad_b2, cu,
                                               static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("score_backward: launch", e);

@@ -30,7 +30,11 @@ __device__ __forceinline__ int dimg(int o, int pos) { return o * 64 + (pos ^ ((o
 
 __device__ __forceinline__ void lds_add_i64(long long* p, long long v)
 {
+#ifdef AHV_DIAG_NO_ATOMICS  // diagnostic build of tools/kbench_bwd only (wrong results): price of the LDS atomics
+    asm volatile("" ::"v"(p), "v"(v));
+#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 
 // |x| < 2^40 -> nearest integer as int64 (there is no f32 -> i64 convert): add 1.5 * 2^52 in fp64, where one ulp
@@ -281,254 +285,610 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 //                                     sample's volume gradient, flushed once per sample
 // ---------------------------------------------------------------------------------------------------
 
-// X image of 2a: plane c rotated by 4c floats, so that the z slab's B operand (16 lanes = 16 channels of one
-// voxel) spreads over 8 banks instead of one; all other accesses have c uniform per instruction.
-__device__ __forceinline__ int xoff(int c, int a0, int b, int e) { return c * 128 + ((qoff(a0, b, e) + 4 * c) & 127); }
+// LDS images of 2a, both LINEAR with a small pad so that every access is "per-lane base + compile-time constant"
+// (one address register, immediate offsets) and the MFMA operand reads are at worst 2-way bank conflicts:
+//   X[c][voxel = a0*64 + b*8 + e], kXwStride = 129 floats per channel plane (odd: the z slab's B operand, 16 lanes =
+//   16 channels of one voxel, lands on 16 different banks);
+//   du[o][pos], kDuStride = 68 floats per row (multiple of 4: the image is filled with aligned float4 stores).
+constexpr int kXwStride = 129;
+constexpr int kXwFloats = 16 * kXwStride;
+constexpr int kDuStride = 68;
+constexpr int kDuFloats = 32 * kDuStride;
 
-__device__ __forceinline__ void load_du_image(float* dbuf, const float* __restrict__ du_hyp, int lane)
+struct DuImage {  // one hypothesis's du (2048 floats) as the wave loads it: 8 coalesced float4 per lane
+    f32x4 v[8];
+};
+
+__device__ __forceinline__ void load_du_image(DuImage& d, const float* __restrict__ du_hyp, int lane)
 {
     const f32x4* src = reinterpret_cast<const f32x4*>(du_hyp);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {  // coalesced float4 loads, aligned float4 stores (dimg keeps groups of 4 together)
+    for (int i = 0; i < 8; ++i) d.v[i] = __builtin_nontemporal_load(src + i * 64 + lane);
+}
+
+__device__ __forceinline__ void store_du_image(float* dbuf, const DuImage& d, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
         const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
-        *reinterpret_cast<f32x4*>(dbuf + dimg(o, pos)) = src[i * 64 + lane];
+        *reinterpret_cast<f32x4*>(dbuf + o * kDuStride + pos) = d.v[i];
     }
 }
 
+// Kernel 2a runs TWO waves per SIMD.  The 192 accumulator registers of dW1 are what kept it at one wave per
+// SIMD, where every LDS round trip and every VALU burst is exposed (the no-MFMA build of the one-wave kernel still
+// took 0.75 of its 1.0 ms).  The OUTPUT is split instead: wave role r = wave / 4 owns the dW1 rows of m-tile r
+// (96 accumulator registers) and needs only du rows 16 r .. 16 r + 15; waves w and w + 4 (same SIMD) walk the
+// same hypotheses independently -- no barrier, each with its own X image -- so each hypothesis is gathered twice
+// (the blend is ~1/6 of the per-hypothesis work) and in exchange the two waves of a SIMD drift apart and cover
+// each other's latencies exactly as in the forward kernel.  (Sharing one gather per pair behind workgroup
+// barriers was tried first: the barriers put both waves of a SIMD in the same phase and it ran 10 % SLOWER than
+// one wave per SIMD.)
+template <int DEPTH>
+struct HatRing {
+    f32x4 slot[DEPTH][4];
+};
+
+template <int S, int DEPTH>
+__device__ __forceinline__ void hat_pass_request(HatRing<DEPTH>& rg, const HatVoxel& vx)
+{
+    const f32x4* row = reinterpret_cast<const f32x4*>(vx.base + hat_off(S & 7));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rg.slot[S % DEPTH][j] = row[j];
+}
+
+template <int S, int DEPTH>
+struct HatPassSteps {  // the 8 corner steps of ONE voxel, source rows requested DEPTH steps ahead (cf. HatSteps, ahv_dual.h)
+    static __device__ __forceinline__ void run(HatRing<DEPTH>& rg, const HatVoxel& vx, f32x2 (&o)[8])
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2 wn = {vx.w[S], vx.w[S]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = rg.slot[S % DEPTH][j];
+            const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            if (S == 0) {
+                o[2 * j] = lo * wn;
+                o[2 * j + 1] = hi * wn;
+            } else {
+                o[2 * j] = __builtin_elementwise_fma(lo, wn, o[2 * j]);
+                o[2 * j + 1] = __builtin_elementwise_fma(hi, wn, o[2 * j + 1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (S + DEPTH < 8) hat_pass_request<(S + DEPTH < 8 ? S + DEPTH : 0), DEPTH>(rg, vx);
+        HatPassSteps<S + 1, DEPTH>::run(rg, vx, o);
+    }
+};
+template <int DEPTH>
+struct HatPassSteps<8, DEPTH> {
+    static __device__ __forceinline__ void run(HatRing<DEPTH>&, const HatVoxel&, f32x2 (&)[8]) {}
+};
+
+template <int DEPTH, int ROW>
+__device__ __forceinline__ void hat_one_pass(const HatVoxel& vx, float* dst)
+{
+    HatRing<DEPTH> rg;
+    f32x2 o[8];
+    hat_pass_request<0, DEPTH>(rg, vx);
+    if (DEPTH > 1) hat_pass_request<(DEPTH > 1 ? 1 : 0), DEPTH>(rg, vx);
+    if (DEPTH > 2) hat_pass_request<(DEPTH > 2 ? 2 : 0), DEPTH>(rg, vx);
+    if (DEPTH > 3) hat_pass_request<(DEPTH > 3 ? 3 : 0), DEPTH>(rg, vx);
+    static_assert(DEPTH <= 4, "prologue written out for up to four slots");
+    HatPassSteps<0, DEPTH>::run(rg, vx, o);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[c * ROW] = o[c >> 1][c & 1];
+}
+
+// dW1 rows of ONE m-tile += du X^T on quarter Q, software-pipelined one chunk deep (operands of chunk k+1 requested
+// before the MFMAs of chunk k; sched_barrier keeps hipcc from sinking the reads back to their uses).
+//   chunks 0-7:  x and y slabs, k-step s = K / 2 (positions pl = 4 s + kq of tile Q), four k-tiles: 1 A value,
+//                8 B values (4 k-tiles x {x, y}), 8 MFMAs
+//   chunks 8-11: z slab, k-steps s = 4 (K-8) .. +3 (all 64 positions): 4 A values, 8 B values, 8 MFMAs
+struct W1Chunk {
+    float a[4];
+    float b[8];
+};
+constexpr int kW1Chunks = 12;  // 8 half-steps of the x / y slabs + 4 groups of the z slab
+
+template <int Q, int K>
+__device__ __forceinline__ void w1_load(W1Chunk& ck, const float* da, const float* bx, const float* by, const float* bz)
+{
+    // da = dbuf + (16 m + row)*kDuStride + kq : A[row = o][k = pos];   bx = xbuf + i0*kXwStride + 8 kq + j;
+    // by = xbuf + i0*kXwStride + kq + 8 j;   bz = xbuf + n*kXwStride + kq
+    if (K < 8) {
+        constexpr int s = K >> 1, k0 = 4 * (K & 1);  // k-step s (pa = s >> 1, pb = 4 (s & 1) + kq), k-tiles k0 .. k0 + 3
+        ck.a[0] = da[16 * Q + 4 * s];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ck.b[2 * i] = bx[2 * (k0 + i) * kXwStride + (s >> 1) * 64 + 32 * (s & 1)];     // X[c = 2 kt + i0][(pa, pb, e = j)]
+            ck.b[2 * i + 1] = by[2 * (k0 + i) * kXwStride + (s >> 1) * 64 + 4 * (s & 1)];  // X[c = 2 kt + i0][(pa, b = j, pb)]
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = 4 * (K - 8) + i;
+            ck.a[i] = da[4 * s];
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0) ck.b[2 * i + a0] = bz[a0 * 64 + 4 * s];  // X[c = n][voxel = a0*64 + 4 s + kq]
+        }
+    }
+}
+
+template <int Q, int K>
+__device__ __forceinline__ void w1_mfma(f32x4 (&ax)[8], f32x4 (&ay)[8], f32x4 (&az)[4][2], const W1Chunk& ck)
+{
+#ifdef AHV_DIAG_W1_NO_MFMA  // diagnostic build of tools/kbench_bwd only (wrong results)
+    asm volatile("" ::"v"(ck.a[0]), "v"(ck.a[3]), "v"(ck.b[0]), "v"(ck.b[1]), "v"(ck.b[7]));
+#else
+    if (K < 8) {
+        constexpr int k0 = 4 * (K & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ax[k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[0], ck.b[2 * i], ax[k0 + i], 0, 0, 0);
+            ay[k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[0], ck.b[2 * i + 1], ay[k0 + i], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0)
+                az[Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[i], ck.b[2 * i + a0], az[Q][a0], 0, 0, 0);
+    }
+#endif
+}
+
+template <int Q, int K>
+struct W1Pipe {
+    static __device__ __forceinline__ void run(f32x4 (&ax)[8], f32x4 (&ay)[8], f32x4 (&az)[4][2], W1Chunk& cur,
+                                               const float* da, const float* bx, const float* by, const float* bz)
+    {
+        W1Chunk nxt;
+        if (K + 1 < kW1Chunks) w1_load<Q, K + 1>(nxt, da, bx, by, bz);
+        __builtin_amdgcn_sched_barrier(0);
+        w1_mfma<Q, K>(ax, ay, az, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (K + 1 < kW1Chunks) W1Pipe<Q, K + 1>::run(ax, ay, az, nxt, da, bx, by, bz);
+    }
+};
 template <int Q>
-__device__ __forceinline__ void bwd_w1_quarter(f32x4 (&ax)[2][8], f32x4 (&ay)[2][8], f32x4 (&az)[2][4][2],
-                                               const float* dbuf, float* xbuf, const float* srcT, const float* Rm,
-                                               int lane)
+struct W1Pipe<Q, kW1Chunks> {
+    static __device__ __forceinline__ void run(f32x4 (&)[8], f32x4 (&)[8], f32x4 (&)[4][2], W1Chunk&, const float*,
+                                               const float*, const float*, const float*) {}
+};
+
+template <int Q>
+__device__ __forceinline__ void bwd_w1_quarter(f32x4 (&ax)[8], f32x4 (&ay)[8], f32x4 (&az)[4][2], const float* dbuf,
+                                               const float* xbuf, int lane)
 {
     const int n = lane & 15, kq = lane >> 4, row = lane & 15;
     const int i0 = n >> 3, j = n & 7;
-    {   // gather quarter Q (same lane -> voxel map as tri_quarter) into the rotated-plane image
-        const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
-        const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
-        const float z = (2.0f * (2 * Q + a0) + 1.0f) * 0.125f - 1.0f;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int b = 4 * p + 2 * b1 + b0;
-            const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
-            TriCoefP k;
-            tri_coef_ptr(k, srcT, Rm, x, y, z);
-            float o[16];
-            tri_blend_ptr(o, k);
-            const int q0 = qoff(a0, b, e);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) xbuf[c * 128 + ((q0 + 4 * c) & 127)] = o[c];
-        }
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {  // x and y slabs: the 16 positions of tile Q, four per k-step
-        const int pl = 4 * s + kq, pa = pl >> 3, pb = pl & 7;
-        const float a0v = dbuf[dimg(row, 16 * Q + pl)], a1v = dbuf[dimg(16 + row, 16 * Q + pl)];
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            const float bx = xbuf[xoff(2 * kt + i0, pa, pb, j)];  // X[k = (c, e = j)][pos = (a0, b)]
-            ax[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bx, ax[0][kt], 0, 0, 0);
-            ax[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bx, ax[1][kt], 0, 0, 0);
-            const float by = xbuf[xoff(2 * kt + i0, pa, j, pb)];  // X[k = (c, b = j)][pos = (a0, e)]
-            ay[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, by, ay[0][kt], 0, 0, 0);
-            ay[1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, by, ay[1][kt], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {  // z slab: all 64 positions (b, e); k = (c = column, a0)
-        const int pl = 4 * s + kq;
-        const float a0v = dbuf[dimg(row, pl)], a1v = dbuf[dimg(16 + row, pl)];
-#pragma unroll
-        for (int a0 = 0; a0 < 2; ++a0) {
-            const float bz = xbuf[xoff(n, a0, pl >> 3, pl & 7)];
-            az[0][Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bz, az[0][Q][a0], 0, 0, 0);
-            az[1][Q][a0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bz, az[1][Q][a0], 0, 0, 0);
-        }
-    }
-    wave_lds_fence();
+    const float* da = dbuf + row * kDuStride + kq;  // the wave's 16 du rows
+    const float* bx = xbuf + i0 * kXwStride + 8 * kq + j;
+    const float* by = xbuf + i0 * kXwStride + kq + 8 * j;
+    const float* bz = xbuf + n * kXwStride + kq;
+    W1Chunk first;
+    w1_load<Q, 0>(first, da, bx, by, bz);
+    W1Pipe<Q, 0>::run(ax, ay, az, first, da, bx, by, bz);
 }
 
-__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_w1_kernel(
+// quarter Q of the rotated volume into this wave's X image, one pass (voxel) after the other
+template <int Q>
+__device__ __forceinline__ void w1_gather(float* xbuf, const float* srcT, const GatherHyp& gh, int lane)
+{
+#ifdef AHV_DIAG_W1_NO_GATHER  // diagnostic build of tools/kbench_bwd only (wrong results)
+    asm volatile("" ::"v"(xbuf), "v"(lane));
+#else
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+    float* d0 = xbuf + a0 * 64 + (2 * b1 + b0) * 8 + e;
+    __builtin_amdgcn_s_setprio(1);  // the gathering wave is latency-bound, its partner streams MFMAs (ahv_dual.h)
+    HatVoxel vx;
+    hat_voxel<Q>(vx, srcT, gh, 0);
+    hat_one_pass<3, kXwStride>(vx, d0);
+    hat_voxel<Q>(vx, srcT, gh, 1);
+    hat_one_pass<3, kXwStride>(vx, d0 + 32);
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+constexpr int kW1Threads = 512;
+constexpr int kDuHalfFloats = 16 * kDuStride;
+
+__global__ __launch_bounds__(kW1Threads, 2) void score_backward_w1_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ R, long r_batch_stride, int B, long N,
-    const float* __restrict__ du_ws, float* __restrict__ grad_W1)
+    const float* __restrict__ du_ws, float* __restrict__ dw1_partials)
 {
     __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
-    __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];
-    __shared__ __attribute__((aligned(16))) float lds_x[4 * kQuarterFloats];
+    // per wave: du rows 16 role .. 16 role + 15 (local rows 0 .. 15) and the X image; after the hypothesis loop the
+    // same pool is the scratch of the in-workgroup reduction of the accumulators
+    __shared__ __attribute__((aligned(16))) float lds_pool[8 * kDuHalfFloats + 8 * kXwFloats];
+    static_assert(8 * kDuHalfFloats + 8 * kXwFloats >= 4 * 96 * 64, "reduction scratch");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave & 3, role = wave >> 2;  // waves w and w + 4 share a SIMD and a hypothesis list
     const int n = lane & 15, kq = lane >> 4;
-    float* dbuf = lds_du + wave * 2048;
-    float* xbuf = lds_x + wave * kQuarterFloats;
-    f32x4 ax[2][8], ay[2][8], az[2][4][2];
+    float* dbuf = lds_pool + wave * kDuHalfFloats;
+    float* xbuf = lds_pool + 8 * kDuHalfFloats + wave * kXwFloats;
+    const GatherLane glane = gather_lane(lane);
+    f32x4 ax[8], ay[8], az[4][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            ax[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ay[m][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int a0 = 0; a0 < 2; ++a0) az[m][q][a0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < 8; ++kt) {
+        ax[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ay[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int a0 = 0; a0 < 2; ++a0) az[q][a0] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long hstep = (long)gridDim.x * 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kBwdThreads);
+        stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kW1Threads);
         __syncthreads();
         const float* Rb = R + (long)b * r_batch_stride;
-        for (long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y); h < N; h += hstep) {
+        long h = (long)slot * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        // this wave's half of du: float4 chunks 4 role .. 4 role + 3 of the hypothesis's 2048 floats = rows 16 role ..
+        f32x4 duh[4];
+        if (h < N) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(du_ws + ((long)b * N + h) * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) duh[i] = __builtin_nontemporal_load(src + (4 * role + i) * 64 + lane);
+        }
+        for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
-            load_du_image(dbuf, du_ws + ((long)b * N + h) * 2048, lane);
-            wave_lds_fence();
-            bwd_w1_quarter<0>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
-            bwd_w1_quarter<1>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
-            bwd_w1_quarter<2>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
-            bwd_w1_quarter<3>(ax, ay, az, dbuf, xbuf, lds_src, Rm, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // this hypothesis's du rows, requested one iteration ago
+                const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
+                *reinterpret_cast<f32x4*>(dbuf + o * kDuStride + pos) = duh[i];
+            }
+            {   // the next hypothesis's travel meanwhile
+                const long hn = (h + hstep < N) ? h + hstep : h;
+                const f32x4* src = reinterpret_cast<const f32x4*>(du_ws + ((long)b * N + hn) * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) duh[i] = __builtin_nontemporal_load(src + (4 * role + i) * 64 + lane);
+            }
+            GatherHyp gh;
+            gather_hyp(gh, Rm, glane);
+            w1_gather<0>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            bwd_w1_quarter<0>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
+            w1_gather<1>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            bwd_w1_quarter<1>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
+            w1_gather<2>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            bwd_w1_quarter<2>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
+            w1_gather<3>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            bwd_w1_quarter<3>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
         }
     }
-    // dW1[o = 16 m + 4 kq + r][k]: x: k = 16 kt + n; y: 128 + 16 kt + n; z: 256 + n*8 + 2 q + a0
+    // Reduce the four waves of each role inside the workgroup (two rounds through LDS), then ONE wave per role
+    // writes the workgroup's partial dW1 rows to the workspace; score_backward_w1_reduce_kernel sums the partials.
+    // (Flushing every wave's 96 accumulator registers with float atomics put 12.6 M atomic adds on 12 288
+    // addresses: 0.37 ms of a 1.07-ms kernel, independent of N.)
+    float* scratch = lds_pool;
+    auto put = [&](int w) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                scratch[((w * 96) + 4 * kt + r) * 64 + lane] = ax[kt][r];
+                scratch[((w * 96) + 32 + 4 * kt + r) * 64 + lane] = ay[kt][r];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[((w * 96) + 64 + 4 * (2 * q + a0) + r) * 64 + lane] = az[q][a0][r];
+    };
+    auto get = [&](int w) {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ax[kt][r] += scratch[((w * 96) + 4 * kt + r) * 64 + lane];
+                ay[kt][r] += scratch[((w * 96) + 32 + 4 * kt + r) * 64 + lane];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a0 = 0; a0 < 2; ++a0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) az[q][a0][r] += scratch[((w * 96) + 64 + 4 * (2 * q + a0) + r) * 64 + lane];
+    };
+    __syncthreads();
+    if (slot >= 2) put((slot - 2) + 2 * role);
+    __syncthreads();
+    if (slot < 2) get(slot + 2 * role);
+    __syncthreads();
+    if (slot == 1) put(role);
+    __syncthreads();
+    if (slot == 0) {
+        get(role);
+        // dW1[o = 16 role + 4 kq + r][k]: x: k = 16 kt + n; y: 128 + 16 kt + n; z: 256 + n*8 + 2 q + a0
+        float* part = dw1_partials + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (32 * 384);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float* g = grad_W1 + (16 * m + 4 * kq + r) * 384;
+            float* g = part + (16 * role + 4 * kq + r) * 384;
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) {
-                global_add(g + 16 * kt + n, ax[m][kt][r]);
-                global_add(g + 128 + 16 * kt + n, ay[m][kt][r]);
+                g[16 * kt + n] = ax[kt][r];
+                g[128 + 16 * kt + n] = ay[kt][r];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int a0 = 0; a0 < 2; ++a0) global_add(g + 256 + n * 8 + 2 * q + a0, az[m][q][a0][r]);
+                for (int a0 = 0; a0 < 2; ++a0) g[256 + n * 8 + 2 * q + a0] = az[q][a0][r];
         }
+    }
 }
 
-template <int Q>
-__device__ __forceinline__ void bwd_vol_quarter(const float (&wx)[8][8], const float (&wy)[8][8],
-                                                const float (&wz)[4][2][8], float* dbuf, float* xbuf,
-                                                long long* dV, float fx_scale, const float* Rm, int lane)
+// grad_W1[i] += sum over the workgroups' partials; blockIdx.y slices the workgroups so that the 50 MB-scale read is
+// spread over the chip (grad_W1 is zeroed beforehand; 16 float atomics per element).
+__global__ __launch_bounds__(256) void score_backward_w1_reduce_kernel(const float* __restrict__ partials, int count,
+                                                                       float* __restrict__ grad_W1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = (count + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per, hi = min(lo + per, count);
+    float acc = 0.0f;
+    for (int w = lo; w < hi; ++w) acc += partials[(size_t)w * (32 * 384) + i];
+    if (hi > lo) global_add(grad_W1 + i, acc);
+}
+
+// ---- kernel 2b building blocks -------------------------------------------------------------------------
+// dX image of kernel 2b: dX[c][voxel], voxel = a0*64 + b*8 + e, rows kVxStride floats apart.  Deliberately NOT
+// the XOR-swizzled layout of the forward's quarter image: here every access is "per-lane base + compile-time
+// constant" (MFMA-result stores, their read-modify-writes and the scatter's reads), so the 16 stores / loads of
+// an MFMA group cost one address register and immediate offsets.  With the swizzle the lane-dependent XOR had
+// to be recomputed for each of them: ~80 VALU instructions per group of 16 MFMAs, more issue time than the
+// MFMAs' own (fp32 MFMA and VALU do not overlap).  The 4-float pad spreads the four k-quads of a store over
+// the banks; the residual 4-way conflicts of the x / y read-modify-writes cost LDS cycles nobody waits for.
+constexpr int kVxStride = 132;
+constexpr int kVxFloats = 16 * kVxStride;
+
+// MFMA with the A operand taken straight from an ACCUMULATOR register.  Kernel 2b keeps the 192 W1^T fragments
+// of a lane resident for the whole launch; with one wave per SIMD they fit the 256 AGPRs, but hipcc treats AGPRs
+// as spill space and re-reads every fragment through v_accvgpr_read (+ hazard nops) in front of its MFMA --
+// 768 extra VALU-slot instructions per hypothesis that the matrix pipe cannot overlap (measured: 0.79 ms of a
+// 1.65-ms kernel for 0.38 ms of MFMA work).  The "a" constraint makes the fragment an AGPR operand of the MFMA
+// itself (legal on gfx90a+: SrcA/SrcB may be AGPRs).  hipcc neither sees the instruction inside the statement nor
+// pads its hazards, so the statement does: `s_nop 1` in front covers a VALU write of an operand immediately
+// before it (2 wait states), and the LAST MFMA of an accumulation chain is followed by 12 wait states before
+// anything may read D (8-pass MFMA -> VALU / LDS reader).  Back-to-back MFMAs on the same accumulator need none.
+__device__ __forceinline__ void mfma_areg(f32x4& d, float a_in_agpr, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "a"(a_in_agpr), "v"(b));
+}
+
+__device__ __forceinline__ void mfma_chain_end(f32x4& d0, f32x4& d1)
+{
+    asm volatile("s_nop 7\n\ts_nop 3" : "+v"(d0), "+v"(d1));
+}
+
+// du of one hypothesis as MFMA B operands, straight from the workspace into registers: lane (n, kq) holds
+// du[o = 4 sp + kq][pos = 16 t + n] for sp < 8, t < 4 -- 32 floats.  The x / y slabs of quarter Q use tile t = Q,
+// the z slab all four tiles, so no LDS image of du is needed in this kernel.
+struct DuRegs {
+    float v[4][8];
+};
+
+__device__ __forceinline__ void load_du_regs(DuRegs& d, const float* __restrict__ du_hyp, int lane)
+{
+    const float* p = du_hyp + (lane >> 4) * 64 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) d.v[t][sp] = p[sp * 256 + 16 * t];
+}
+
+// dX = W1^T du for the voxels of quarter Q into `xbuf` (linear image, kVxStride), cut into 12 groups of 16 MFMAs so
+// that the groups can be slotted between the scatter steps of the PREVIOUS quarter (bwd_vol_merged): the LDS
+// atomics of the scatter then drain underneath the matrix pipe.  Every output tile is ONE accumulator fed by 8
+// k-steps; two tiles run side by side so that consecutive MFMAs never wait for each other's result
+// (dependent-accumulator latency 40 cycles against a 32-cycle issue interval).
+//   groups 0-3  z slab, tile t = G (plain stores):  rows c = 4 kq + r; column = position (b = 2 t + i0, e = j)
+//   groups 4-7  x slab, k-tiles 2 (G-4), +1 (read-modify-write): rows k -> c = 2 kt + (kq >> 1), e = 4 (kq & 1) + r;
+//               column = position (a0 = i0, b = j)
+//   groups 8-11 y slab (read-modify-write): rows k -> c = 2 kt + (kq >> 1), b = 4 (kq & 1) + r; column = (a0 = i0, e = j)
+template <int Q, int G>
+__device__ __forceinline__ void bwd_vol_dx_group(const float (&wx)[8][8], const float (&wy)[8][8], const float (&wz)[4][2][8],
+                                                 const DuRegs& du, float* xbuf, int lane)
 {
     const int n = lane & 15, kq = lane >> 4;
     const int i0 = n >> 3, j = n & 7;
-    // ---- dX = W1^T du for the voxels of quarter Q ---------------------------------------------------
-    float bq[8];  // du[o = 4 s' + kq][pos = 16 Q + n]: B operand of the x and y slabs
+    f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+    if (G < 4) {
+        constexpr int t = G & 3;
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp) bq[sp] = dbuf[dimg(4 * sp + kq, 16 * Q + n)];
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[kt][sp], bq[sp], d, 0, 0, 0);
-        // rows k = 16 kt + 4 kq + r -> c = 2 kt + (kq >> 1), e = 4 (kq & 1) + r; column = position (a0 = i0, b = j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xbuf[xoff(2 * kt + (kq >> 1), i0, j, 4 * (kq & 1) + r)] = d[r];
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wy[kt][sp], bq[sp], d, 0, 0, 0);
-        // rows k -> c = 2 kt + (kq >> 1), b = 4 (kq & 1) + r; column = position (a0 = i0, e = j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xbuf[xoff(2 * kt + (kq >> 1), i0, 4 * (kq & 1) + r, j)] += d[r];
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float bt[8];
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) bt[sp] = dbuf[dimg(4 * sp + kq, 16 * t + n)];
-#pragma unroll
-        for (int a0 = 0; a0 < 2; ++a0) {
-            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int sp = 0; sp < 8; ++sp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[Q][a0][sp], bt[sp], d, 0, 0, 0);
-            // rows c = 4 kq + r; column = position (b = 2 t + i0, e = j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xbuf[xoff(4 * kq + r, a0, 2 * t + i0, j)] += d[r];
+        for (int sp = 0; sp < 8; ++sp) {
+            mfma_areg(d0, wz[Q][0][sp], du.v[t][sp]);
+            mfma_areg(d1, wz[Q][1][sp], du.v[t][sp]);
         }
-    }
-    wave_lds_fence();
-    // ---- dV += trilinear^T dX ----------------------------------------------------------------------------
-    // Phase A, one voxel per lane (the gather's map): the 8 corner weights and row offsets go to a small table
-    // that takes the place of the du image (reloaded at the start of the next quarter).
-    float* ctab = dbuf;
-    {
-        const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
-        const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
-        const float z = (2.0f * (2 * Q + a0) + 1.0f) * 0.125f - 1.0f;
+        mfma_chain_end(d0, d1);
+        float* zb = xbuf + 4 * kq * kVxStride + 8 * i0 + j;  // c = 4 kq + r, voxel = a0*64 + (2 t + i0)*8 + j
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int b = 4 * p + 2 * b1 + b0;
-            const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
-            float w[8];
-            int a[8];
-            tri_coef_dense(w, a, Rm, x, y, z);
-            float* row = ctab + (a0 * 64 + b * 8 + e) * 16;
-            *reinterpret_cast<f32x4*>(row + 0) = f32x4{w[0], w[1], w[2], w[3]};
-            *reinterpret_cast<f32x4*>(row + 4) = f32x4{w[4], w[5], w[6], w[7]};
-            *reinterpret_cast<f32x4*>(row + 8) = f32x4{__int_as_float(a[0]), __int_as_float(a[1]), __int_as_float(a[2]),
-                                                       __int_as_float(a[3])};
-            *reinterpret_cast<f32x4*>(row + 12) = f32x4{__int_as_float(a[4]), __int_as_float(a[5]), __int_as_float(a[6]),
-                                                        __int_as_float(a[7])};
+        for (int r = 0; r < 4; ++r) {
+            zb[r * kVxStride + 16 * t] = d0[r];
+            zb[r * kVxStride + 64 + 16 * t] = d1[r];
         }
+        if (G == 3) wave_lds_fence();
+    } else {
+        constexpr bool isx = G < 8;
+        constexpr int kt = 2 * (G & 3);
+        // x: c = 2 kt + (kq >> 1), voxel = i0*64 + j*8 + 4 (kq & 1) + r;  y: voxel = i0*64 + (4 (kq & 1) + r)*8 + j
+        float* rb = xbuf + (kq >> 1) * kVxStride + 64 * i0 + (isx ? 8 * j + 4 * (kq & 1) : 32 * (kq & 1) + j);
+        constexpr int rs = isx ? 1 : 8;
+        float o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = rb[2 * kt * kVxStride + rs * r];
+            o1[r] = rb[(2 * kt + 2) * kVxStride + rs * r];
+        }
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+            mfma_areg(d0, isx ? wx[kt][sp] : wy[kt][sp], du.v[Q][sp]);
+            mfma_areg(d1, isx ? wx[kt + 1][sp] : wy[kt + 1][sp], du.v[Q][sp]);
+        }
+        mfma_chain_end(d0, d1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rb[2 * kt * kVxStride + rs * r] = o0[r] + d0[r];
+            rb[(2 * kt + 2) * kVxStride + rs * r] = o1[r] + d1[r];
+        }
+        if (G == 7 || G == 11) wave_lds_fence();
     }
-    wave_lds_fence();
-    // Phase B, one channel per lane: lane (c, vq) adds channel c of four voxels per step.  The four voxels of a
-    // step are 4 apart in b and/or e, so their 2x2x2 corner footprints are disjoint (a rotation preserves
-    // distances): no two lanes of an atomic ever hit the same address, and the 16 channels of a corner row are
-    // 16 consecutive words.  The image is 64-bit fixed point because ds_add_f32 is ~40x slower than the integer
-    // LDS atomics on gfx950 (tools/lds_atomic_probe.cpp: 771 vs 19 (u32) / 28 (u64) cycles per wave-instruction);
-    // as a bonus the per-workgroup sums do not depend on the order of the adds.
+}
+
+template <int Q, int G>
+struct BwdVolDx {
+    static __device__ __forceinline__ void run(const float (&wx)[8][8], const float (&wy)[8][8], const float (&wz)[4][2][8],
+                                               const DuRegs& du, float* xbuf, int lane)
     {
-        const int c = lane & 15, vq = lane >> 4;
+        bwd_vol_dx_group<Q, G>(wx, wy, wz, du, xbuf, lane);
+        BwdVolDx<Q, G + 1>::run(wx, wy, wz, du, xbuf, lane);
+    }
+};
+template <int Q>
+struct BwdVolDx<Q, 12> {
+    static __device__ __forceinline__ void run(const float (&)[8][8], const float (&)[8][8], const float (&)[4][2][8],
+                                               const DuRegs&, float*, int) {}
+};
+
+// Corner table of quarter Q (phase A, one voxel per lane and pass: the gather's map): 8 hat weights and the byte
+// offset of row (jz, jy, jx) in the dense 64-bit image of dV; the eight corners sit at constant offsets from it
+// (the base index is clamped to [0, 6], see ahv_dual.h).  12 floats per voxel.
+constexpr int kCtRow = 12;
+// dense channel-last image of dV in 64-bit words, kDvRow = 17 words per voxel (16 channels + 1 pad): the four voxels
+// of a scatter instruction then start on different banks instead of all on bank 0 (136-byte rows)
+constexpr int kDvRow = 17;
+constexpr int kDvCornerBytes(int n) { return (((n & 1) ? 1 : 0) + ((n & 2) ? 8 : 0) + ((n & 4) ? 64 : 0)) * kDvRow * 8; }
+
+template <int Q>
+__device__ __forceinline__ void bwd_vol_corners(float* ctab, const GatherHyp& h, int lane)
+{
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
+        hat_axis(fmaf((float)Q, h.dq[0], h.i0[0][p]), jx, wx0, wx1);
+        hat_axis(fmaf((float)Q, h.dq[1], h.i0[1][p]), jy, wy0, wy1);
+        hat_axis(fmaf((float)Q, h.dq[2], h.i0[2][p]), jz, wz0, wz1);
+        const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
+        const float base = fmaf(jz, 64.0f * (kDvRow * 8), fmaf(jy, 8.0f * (kDvRow * 8), jx * (float)(kDvRow * 8)));  // bytes
+        const int b = 4 * p + 2 * b1 + b0;
+        float* row = ctab + (a0 * 64 + b * 8 + e) * kCtRow;
+        *reinterpret_cast<f32x4*>(row + 0) = f32x4{w00 * wx0, w00 * wx1, w01 * wx0, w01 * wx1};
+        *reinterpret_cast<f32x4*>(row + 4) = f32x4{w10 * wx0, w10 * wx1, w11 * wx0, w11 * wx1};
+        row[8] = __uint_as_float((unsigned)base);
+    }
+}
+
+// x (|x| < 2^31, scaled contribution) -> nearest integer, sign-extended to the 64-bit accumulator word.
+// v_cvt_rpi_i32_f32 = floor(x + 0.5): one instruction, no bias towards zero (v_cvt_i32_f32 truncates).
+__device__ __forceinline__ long long to_fixed32(float x)
+{
+    int i;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+    return (long long)i;
+}
+
+// dV += trilinear^T dX (phase B), one CHANNEL per lane: lane (c, vq) adds channel c of four voxels per step.
+// The four voxels of a step are 4 apart in b and/or e, so for a rotation their 2x2x2 corner footprints are
+// disjoint and no two lanes of an atomic hit the same word (any R stays correct: the adds are atomic).  The
+// image is 64-bit fixed point because ds_add_f32 is ~40x slower than the integer LDS atomics on gfx950
+// (tools/lds_atomic_probe.cpp: 771 vs 19 (u32) / 28 (u64) cycles per wave-instruction); every addend is rounded
+// to a 32-bit integer (31 bits below the per-sample bound, finer than an fp32 mantissa for all but the largest
+// terms), the sums are exact and do not depend on the order of the adds.
+struct ScatterStep {  // operands of one step, read ahead of the previous step's atomics (LDS serves a wave in order)
+    float d;
+    f32x4 w0, w1;
+    unsigned base;
+};
+
+__device__ __forceinline__ void scatter_read(ScatterStep& st, const float* xbuf, const float* ctab, int c, int vq, int step)
+{
+    const int a0 = step >> 4, be = step & 15;
+    const int vox = 32 * (vq & 1) + 4 * (vq >> 1) + a0 * 64 + 8 * (be >> 2) + (be & 3);  // b = (be>>2) + 4 (vq&1), e = (be&3) + 4 (vq>>1)
+    st.d = xbuf[c * kVxStride + vox];
+    const float* row = ctab + vox * kCtRow;
+    st.w0 = *reinterpret_cast<const f32x4*>(row + 0);
+    st.w1 = *reinterpret_cast<const f32x4*>(row + 4);
+    st.base = __float_as_uint(row[8]);
+}
+
+__device__ __forceinline__ void scatter_add(const ScatterStep& st, char* dvc, float fx_scale)
+{
+    const float d = st.d * fx_scale;
+    char* base = dvc + st.base;
+    // unconditional: a zero weight adds 0 to a valid row.  Branching on the weight put every atomic in its
+    // own basic block behind an s_waitcnt lgkmcnt(0), i.e. serialised their latencies.
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        lds_add_i64(reinterpret_cast<long long*>(base + kDvCornerBytes(nb)), to_fixed32(st.w0[nb] * d));
+        lds_add_i64(reinterpret_cast<long long*>(base + kDvCornerBytes(4 + nb)), to_fixed32(st.w1[nb] * d));
+    }
+}
+
+// Scatter of one quarter (32 steps, 256 atomic wave-instructions at ~28 LDS cycles each) MERGED with the dX
+// groups of the next quarter: after every second step one group of 16 MFMAs is issued, so the atomics drain
+// while the wave sits in the matrix pipe and the matrix pipe idles only during the scatter's own VALU work
+// (fp32 MFMA and VALU do not overlap on gfx950).  xcur: dX image being scattered; xnext: image the groups fill.
+template <int QN>
+__device__ __forceinline__ void bwd_vol_merged(const float (&wx)[8][8], const float (&wy)[8][8], const float (&wz)[4][2][8],
+                                               const DuRegs& du, const float* xcur, float* xnext, const float* ctab,
+                                               long long* dV, float fx_scale, int lane)
+{
+    const int c = lane & 15, vq = lane >> 4;
+    char* dvc = reinterpret_cast<char*>(dV + c);
+    ScatterStep s0, s1;
+    scatter_read(s0, xcur, ctab, c, vq, 0);
+    scatter_read(s1, xcur, ctab, c, vq, 1);
 #pragma unroll 1
-        for (int a0 = 0; a0 < 2; ++a0)
-#pragma unroll 2
-            for (int be = 0; be < 16; ++be) {
-                const int b = (be >> 2) + 4 * (vq & 1), e = (be & 3) + 4 * (vq >> 1);
-                const float d = xbuf[xoff(c, a0, b, e)] * fx_scale;
-                const float* row = ctab + (a0 * 64 + b * 8 + e) * 16;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(row + 0), w1 = *reinterpret_cast<const f32x4*>(row + 4);
-                const f32x4 o0 = *reinterpret_cast<const f32x4*>(row + 8), o1 = *reinterpret_cast<const f32x4*>(row + 12);
-                // unconditional: a zero weight adds 0 to a clamped (valid) row.  Branching on the weight put every
-                // atomic in its own basic block behind an s_waitcnt lgkmcnt(0), i.e. serialised their latencies.
-                long long fx[8];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    fx[nb] = to_fixed(w0[nb] * d);
-                    fx[4 + nb] = to_fixed(w1[nb] * d);
-                }
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    lds_add_i64(dV + __float_as_int(o0[nb]) + c, fx[nb]);
-                    lds_add_i64(dV + __float_as_int(o1[nb]) + c, fx[4 + nb]);
-                }
-            }
+    for (int ds = 0; ds < 16; ++ds) {
+        ScatterStep n0, n1;  // the next pair's operands are requested BEFORE this pair's atomics enter the LDS queue
+        const int nx = ds < 15 ? 2 * ds + 2 : 30;
+        scatter_read(n0, xcur, ctab, c, vq, nx);
+        scatter_read(n1, xcur, ctab, c, vq, nx + 1);
+        scatter_add(s0, dvc, fx_scale);
+        scatter_add(s1, dvc, fx_scale);
+#ifdef AHV_DIAG_NO_DX  // diagnostic build of tools/kbench_bwd only (wrong results): scatter without the merged MFMA groups
+        if (false)
+#endif
+        switch (ds) {  // uniform: one group of the next quarter's dX per double step
+            case 0: bwd_vol_dx_group<QN, 0>(wx, wy, wz, du, xnext, lane); break;
+            case 1: bwd_vol_dx_group<QN, 1>(wx, wy, wz, du, xnext, lane); break;
+            case 2: bwd_vol_dx_group<QN, 2>(wx, wy, wz, du, xnext, lane); break;
+            case 3: bwd_vol_dx_group<QN, 3>(wx, wy, wz, du, xnext, lane); break;
+            case 4: bwd_vol_dx_group<QN, 4>(wx, wy, wz, du, xnext, lane); break;
+            case 5: bwd_vol_dx_group<QN, 5>(wx, wy, wz, du, xnext, lane); break;
+            case 6: bwd_vol_dx_group<QN, 6>(wx, wy, wz, du, xnext, lane); break;
+            case 7: bwd_vol_dx_group<QN, 7>(wx, wy, wz, du, xnext, lane); break;
+            case 8: bwd_vol_dx_group<QN, 8>(wx, wy, wz, du, xnext, lane); break;
+            case 9: bwd_vol_dx_group<QN, 9>(wx, wy, wz, du, xnext, lane); break;
+            case 10: bwd_vol_dx_group<QN, 10>(wx, wy, wz, du, xnext, lane); break;
+            case 11: bwd_vol_dx_group<QN, 11>(wx, wy, wz, du, xnext, lane); break;
+            default: break;
+        }
+        s0 = n0;
+        s1 = n1;
     }
-    wave_lds_fence();
 }
 
 __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
     const float* __restrict__ R, long r_batch_stride, const float* __restrict__ W1, int B, long N,
     const float* __restrict__ du_ws, const unsigned* __restrict__ du_max_bits, float* __restrict__ grad_vol)
 {
-    __shared__ __attribute__((aligned(16))) long long lds_dv[512 * 16];  // dense channel-last, 64-bit fixed point
-    __shared__ __attribute__((aligned(16))) float lds_du[4 * 2048];      // per wave: du image, then the corner table
-    __shared__ __attribute__((aligned(16))) float lds_x[4 * kQuarterFloats];
+    __shared__ __attribute__((aligned(16))) long long lds_dv[512 * kDvRow];  // channel-last, 64-bit fixed point
+    __shared__ __attribute__((aligned(16))) float lds_x[4 * 2 * kVxFloats];  // per wave: two dX images (scattered / being filled)
+    __shared__ __attribute__((aligned(16))) float lds_ct[4 * 128 * kCtRow];      // per wave: corner table of a quarter
     __shared__ float lds_bound[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, row = lane & 15;
-    float* dbuf = lds_du + wave * 2048;
-    float* xbuf = lds_x + wave * kQuarterFloats;
+    float* x0 = lds_x + wave * (2 * kVxFloats);
+    float* x1 = x0 + kVxFloats;
+    float* ctab = lds_ct + wave * (128 * kCtRow);
 
     // |dX| <= (sum over the three slabs of max_k sum_o |W1[o][k]|) * max|du|: fixes the fixed-point scale per sample
     {
@@ -563,37 +923,47 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
 #pragma unroll
             for (int a0 = 0; a0 < 2; ++a0) wz[q][a0][sp] = w[256 + row * 8 + 2 * q + a0];
     }
+    const GatherLane glane = gather_lane(lane);
 
     const long hstep = (long)gridDim.x * 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        for (int i = tid; i < 512 * 16; i += kBwdThreads) lds_dv[i] = 0ll;
+        for (int i = tid; i < 512 * kDvRow; i += kBwdThreads) lds_dv[i] = 0ll;
         __syncthreads();
-        // every contribution w * dX (w <= 1) stays below 2^40 in units of 2^-fx_exp: 23 bits of headroom for the sum
+        // every addend w * dX (w <= 1) is rounded to a 32-bit integer in units of 2^-fx_exp with |addend| < 2^30;
+        // the 64-bit words then have room for 2^33 of them
         const float bound = w1_bound * __uint_as_float(du_max_bits[b]);
         int ex = 0;
         (void)frexpf(bound, &ex);
         const bool usable = bound > 0.0f && bound < 3.0e38f;
-        // a word collects at most 8 corners x (hypotheses of this workgroup): give up precision bits, never range,
-        // when that exceeds the 2^22 adds the 63-bit word has room for (only beyond ~500 000 hypotheses per workgroup)
-        const long adds = 8 * ((N + gridDim.x - 1) / gridDim.x);
-        const int spare = (adds > (1l << 22)) ? (64 - __builtin_clzl((unsigned long)(adds - 1))) - 22 : 0;
-        const int fx_exp = usable ? min(max(40 - spare - ex, -80), 80) : 0;
+        const int fx_exp = usable ? min(max(30 - ex, -80), 80) : 0;
         const float fx_scale = usable ? ldexpf(1.0f, fx_exp) : 0.0f;
         const float* Rb = R + (long)b * r_batch_stride;
-        for (long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y); h < N; h += hstep) {
+        long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        DuRegs du;
+        if (h < N) {  // prologue of the pipeline: quarter 0 of this wave's first hypothesis
+            load_du_regs(du, du_ws + ((long)b * N + h) * 2048, lane);
+            BwdVolDx<0, 0>::run(wx, wy, wz, du, x0, lane);
+        }
+        for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
-            const float* du_h = du_ws + ((long)b * N + h) * 2048;
-            load_du_image(dbuf, du_h, lane); wave_lds_fence();
-            bwd_vol_quarter<0>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
-            load_du_image(dbuf, du_h, lane); wave_lds_fence();
-            bwd_vol_quarter<1>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
-            load_du_image(dbuf, du_h, lane); wave_lds_fence();
-            bwd_vol_quarter<2>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
-            load_du_image(dbuf, du_h, lane); wave_lds_fence();
-            bwd_vol_quarter<3>(wx, wy, wz, dbuf, xbuf, lds_dv, fx_scale, Rm, lane);
+            GatherHyp gh;
+            gather_hyp(gh, Rm, glane);
+            DuRegs nxt;  // the next hypothesis's du travels from HBM / L2 while this one is processed
+            const long hn = (h + hstep < N) ? h + hstep : h;
+            load_du_regs(nxt, du_ws + ((long)b * N + hn) * 2048, lane);
+            bwd_vol_corners<0>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_merged<1>(wx, wy, wz, du, x0, x1, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_corners<1>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_merged<2>(wx, wy, wz, du, x1, x0, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_corners<2>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_merged<3>(wx, wy, wz, du, x0, x1, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_corners<3>(ctab, gh, lane); wave_lds_fence();
+            // the last scatter of this hypothesis carries quarter 0 of the next one (a harmless repeat on the last)
+            bwd_vol_merged<0>(wx, wy, wz, nxt, x1, x0, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            du = nxt;
         }
         __syncthreads();
         // non-finite upstream gradients: the bound is inf/NaN, nothing was accumulated -> report NaN like autograd would
@@ -601,7 +971,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
         float* gv = grad_vol + (long)b * (16 * 512);
         for (int i = tid; i < 16 * 512; i += kBwdThreads) {
             const int c = i >> 9, v = i & 511;
-            const long long a = lds_dv[v * 16 + c];
+            const long long a = lds_dv[v * kDvRow + c];
             if (a != 0ll || !usable) global_add(gv + i, (float)a * unscale + (usable ? 0.0f : unscale));
         }
     }
@@ -610,8 +980,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
 // ---- host-side launcher -------------------------------------------------------------------------------
 hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
                                  const float* W1, const float* W2, const float* b2, int B, int64_t N,
-                                 const float* grad_scores, float* du_ws, unsigned* du_max_bits, float* grad_vol,
-                                 float* grad_feat_tgt,
+                                 const float* grad_scores, float* du_ws, unsigned* du_max_bits, float* dw1_partials,
+                                 float* grad_vol, float* grad_feat_tgt,
                                  float* grad_W1, float* grad_W2, float* grad_b2, int num_cu, hipStream_t stream)
 {
     hipError_t e;
@@ -632,8 +1002,11 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
                        (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2,
                        grad_b2);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(score_backward_w1_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, R, (long)r_batch_stride,
-                       B, (long)N, du_ws, grad_W1);
+    hipLaunchKernelGGL(score_backward_w1_kernel, grid, dim3(kW1Threads), 0, stream, vol_src, R, (long)r_batch_stride,
+                       B, (long)N, du_ws, dw1_partials);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(score_backward_w1_reduce_kernel, dim3(32 * 384 / 256, 16), dim3(256), 0, stream, dw1_partials,
+                       gx * gy, grad_W1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kBwdThreads), 0, stream, R, (long)r_batch_stride, W1,
                        B, (long)N, du_ws, du_max_bits, grad_vol);

@@ -266,7 +266,8 @@ __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, co
     hat_voxel<Q>(st.vx[1], srcT, h, 1);
 }
 
-template <int S>
+// ROW = floats between the channel planes of the destination image (128: the forward's swizzled quarter image)
+template <int S, int ROW = 128>
 struct HatSteps {
     static __device__ __forceinline__ void run(HatState& st, f32x2 (&o)[8], float* dst0, float* dst1)
     {
@@ -290,13 +291,13 @@ struct HatSteps {
         if (n == 7) {
             float* dst = p ? dst1 : dst0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) dst[c * 128] = o[c >> 1][c & 1];
+            for (int c = 0; c < 16; ++c) dst[c * ROW] = o[c >> 1][c & 1];
         }
-        HatSteps<S + 1>::run(st, o, dst0, dst1);
+        HatSteps<S + 1, ROW>::run(st, o, dst0, dst1);
     }
 };
-template <>
-struct HatSteps<16> {
+template <int ROW>
+struct HatSteps<16, ROW> {
     static __device__ __forceinline__ void run(HatState&, f32x2 (&)[8], float*, float*) {}
 };
 
@@ -312,6 +313,16 @@ __device__ __forceinline__ void hat_body(HatState& st, float* buf, int lane)
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif
+}
+
+// the same into a LINEAR image X[c][voxel = a0*64 + b*8 + e] with ROW floats per channel plane (backward kernels)
+template <int ROW>
+__device__ __forceinline__ void hat_body_linear(HatState& st, float* img, int lane)
+{
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+    f32x2 o[8];
+    float* d0 = img + a0 * 64 + (2 * b1 + b0) * 8 + e;
+    HatSteps<0, ROW>::run(st, o, d0, d0 + 32);
 }
 
 }  // namespace ahv

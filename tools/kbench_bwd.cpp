@@ -1,0 +1,77 @@
+// kbench_bwd.cpp -- developer micro-benchmark of the scorer's three backward kernels at the reference's training
+// size (B = 12 per-sample rotation sets of N = 3000), kernel by kernel, with diagnostic switches
+// (-DAHV_DIAG_NO_ATOMICS, -DAHV_DIAG_NO_DX: wrong results, to price a component).  Not part of the product.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I3dahv_amd/csrc -Iinclude tools/kbench_bwd.cpp -o tools/kbench_bwd
+#include "../3dahv_amd/csrc/ahv_backward.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 12;
+    const long N = argc > 2 ? atol(argv[2]) : 3000;
+    const int iters = argc > 3 ? atoi(argv[3]) : 10;
+    std::mt19937 rng(0);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> vol((size_t)B * 8192), ft((size_t)B * 2048), R((size_t)B * N * 9), W1(32 * 384), W2(1024), b2(32), gs((size_t)B * N);
+    for (auto& x : vol) x = 1.15f * nd(rng);
+    for (auto& x : ft) x = nd(rng) / 5.6f;
+    for (auto& x : W1) x = nd(rng) * 0.03f;
+    for (auto& x : W2) x = nd(rng) * 0.1f;
+    for (auto& x : b2) x = nd(rng) * 0.1f;
+    for (auto& x : gs) x = nd(rng);
+    for (long n = 0; n < B * N; ++n) {
+        double q[4], s = 0;
+        for (double& c : q) { c = nd(rng); s += c * c; }
+        const double t = 2.0 / s, r = q[0], i = q[1], j = q[2], k = q[3];
+        const double m[9] = {1 - t * (j * j + k * k), t * (i * j - k * r), t * (i * k + j * r), t * (i * j + k * r), 1 - t * (i * i + k * k),
+                             t * (j * k - i * r), t * (i * k - j * r), t * (j * k + i * r), 1 - t * (i * i + j * j)};
+        for (int e = 0; e < 9; ++e) R[n * 9 + e] = (float)m[e];
+    }
+    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dgs, *dws, *gvol, *gft, *gW1, *gW2, *gb2, *dpart;
+    unsigned* dmax;
+    CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
+    CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
+    CK(hipMalloc(&dgs, gs.size() * 4)); CK(hipMalloc(&dws, (size_t)B * N * 2048 * 4)); CK(hipMalloc(&dmax, B * 4));
+    CK(hipMalloc(&dpart, (size_t)1024 * 32 * 384 * 4)); CK(hipMalloc(&gvol, vol.size() * 4)); CK(hipMalloc(&gft, ft.size() * 4)); CK(hipMalloc(&gW1, W1.size() * 4));
+    CK(hipMalloc(&gW2, W2.size() * 4)); CK(hipMalloc(&gb2, b2.size() * 4));
+    CK(hipMemcpy(dvol, vol.data(), vol.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dft, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW1, W1.data(), W1.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW2, W2.data(), W2.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dgs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
+    int cu = 0;
+    CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0));
+    int gy = B < cu ? B : cu, gx = cu / gy;
+    const dim3 grid(gx, gy);
+    hipEvent_t e[4];
+    for (auto& x : e) CK(hipEventCreate(&x));
+    double t[3] = {0, 0, 0};
+    for (int it = -2; it < iters; ++it) {
+        CK(hipMemsetAsync(gvol, 0, vol.size() * 4, 0)); CK(hipMemsetAsync(gft, 0, ft.size() * 4, 0));
+        CK(hipMemsetAsync(gW1, 0, W1.size() * 4, 0)); CK(hipMemsetAsync(gW2, 0, 4096, 0)); CK(hipMemsetAsync(gb2, 0, 128, 0));
+        CK(hipMemsetAsync(dmax, 0, B * 4, 0));
+        CK(hipEventRecord(e[0], 0));
+        hipLaunchKernelGGL(ahv::score_backward_head_kernel, grid, dim3(ahv::kBwdThreads), 0, 0, dvol, dft, dR, (long)(N * 9), dW1, dW2, db2,
+                           B, N, dgs, dws, dmax, gft, gW2, gb2);
+        CK(hipEventRecord(e[1], 0));
+        hipLaunchKernelGGL(ahv::score_backward_w1_kernel, grid, dim3(ahv::kW1Threads), 0, 0, dvol, dR, (long)(N * 9), B, N, dws, dpart);
+        hipLaunchKernelGGL(ahv::score_backward_w1_reduce_kernel, dim3(32 * 384 / 256, 16), dim3(256), 0, 0, dpart, gx * gy, gW1);
+        CK(hipEventRecord(e[2], 0));
+        hipLaunchKernelGGL(ahv::score_backward_volume_kernel, grid, dim3(ahv::kBwdThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, dmax, gvol);
+        CK(hipEventRecord(e[3], 0));
+        CK(hipEventSynchronize(e[3]));
+        CK(hipGetLastError());
+        if (it >= 0)
+            for (int k = 0; k < 3; ++k) { float ms; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); t[k] += ms; }
+    }
+    std::vector<float> hv(64);
+    CK(hipMemcpy(hv.data(), gvol, 256, hipMemcpyDeviceToHost));
+    printf("B=%d N=%ld: head %.3f ms  dW1 %.3f ms  dV %.3f ms  total %.3f ms   (grad_vol[0..2] = %g %g %g)\n", B, N, t[0] / iters,
+           t[1] / iters, t[2] / iters, (t[0] + t[1] + t[2]) / iters, hv[0], hv[1], hv[2]);
+    return 0;
+}

@@ -37,11 +37,17 @@ __global__ __launch_bounds__(THREADS) void probe(const float* __restrict__ in, f
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(v[i], f32x2{w[n], w[n]}, a[i]);
         }
-        if (MODE >= 2) {
+        if (MODE >= 2 && MODE != 5) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, acc[i], 0, 0, 0);
+        }
+        if (MODE == 5) {  // the dependency pattern of the scorer's x / y slabs: two accumulators, alternating
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, acc[i], 0, 0, 0);
         }
         // keep the loop-carried values opaque so that nothing is hoisted or folded across iterations
 #pragma unroll
@@ -82,6 +88,9 @@ int main()
     if (run<1, 256>("64 v_pk_fma_f32 (same FLOPs), 1 wave/SIMD", din, dout, it)) return 1;
     if (run<0, 512>("128 v_fma_f32, 2 waves/SIMD", din, dout, it)) return 1;
     if (run<1, 512>("64 v_pk_fma_f32, 2 waves/SIMD", din, dout, it)) return 1;
+    if (run<2, 256>("32 MFMA 16x16x4 only (8 independent accumulators), 1 wave/SIMD", din, dout, it)) return 1;
+    if (run<5, 256>("32 MFMA 16x16x4, 2 alternating accumulators, 1 wave/SIMD", din, dout, it)) return 1;
+    if (run<5, 512>("32 MFMA 16x16x4, 2 alternating accumulators, 2 waves/SIMD", din, dout, it)) return 1;
     if (run<2, 512>("32 MFMA 16x16x4 only, 2 waves/SIMD", din, dout, it)) return 1;
     if (run<3, 512>("128 v_fma_f32 + 32 MFMA, 2 waves/SIMD", din, dout, it)) return 1;
     if (run<4, 512>("64 v_pk_fma_f32 + 32 MFMA, 2 waves/SIMD", din, dout, it)) return 1;

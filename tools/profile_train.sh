@@ -13,7 +13,20 @@ grep "training scorer step" $OUT/train.log
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/*/*_kernel_stats.csv")[0]
-for r in csv.DictReader(open(f)):
-    if "score_" in r["Name"]:
-        print("%-60s calls %4s avg %9.1f us" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3))
+import collections
+# full-size launches only: the same kernels also run at N = 1 for forward_3d2d's backward (a few microseconds)
+t = glob.glob("$OUT/trace/*/*_kernel_trace.csv")[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(t)):
+    if "score_" in r["Kernel_Name"]:
+        d[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+rows = []
+for k, v in sorted(d.items()):
+    big = [x for x in v if x > 100.0]
+    rows.append((k, len(big), sum(big) / max(len(big), 1), min(big), max(big)))
+    print("%-48s full-size launches %3d  avg %8.1f us  min %8.1f  max %8.1f" % rows[-1])
+with open("$OUT/training_kernels.csv", "w") as o:
+    o.write("kernel,full_size_launches,avg_us,min_us,max_us\n")
+    for r in rows:
+        o.write("%s,%d,%.1f,%.1f,%.1f\n" % r)
 PY
