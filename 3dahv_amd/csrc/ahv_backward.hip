@@ -682,85 +682,81 @@ __device__ __forceinline__ void load_du_regs(DuRegs& d, const float* __restrict_
         for (int sp = 0; sp < 8; ++sp) d.v[t][sp] = p[sp * 256 + 16 * t];
 }
 
-// dX = W1^T du for the voxels of quarter Q into `xbuf` (linear image, kVxStride), cut into 12 groups of 16 MFMAs so
-// that the groups can be slotted between the scatter steps of the PREVIOUS quarter (bwd_vol_merged): the LDS
-// atomics of the scatter then drain underneath the matrix pipe.  Every output tile is ONE accumulator fed by 8
-// k-steps; two tiles run side by side so that consecutive MFMAs never wait for each other's result
-// (dependent-accumulator latency 40 cycles against a 32-cycle issue interval).
-//   groups 0-3  z slab, tile t = G (plain stores):  rows c = 4 kq + r; column = position (b = 2 t + i0, e = j)
-//   groups 4-7  x slab, k-tiles 2 (G-4), +1 (read-modify-write): rows k -> c = 2 kt + (kq >> 1), e = 4 (kq & 1) + r;
-//               column = position (a0 = i0, b = j)
-//   groups 8-11 y slab (read-modify-write): rows k -> c = 2 kt + (kq >> 1), b = 4 (kq & 1) + r; column = (a0 = i0, e = j)
-template <int Q, int G>
-__device__ __forceinline__ void bwd_vol_dx_group(const float (&wx)[8][8], const float (&wy)[8][8], const float (&wz)[4][2][8],
-                                                 const DuRegs& du, float* xbuf, int lane)
+// Kernel 2b runs TWO waves per SIMD, split by CHANNEL: wave role r = wave / 4 owns channels 8 r .. 8 r + 7 of
+// dV.  Everything downstream of du splits cleanly along that axis -- the rows of dX = W1^T du are (channel,
+// slab index), the scatter adds channel by channel -- so the pair shares nothing but the (atomic) dV image:
+//   * W1^T fragments per wave: x and y slabs k-tiles 4 r .. 4 r + 3 (channel = 2 kt + (kq >> 1)), z slab with the
+//     tile rows re-packed as (a0, channel - 8 r): 32 + 32 + 32 = 96 accumulator-file registers instead of 192,
+//     384 MFMAs per wave and hypothesis instead of 768, none wasted;
+//   * dX image per wave: 8 channels x 128 voxels; scatter lanes = 8 channels x 8 voxels per step.
+// Waves w and w + 4 (same SIMD) walk the same hypotheses independently, like kernel 2a.  The one-wave-per-SIMD
+// form of this kernel (1.44 ms) was the sum of its parts: 0.47 ms skeleton + 0.26 ms atomics + 0.69 ms for
+// 0.38 ms worth of MFMAs, nothing overlapping anything.
+constexpr int kVhFloats = 8 * kVxStride;  // half-channel dX image
+
+// one MFMA output tile = one accumulator fed by 8 k-steps; two tiles side by side (see mfma_areg)
+template <int Q>
+__device__ __forceinline__ void bwd_vol_dx(const float (&wx)[4][8], const float (&wy)[4][8], const float (&wz)[4][8],
+                                           const DuRegs& du, float* xbuf, int lane)
 {
     const int n = lane & 15, kq = lane >> 4;
     const int i0 = n >> 3, j = n & 7;
-    f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
-    if (G < 4) {
-        constexpr int t = G & 3;
+    // z slab: tile rows = (a0' = row >> 3, c8 = row & 7); row = 4 kq + r; column = position (b = 2 t + i0, e = j)
+    {
+        float* zb = xbuf + 4 * (kq & 1) * kVxStride + (kq >> 1) * 64 + 8 * i0 + j;
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
-            mfma_areg(d0, wz[Q][0][sp], du.v[t][sp]);
-            mfma_areg(d1, wz[Q][1][sp], du.v[t][sp]);
-        }
-        mfma_chain_end(d0, d1);
-        float* zb = xbuf + 4 * kq * kVxStride + 8 * i0 + j;  // c = 4 kq + r, voxel = a0*64 + (2 t + i0)*8 + j
+        for (int t = 0; t < 4; t += 2) {
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            zb[r * kVxStride + 16 * t] = d0[r];
-            zb[r * kVxStride + 64 + 16 * t] = d1[r];
-        }
-        if (G == 3) wave_lds_fence();
-    } else {
-        constexpr bool isx = G < 8;
-        constexpr int kt = 2 * (G & 3);
-        // x: c = 2 kt + (kq >> 1), voxel = i0*64 + j*8 + 4 (kq & 1) + r;  y: voxel = i0*64 + (4 (kq & 1) + r)*8 + j
-        float* rb = xbuf + (kq >> 1) * kVxStride + 64 * i0 + (isx ? 8 * j + 4 * (kq & 1) : 32 * (kq & 1) + j);
-        constexpr int rs = isx ? 1 : 8;
-        float o0[4], o1[4];
+            for (int sp = 0; sp < 8; ++sp) {
+                mfma_areg(d0, wz[Q][sp], du.v[t][sp]);
+                mfma_areg(d1, wz[Q][sp], du.v[t + 1][sp]);
+            }
+            mfma_chain_end(d0, d1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o0[r] = rb[2 * kt * kVxStride + rs * r];
-            o1[r] = rb[(2 * kt + 2) * kVxStride + rs * r];
+            for (int r = 0; r < 4; ++r) {
+                zb[r * kVxStride + 16 * t] = d0[r];
+                zb[r * kVxStride + 16 * (t + 1)] = d1[r];
+            }
         }
+    }
+    wave_lds_fence();
+    // x: local channel = 2 kt + (kq >> 1), voxel = i0*64 + j*8 + 4 (kq & 1) + r;  y: voxel = i0*64 + (4 (kq & 1) + r)*8 + j
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
-            mfma_areg(d0, isx ? wx[kt][sp] : wy[kt][sp], du.v[Q][sp]);
-            mfma_areg(d1, isx ? wx[kt + 1][sp] : wy[kt + 1][sp], du.v[Q][sp]);
-        }
-        mfma_chain_end(d0, d1);
+    for (int slab = 0; slab < 2; ++slab) {
+        float* rb = xbuf + (kq >> 1) * kVxStride + 64 * i0 + (slab == 0 ? 8 * j + 4 * (kq & 1) : 32 * (kq & 1) + j);
+        const int rs = slab == 0 ? 1 : 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rb[2 * kt * kVxStride + rs * r] = o0[r] + d0[r];
-            rb[(2 * kt + 2) * kVxStride + rs * r] = o1[r] + d1[r];
+        for (int kt = 0; kt < 4; kt += 2) {
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+            float o0[4], o1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[r] = rb[2 * kt * kVxStride + rs * r];
+                o1[r] = rb[(2 * kt + 2) * kVxStride + rs * r];
+            }
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+                mfma_areg(d0, slab == 0 ? wx[kt][sp] : wy[kt][sp], du.v[Q][sp]);
+                mfma_areg(d1, slab == 0 ? wx[kt + 1][sp] : wy[kt + 1][sp], du.v[Q][sp]);
+            }
+            mfma_chain_end(d0, d1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rb[2 * kt * kVxStride + rs * r] = o0[r] + d0[r];
+                rb[(2 * kt + 2) * kVxStride + rs * r] = o1[r] + d1[r];
+            }
         }
-        if (G == 7 || G == 11) wave_lds_fence();
+        wave_lds_fence();
     }
 }
 
-template <int Q, int G>
-struct BwdVolDx {
-    static __device__ __forceinline__ void run(const float (&wx)[8][8], const float (&wy)[8][8], const float (&wz)[4][2][8],
-                                               const DuRegs& du, float* xbuf, int lane)
-    {
-        bwd_vol_dx_group<Q, G>(wx, wy, wz, du, xbuf, lane);
-        BwdVolDx<Q, G + 1>::run(wx, wy, wz, du, xbuf, lane);
-    }
-};
-template <int Q>
-struct BwdVolDx<Q, 12> {
-    static __device__ __forceinline__ void run(const float (&)[8][8], const float (&)[8][8], const float (&)[4][2][8],
-                                               const DuRegs&, float*, int) {}
-};
-
 // Corner table of quarter Q (phase A, one voxel per lane and pass: the gather's map): 8 hat weights and the byte
-// offset of row (jz, jy, jx) in the dense 64-bit image of dV; the eight corners sit at constant offsets from it
-// (the base index is clamped to [0, 6], see ahv_dual.h).  12 floats per voxel.
+// offset of row (jz, jy, jx) in the image of dV; the eight corners sit at constant offsets from it (the base index
+// is clamped to [0, 6], see ahv_dual.h).  12 floats per voxel.
 constexpr int kCtRow = 12;
-// dense channel-last image of dV in 64-bit words, kDvRow = 17 words per voxel (16 channels + 1 pad): the four voxels
-// of a scatter instruction then start on different banks instead of all on bank 0 (136-byte rows)
+// channel-last image of dV in 64-bit words, kDvRow = 17 words per voxel (16 channels + 1 pad): the voxels of a
+// scatter instruction then start on different banks instead of all on bank 0 (136-byte rows)
 constexpr int kDvRow = 17;
 constexpr int kDvCornerBytes(int n) { return (((n & 1) ? 1 : 0) + ((n & 2) ? 8 : 0) + ((n & 4) ? 64 : 0)) * kDvRow * 8; }
 
@@ -793,107 +789,61 @@ __device__ __forceinline__ long long to_fixed32(float x)
     return (long long)i;
 }
 
-// dV += trilinear^T dX (phase B), one CHANNEL per lane: lane (c, vq) adds channel c of four voxels per step.
-// The four voxels of a step are 4 apart in b and/or e, so for a rotation their 2x2x2 corner footprints are
-// disjoint and no two lanes of an atomic hit the same word (any R stays correct: the adds are atomic).  The
-// image is 64-bit fixed point because ds_add_f32 is ~40x slower than the integer LDS atomics on gfx950
-// (tools/lds_atomic_probe.cpp: 771 vs 19 (u32) / 28 (u64) cycles per wave-instruction); every addend is rounded
-// to a 32-bit integer (31 bits below the per-sample bound, finer than an fp32 mantissa for all but the largest
-// terms), the sums are exact and do not depend on the order of the adds.
-struct ScatterStep {  // operands of one step, read ahead of the previous step's atomics (LDS serves a wave in order)
-    float d;
-    f32x4 w0, w1;
-    unsigned base;
-};
-
-__device__ __forceinline__ void scatter_read(ScatterStep& st, const float* xbuf, const float* ctab, int c, int vq, int step)
+// dV += trilinear^T dX (phase B): lane (c8, vq) adds local channel c8 of eight voxels per step, the voxels of a
+// step 4 apart in b and 2 apart in e, so that for a rotation their 2x2x2 corner footprints rarely share a word
+// (any R stays correct: the adds are atomic).  The image is 64-bit fixed point because ds_add_f32 is ~40x slower
+// than the integer LDS atomics on gfx950 (tools/lds_atomic_probe.cpp: 771 vs 19 (u32) / 28 (u64) cycles per
+// wave-instruction); every addend is rounded to a 32-bit integer (31 bits below the per-sample bound, finer than an
+// fp32 mantissa for all but the largest terms), the sums are exact and do not depend on the order of the adds.
+__device__ __forceinline__ void bwd_vol_scatter(const float* xbuf, const float* ctab, long long* dV, float fx_scale, int role, int lane)
 {
-    const int a0 = step >> 4, be = step & 15;
-    const int vox = 32 * (vq & 1) + 4 * (vq >> 1) + a0 * 64 + 8 * (be >> 2) + (be & 3);  // b = (be>>2) + 4 (vq&1), e = (be&3) + 4 (vq>>1)
-    st.d = xbuf[c * kVxStride + vox];
-    const float* row = ctab + vox * kCtRow;
-    st.w0 = *reinterpret_cast<const f32x4*>(row + 0);
-    st.w1 = *reinterpret_cast<const f32x4*>(row + 4);
-    st.base = __float_as_uint(row[8]);
-}
-
-__device__ __forceinline__ void scatter_add(const ScatterStep& st, char* dvc, float fx_scale)
-{
-    const float d = st.d * fx_scale;
-    char* base = dvc + st.base;
-    // unconditional: a zero weight adds 0 to a valid row.  Branching on the weight put every atomic in its
-    // own basic block behind an s_waitcnt lgkmcnt(0), i.e. serialised their latencies.
+    const int c8 = lane & 7, vq = lane >> 3;
+    char* dvc = reinterpret_cast<char*>(dV + 8 * role + c8);
+    const int vlane = 32 * (vq & 1) + 2 * (vq >> 1);  // b += 4 (vq & 1), e += 2 (vq >> 1)
+#pragma unroll 2
+    for (int st = 0; st < 16; ++st) {
+        // step -> (a0, b' < 4, e' < 2): voxel = a0*64 + (b' + 4 (vq&1))*8 + e' + 2 (vq>>1)
+        const int vox = vlane + (st >> 3) * 64 + ((st >> 1) & 3) * 8 + (st & 1);
+        const float d = xbuf[c8 * kVxStride + vox] * fx_scale;
+        const float* row = ctab + vox * kCtRow;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(row + 0), w1 = *reinterpret_cast<const f32x4*>(row + 4);
+        char* base = dvc + __float_as_uint(row[8]);
+        // unconditional: a zero weight adds 0 to a valid row.  Branching on the weight put every atomic in its
+        // own basic block behind an s_waitcnt lgkmcnt(0), i.e. serialised their latencies.
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        lds_add_i64(reinterpret_cast<long long*>(base + kDvCornerBytes(nb)), to_fixed32(st.w0[nb] * d));
-        lds_add_i64(reinterpret_cast<long long*>(base + kDvCornerBytes(4 + nb)), to_fixed32(st.w1[nb] * d));
-    }
-}
-
-// Scatter of one quarter (32 steps, 256 atomic wave-instructions at ~28 LDS cycles each) MERGED with the dX
-// groups of the next quarter: after every second step one group of 16 MFMAs is issued, so the atomics drain
-// while the wave sits in the matrix pipe and the matrix pipe idles only during the scatter's own VALU work
-// (fp32 MFMA and VALU do not overlap on gfx950).  xcur: dX image being scattered; xnext: image the groups fill.
-template <int QN>
-__device__ __forceinline__ void bwd_vol_merged(const float (&wx)[8][8], const float (&wy)[8][8], const float (&wz)[4][2][8],
-                                               const DuRegs& du, const float* xcur, float* xnext, const float* ctab,
-                                               long long* dV, float fx_scale, int lane)
-{
-    const int c = lane & 15, vq = lane >> 4;
-    char* dvc = reinterpret_cast<char*>(dV + c);
-    ScatterStep s0, s1;
-    scatter_read(s0, xcur, ctab, c, vq, 0);
-    scatter_read(s1, xcur, ctab, c, vq, 1);
-#pragma unroll 1
-    for (int ds = 0; ds < 16; ++ds) {
-        ScatterStep n0, n1;  // the next pair's operands are requested BEFORE this pair's atomics enter the LDS queue
-        const int nx = ds < 15 ? 2 * ds + 2 : 30;
-        scatter_read(n0, xcur, ctab, c, vq, nx);
-        scatter_read(n1, xcur, ctab, c, vq, nx + 1);
-        scatter_add(s0, dvc, fx_scale);
-        scatter_add(s1, dvc, fx_scale);
-#ifdef AHV_DIAG_NO_DX  // diagnostic build of tools/kbench_bwd only (wrong results): scatter without the merged MFMA groups
-        if (false)
-#endif
-        switch (ds) {  // uniform: one group of the next quarter's dX per double step
-            case 0: bwd_vol_dx_group<QN, 0>(wx, wy, wz, du, xnext, lane); break;
-            case 1: bwd_vol_dx_group<QN, 1>(wx, wy, wz, du, xnext, lane); break;
-            case 2: bwd_vol_dx_group<QN, 2>(wx, wy, wz, du, xnext, lane); break;
-            case 3: bwd_vol_dx_group<QN, 3>(wx, wy, wz, du, xnext, lane); break;
-            case 4: bwd_vol_dx_group<QN, 4>(wx, wy, wz, du, xnext, lane); break;
-            case 5: bwd_vol_dx_group<QN, 5>(wx, wy, wz, du, xnext, lane); break;
-            case 6: bwd_vol_dx_group<QN, 6>(wx, wy, wz, du, xnext, lane); break;
-            case 7: bwd_vol_dx_group<QN, 7>(wx, wy, wz, du, xnext, lane); break;
-            case 8: bwd_vol_dx_group<QN, 8>(wx, wy, wz, du, xnext, lane); break;
-            case 9: bwd_vol_dx_group<QN, 9>(wx, wy, wz, du, xnext, lane); break;
-            case 10: bwd_vol_dx_group<QN, 10>(wx, wy, wz, du, xnext, lane); break;
-            case 11: bwd_vol_dx_group<QN, 11>(wx, wy, wz, du, xnext, lane); break;
-            default: break;
+        for (int nb = 0; nb < 4; ++nb) {
+            lds_add_i64(reinterpret_cast<long long*>(base + kDvCornerBytes(nb)), to_fixed32(w0[nb] * d));
+            lds_add_i64(reinterpret_cast<long long*>(base + kDvCornerBytes(4 + nb)), to_fixed32(w1[nb] * d));
         }
-        s0 = n0;
-        s1 = n1;
     }
 }
 
-__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
+constexpr int kVolThreads = 512;
+#ifdef AHV_VOL_NOPRIO
+#define AHV_VOL_PRIO(x)
+#else  // the scattering wave (VALU + LDS latency) issues first, its partner streams MFMAs: same reasoning as the forward's gather
+#define AHV_VOL_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+
+__global__ __launch_bounds__(kVolThreads, 2) void score_backward_volume_kernel(
     const float* __restrict__ R, long r_batch_stride, const float* __restrict__ W1, int B, long N,
     const float* __restrict__ du_ws, const unsigned* __restrict__ du_max_bits, float* __restrict__ grad_vol)
 {
-    __shared__ __attribute__((aligned(16))) long long lds_dv[512 * kDvRow];  // channel-last, 64-bit fixed point
-    __shared__ __attribute__((aligned(16))) float lds_x[4 * 2 * kVxFloats];  // per wave: two dX images (scattered / being filled)
-    __shared__ __attribute__((aligned(16))) float lds_ct[4 * 128 * kCtRow];      // per wave: corner table of a quarter
+    __shared__ __attribute__((aligned(16))) long long lds_dv[512 * kDvRow];   // channel-last, 64-bit fixed point
+    __shared__ __attribute__((aligned(16))) float lds_x[8 * kVhFloats];       // per wave: dX of its 8 channels
+    __shared__ __attribute__((aligned(16))) float lds_ct[8 * 128 * kCtRow];   // per wave: corner table of a quarter
     __shared__ float lds_bound[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave & 3, role = wave >> 2;  // waves w and w + 4 share a SIMD and a hypothesis list
     const int kq = lane >> 4, row = lane & 15;
-    float* x0 = lds_x + wave * (2 * kVxFloats);
-    float* x1 = x0 + kVxFloats;
+    float* xbuf = lds_x + wave * kVhFloats;
     float* ctab = lds_ct + wave * (128 * kCtRow);
 
     // |dX| <= (sum over the three slabs of max_k sum_o |W1[o][k]|) * max|du|: fixes the fixed-point scale per sample
     {
         float* colsum = lds_x;  // 384 floats of scratch before the hypothesis loop
-        for (int k = tid; k < 384; k += kBwdThreads) {
+        for (int k = tid; k < 384; k += kVolThreads) {
             float a = 0.0f;
             for (int o = 0; o < 32; ++o) a += fabsf(W1[o * 384 + k]);
             colsum[k] = a;
@@ -908,27 +858,27 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
     }
     const float w1_bound = lds_bound[0] + lds_bound[1] + lds_bound[2];
 
-    // W1^T fragments, A operands of dX: [k-tile][k-step over o]: W1[o = 4 s' + kq][k = base + row]
-    float wx[8][8], wy[8][8], wz[4][2][8];
+    // W1^T fragments of this wave's channel half, A operands of dX: [tile][k-step over o]: W1[o = 4 s' + kq][k]
+    //   x / y: k = 16 (4 role + kt) + row                 (channel 8 role + 2 kt + (row >> 3), slab index row & 7)
+    //   z:     k = 256 + (8 role + (row & 7)) * 8 + 2 q + (row >> 3)      (tile rows = (a0, local channel))
+    float wx[4][8], wy[4][8], wz[4][8];
 #pragma unroll
     for (int sp = 0; sp < 8; ++sp) {
         const float* w = W1 + (4 * sp + kq) * 384;
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            wx[kt][sp] = w[16 * kt + row];
-            wy[kt][sp] = w[128 + 16 * kt + row];
+        for (int kt = 0; kt < 4; ++kt) {
+            wx[kt][sp] = w[16 * (4 * role + kt) + row];
+            wy[kt][sp] = w[128 + 16 * (4 * role + kt) + row];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int a0 = 0; a0 < 2; ++a0) wz[q][a0][sp] = w[256 + row * 8 + 2 * q + a0];
+        for (int q = 0; q < 4; ++q) wz[q][sp] = w[256 + (8 * role + (row & 7)) * 8 + 2 * q + (row >> 3)];
     }
     const GatherLane glane = gather_lane(lane);
 
     const long hstep = (long)gridDim.x * 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
-        for (int i = tid; i < 512 * kDvRow; i += kBwdThreads) lds_dv[i] = 0ll;
+        for (int i = tid; i < 512 * kDvRow; i += kVolThreads) lds_dv[i] = 0ll;
         __syncthreads();
         // every addend w * dX (w <= 1) is rounded to a 32-bit integer in units of 2^-fx_exp with |addend| < 2^30;
         // the 64-bit words then have room for 2^33 of them
@@ -939,12 +889,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
         const int fx_exp = usable ? min(max(30 - ex, -80), 80) : 0;
         const float fx_scale = usable ? ldexpf(1.0f, fx_exp) : 0.0f;
         const float* Rb = R + (long)b * r_batch_stride;
-        long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        long h = (long)slot * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
         DuRegs du;
-        if (h < N) {  // prologue of the pipeline: quarter 0 of this wave's first hypothesis
-            load_du_regs(du, du_ws + ((long)b * N + h) * 2048, lane);
-            BwdVolDx<0, 0>::run(wx, wy, wz, du, x0, lane);
-        }
+        if (h < N) load_du_regs(du, du_ws + ((long)b * N + h) * 2048, lane);
         for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
@@ -954,22 +901,33 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_volume_kernel(
             DuRegs nxt;  // the next hypothesis's du travels from HBM / L2 while this one is processed
             const long hn = (h + hstep < N) ? h + hstep : h;
             load_du_regs(nxt, du_ws + ((long)b * N + hn) * 2048, lane);
+            bwd_vol_dx<0>(wx, wy, wz, du, xbuf, lane);
+            AHV_VOL_PRIO(1);
             bwd_vol_corners<0>(ctab, gh, lane); wave_lds_fence();
-            bwd_vol_merged<1>(wx, wy, wz, du, x0, x1, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
+            AHV_VOL_PRIO(0);
+            bwd_vol_dx<1>(wx, wy, wz, du, xbuf, lane);
+            AHV_VOL_PRIO(1);
             bwd_vol_corners<1>(ctab, gh, lane); wave_lds_fence();
-            bwd_vol_merged<2>(wx, wy, wz, du, x1, x0, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
+            AHV_VOL_PRIO(0);
+            bwd_vol_dx<2>(wx, wy, wz, du, xbuf, lane);
+            AHV_VOL_PRIO(1);
             bwd_vol_corners<2>(ctab, gh, lane); wave_lds_fence();
-            bwd_vol_merged<3>(wx, wy, wz, du, x0, x1, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
+            AHV_VOL_PRIO(0);
+            bwd_vol_dx<3>(wx, wy, wz, du, xbuf, lane);
+            AHV_VOL_PRIO(1);
             bwd_vol_corners<3>(ctab, gh, lane); wave_lds_fence();
-            // the last scatter of this hypothesis carries quarter 0 of the next one (a harmless repeat on the last)
-            bwd_vol_merged<0>(wx, wy, wz, nxt, x1, x0, ctab, lds_dv, fx_scale, lane); wave_lds_fence();
+            bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
+            AHV_VOL_PRIO(0);
             du = nxt;
         }
         __syncthreads();
         // non-finite upstream gradients: the bound is inf/NaN, nothing was accumulated -> report NaN like autograd would
         const float unscale = usable ? ldexpf(1.0f, -fx_exp) : (bound == 0.0f ? 0.0f : __builtin_nanf(""));
         float* gv = grad_vol + (long)b * (16 * 512);
-        for (int i = tid; i < 16 * 512; i += kBwdThreads) {
+        for (int i = tid; i < 16 * 512; i += kVolThreads) {
             const int c = i >> 9, v = i & 511;
             const long long a = lds_dv[v * kDvRow + c];
             if (a != 0ll || !usable) global_add(gv + i, (float)a * unscale + (usable ? 0.0f : unscale));
@@ -1008,7 +966,7 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     hipLaunchKernelGGL(score_backward_w1_reduce_kernel, dim3(32 * 384 / 256, 16), dim3(256), 0, stream, dw1_partials,
                        gx * gy, grad_W1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kBwdThreads), 0, stream, R, (long)r_batch_stride, W1,
+    hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kVolThreads), 0, stream, R, (long)r_batch_stride, W1,
                        B, (long)N, du_ws, du_max_bits, grad_vol);
     return hipGetLastError();
 }

@@ -62,7 +62,7 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(ahv::score_backward_w1_kernel, grid, dim3(ahv::kW1Threads), 0, 0, dvol, dR, (long)(N * 9), B, N, dws, dpart);
         hipLaunchKernelGGL(ahv::score_backward_w1_reduce_kernel, dim3(32 * 384 / 256, 16), dim3(256), 0, 0, dpart, gx * gy, gW1);
         CK(hipEventRecord(e[2], 0));
-        hipLaunchKernelGGL(ahv::score_backward_volume_kernel, grid, dim3(ahv::kBwdThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, dmax, gvol);
+        hipLaunchKernelGGL(ahv::score_backward_volume_kernel, grid, dim3(ahv::kVolThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, dmax, gvol);
         CK(hipEventRecord(e[3], 0));
         CK(hipEventSynchronize(e[3]));
         CK(hipGetLastError());

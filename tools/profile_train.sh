@@ -23,6 +23,8 @@ for r in csv.DictReader(open(t)):
 rows = []
 for k, v in sorted(d.items()):
     big = [x for x in v if x > 100.0]
+    if not big:
+        continue
     rows.append((k, len(big), sum(big) / max(len(big), 1), min(big), max(big)))
     print("%-48s full-size launches %3d  avg %8.1f us  min %8.1f  max %8.1f" % rows[-1])
 with open("$OUT/training_kernels.csv", "w") as o:
