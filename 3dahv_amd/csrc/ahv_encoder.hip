@@ -381,6 +381,133 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
+// Attention + output projection in one launch, for small batches (CrossAttention.forward,
+// transformer/attention.py:214-237, up to but not including to_out's bias).  grid = (B * nprob, 4 query tiles,
+// 4 column quarters); 256 threads = one wave per HEAD.  Each wave computes its head's O^T tile exactly as
+// attention_kernel does (the three column-quarter siblings repeat it: 96 MFMAs and 36 KB of L2 reads, cheaper than
+// a launch boundary while B is small), and then contracts it with its 64-column slice of W_out:
+// D^T[n][q] = sum_d W_out[n][64 h + d] O_h[q][d].  Accumulator register r of tile dt holds
+// O[q = lane & 15][d = 16 dt + 4 kq + r], which IS the B operand of the k-step whose four k values are
+// {16 dt + 4 kq + r}, and the matching A operand is component r of ONE aligned float4 of W_out per lane and dt: no
+// lane movement, no LDS round trip.  The four heads' partial tiles meet in LDS.  Output: P[M][256] without bias
+// (ln_kernel adds it), i.e. one split-K slab.  Measured at B = 1: one launch less per block pair, 409 -> 391 us
+// per forward_2d3d replayed from a hipGraph; at B = 32 the repeated attention costs more than the launch (+4 %),
+// so run_block_pair keeps the two-kernel form there.
+// -------------------------------------------------------------------------------------------------
+struct AttnOutProb {
+    const float *Q, *K, *V;
+    const float* Wo;  // [256][256] to_out.0.weight
+    float* P;         // [M][256]
+    long ldq, ldkv;
+};
+struct AttnOutArgs {
+    AttnOutProb p[2];
+    int B;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attention_out_kernel(const AttnOutArgs a)
+{
+    __shared__ float red[4 * 64 * 17];
+    const int lane = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // head of this wave
+    const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
+    const AttnOutProb pr = a.p[pi];
+    const int it = blockIdx.y, nq = blockIdx.z;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const float* q = pr.Q + (long)b * 64 * pr.ldq + h * 64 + (long)(it * 16 + c16) * pr.ldq + 4 * kq;
+    const float* k = pr.K + (long)b * 64 * pr.ldkv + h * 64 + (long)c16 * pr.ldkv + 4 * kq;
+    const float* v = pr.V + (long)b * 64 * pr.ldkv + h * 64 + c16;
+    // every operand is requested before the first MFMA
+    f32x4 ka[4][4], qb[4], wf[4][4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+        qb[ds] = *reinterpret_cast<const f32x4*>(q + 16 * ds);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ka[ds][jt] = *reinterpret_cast<const f32x4*>(k + (long)(jt * 16) * pr.ldkv + 16 * ds);
+    }
+    float va[4][4][4];  // [jt][r][dt]: V[jt*16 + 4kq + r][dt*16 + c16]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) va[jt][r][dt] = v[(long)(jt * 16 + 4 * kq + r) * pr.ldkv + dt * 16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            wf[nt][dt] = *reinterpret_cast<const f32x4*>(pr.Wo + (long)(nq * 64 + nt * 16 + c16) * 256 + h * 64 + 16 * dt + 4 * kq);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 st[4];  // [jt]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                st[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][jt][s], qb[ds][s], st[jt], 0, 0, 0);
+    // softmax over the 64 keys of query column i = it*16 + c16
+    float m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[jt][r] *= a.scale;
+            m = fmaxf(m, st[jt][r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = expf(st[jt][r] - m);
+            st[jt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    f32x4 ot[4];  // [dt]
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = st[jt][r] * inv;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[jt][r][dt], p, ot[dt], 0, 0, 0);
+        }
+    // this head's share of the output projection: D^T[n][q] += W_out[n][64 h + d] O[q][d]
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][dt][r], ot[dt][r], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(h * 64 + nt * 16 + 4 * kq + r) * 17 + c16] = acc[nt][r];
+    __syncthreads();
+    float* out = pr.P + ((long)b * 64 + it * 16) * 256 + nq * 64;
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int qq = i >> 6, n = i & 63;
+        out[(long)qq * 256 + n] = red[n * 17 + qq] + red[(64 + n) * 17 + qq] + red[(128 + n) * 17 + qq] + red[(192 + n) * 17 + qq];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Row kernels (one wave per 256-wide row; blockIdx.y = problem).
 // -------------------------------------------------------------------------------------------------
 struct LnProb {
@@ -628,9 +755,22 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         AHV_TRY(launch_linear(sp, 4, 256, 256, M, 256, 1, 0, s), "q / kv projections");
         for (int i = 0; i < 2; ++i) at.p[i] = AttnProb{ws[i].qkv, ws[i].kv, ws[i].kv + 256, ws[i].att, 256, 512};
     }
-    hipLaunchKernelGGL(attention_kernel, dim3(2 * B, 4), dim3(256), 0, s, at);
-    AHV_TRY(hipGetLastError(), "attention");
-    {
+    if (B <= 4) {  // small batch: attention and the output projection in ONE launch (attention_out_kernel)
+        AttnOutArgs ao;
+        ao.B = B;
+        ao.scale = at.scale;
+        for (int i = 0; i < 2; ++i)
+            ao.p[i] = AttnOutProb{at.p[i].Q, at.p[i].K, at.p[i].V, w[i]->w_out, ws[i].part, at.p[i].ldq, at.p[i].ldkv};
+        hipLaunchKernelGGL(attention_out_kernel, dim3(2 * B, 4, 4), dim3(256), 0, s, ao);
+        AHV_TRY(hipGetLastError(), "attention + out projection");
+        LnArgs ln;
+        ln.KS = 1; ln.M = M;
+        for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].part, w[i]->b_out, w[i]->ln1_g, w[i]->ln1_b, x[i], ws[i].cat};
+        hipLaunchKernelGGL(ln_kernel<true>, dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_TRY(hipGetLastError(), "norm1 + concat");
+    } else {
+        hipLaunchKernelGGL(attention_kernel, dim3(2 * B, 4), dim3(256), 0, s, at);
+        AHV_TRY(hipGetLastError(), "attention");
         LinSpec sp[2];
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].att, w[i]->w_out, ws[i].part, nullptr, 256};
         AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 2, 0, s), "out projection");
