@@ -15,7 +15,7 @@ t = glob.glob("$OUT/trace/*/*_kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "nchw_to_tokens" in r["Kernel_Name"]]
 # one B = 1 forward in the middle of the eager timing loop (grid of nchw_to_tokens tells B)
-segs = [(a, b) for a, b in zip(idx, idx[1:]) if 60 <= b - a <= 90]
+segs = [(a, b) for a, b in zip(idx, idx[1:]) if 30 <= b - a <= 90]
 a, b = segs[len(segs) // 2]
 seg = rows[a:b]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in seg]
