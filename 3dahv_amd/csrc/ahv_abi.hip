@@ -30,6 +30,7 @@ hipError_t launch_so3_grid(int64_t, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
                                  const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*, float*,
                                  float*, float*, int, hipStream_t);
+hipError_t launch_zero_fill(void* const* ptrs, const size_t* bytes, int count, hipStream_t stream);
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
 size_t forward_2d3d_workspace_floats(int B);
@@ -86,6 +87,14 @@ int ahv_device_cu_count(void)
     return cu;
 }
 
+// hipMemsetAsync is not used anywhere in the library: see zero_fill_kernel (ahv_ops.hip).
+static hipError_t zero_span(void* p, size_t bytes, hipStream_t s)
+{
+    void* const ptrs[1] = {p};
+    const size_t n[1] = {bytes};
+    return ahv::launch_zero_fill(ptrs, n, 1, s);
+}
+
 static int score_common(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
                         int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
                         float* scores, uint64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream)
@@ -100,8 +109,8 @@ static int score_common(const float* vol_src, const float* feat_tgt, const float
     if (flags & ~(AHV_SCORE_RESET_BEST | AHV_SCORE_SPLIT_F16)) return fail(AHV_EINVAL, "score: unknown flags 0x%x", flags);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (best_key && (flags & AHV_SCORE_RESET_BEST) && B > 0) {
-        hipError_t e = hipMemsetAsync(best_key, 0, sizeof(uint64_t) * (size_t)B, s);
-        if (e != hipSuccess) return hip_fail("score: hipMemsetAsync(best_key)", e);
+        hipError_t e = zero_span(best_key, sizeof(uint64_t) * (size_t)B, s);
+        if (e != hipSuccess) return hip_fail("score: zero fill (best_key)", e);
     }
     if (B == 0 || N == 0) return AHV_OK;
     const int cu = cu_count();
@@ -171,8 +180,8 @@ int ahv_rotate_volume_backward_f32(const float* grad_out, int64_t vol_batch_stri
     const int64_t n_vol = vol_batch_stride == 0 ? 1 : N;
     if (n_vol > 0) {
         const size_t bytes = sizeof(float) * (size_t)(vol_batch_stride == 0 ? vol_elems : (N - 1) * vol_batch_stride + vol_elems);
-        hipError_t e = hipMemsetAsync(grad_vol, 0, bytes, s);
-        if (e != hipSuccess) return hip_fail("rotate_volume_backward: hipMemsetAsync", e);
+        hipError_t e = zero_span(grad_vol, bytes, s);
+        if (e != hipSuccess) return hip_fail("rotate_volume_backward: zero fill", e);
     }
     if (N == 0) return AHV_OK;
     if (!grad_out || !R) return fail(AHV_EINVAL, "rotate_volume_backward: null pointer");
@@ -362,8 +371,8 @@ int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint
     if (flags & ~AHV_SCORE_RESET_BEST) return fail(AHV_EINVAL, "argmax: unknown flags 0x%x", flags);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((flags & AHV_SCORE_RESET_BEST) && B > 0) {
-        hipError_t e = hipMemsetAsync(best_key, 0, sizeof(uint64_t) * (size_t)B, s);
-        if (e != hipSuccess) return hip_fail("argmax: hipMemsetAsync(best_key)", e);
+        hipError_t e = zero_span(best_key, sizeof(uint64_t) * (size_t)B, s);
+        if (e != hipSuccess) return hip_fail("argmax: zero fill (best_key)", e);
     }
     if (B == 0 || N == 0) return AHV_OK;
     const int cu = cu_count();

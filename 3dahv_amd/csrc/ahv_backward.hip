@@ -935,6 +935,8 @@ __global__ __launch_bounds__(kVolThreads, 2) void score_backward_volume_kernel(
     }
 }
 
+hipError_t launch_zero_fill(void* const* ptrs, const size_t* bytes, int count, hipStream_t stream);  // ahv_ops.hip
+
 // ---- host-side launcher -------------------------------------------------------------------------------
 hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
                                  const float* W1, const float* W2, const float* b2, int B, int64_t N,
@@ -943,13 +945,13 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
                                  float* grad_W1, float* grad_W2, float* grad_b2, int num_cu, hipStream_t stream)
 {
     hipError_t e;
-    if ((e = hipMemsetAsync(grad_vol, 0, sizeof(float) * (size_t)B * 8192, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(grad_feat_tgt, 0, sizeof(float) * (size_t)B * 2048, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(grad_W1, 0, sizeof(float) * 32 * 384, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(grad_W2, 0, sizeof(float) * 32 * 32, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(grad_b2, 0, sizeof(float) * 32, stream)) != hipSuccess) return e;
+    {   // accumulation targets (and the running maximum of |du|, bit pattern 0 = 0.0f): one zero-fill launch
+        void* const ptrs[6] = {grad_vol, grad_feat_tgt, grad_W1, grad_W2, grad_b2, du_max_bits};
+        const size_t bytes[6] = {sizeof(float) * (size_t)B * 8192, sizeof(float) * (size_t)B * 2048, sizeof(float) * 32 * 384,
+                                 sizeof(float) * 32 * 32, sizeof(float) * 32, (B > 0 && N > 0) ? sizeof(unsigned) * (size_t)B : 0};
+        if ((e = launch_zero_fill(ptrs, bytes, 6, stream)) != hipSuccess) return e;
+    }
     if (B == 0 || N == 0) return hipSuccess;
-    if ((e = hipMemsetAsync(du_max_bits, 0, sizeof(unsigned) * (size_t)B, stream)) != hipSuccess) return e;
     int gy = B < num_cu ? B : num_cu;
     int gx = num_cu / gy;
     const int64_t need = (N + 3) / 4;

@@ -692,4 +692,49 @@ hipError_t launch_argmax(const float* scores, int B, int64_t N, int64_t n_offset
     return hipGetLastError();
 }
 
+// ---- zero fill ------------------------------------------------------------------------------------------
+// The library's accumulation targets (gradients, best keys) are zeroed by THIS kernel, not by hipMemsetAsync: a run
+// of memset nodes captured into a hipGraph (six in front of the scorer backward) did not reliably take effect on
+// replay on ROCm 7.2 -- replay 0 was right because fresh pool memory is zero, every later replay accumulated onto
+// whatever the pool block held (tests/test_gpu_graph_replay.py).  One launch for up to six spans.
+struct ZeroSpans {
+    void* p[6];
+    unsigned long long bytes[6];  // multiples of 4
+};
+
+__global__ __launch_bounds__(256) void zero_fill_kernel(const ZeroSpans a)
+{
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * 256 + threadIdx.x, step = (unsigned long long)gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned long long nb = a.bytes[k];
+        if (nb == 0) continue;
+        unsigned long long n16 = (reinterpret_cast<unsigned long long>(a.p[k]) & 15) ? 0 : nb >> 4;
+        uint4* q = static_cast<uint4*>(a.p[k]);
+        for (unsigned long long i = i0; i < n16; i += step) q[i] = uint4{0u, 0u, 0u, 0u};
+        unsigned* d = static_cast<unsigned*>(a.p[k]) + 4 * n16;
+        const unsigned long long nd = (nb >> 2) - 4 * n16;
+        for (unsigned long long i = i0; i < nd; i += step) d[i] = 0u;
+    }
+}
+
+hipError_t launch_zero_fill(void* const* ptrs, const size_t* bytes, int count, hipStream_t stream)
+{
+    if (count < 0 || count > 6) return hipErrorInvalidValue;
+    ZeroSpans a;
+    unsigned long long most = 0;
+    for (int k = 0; k < 6; ++k) {
+        a.p[k] = k < count ? ptrs[k] : nullptr;
+        a.bytes[k] = (k < count && ptrs[k]) ? bytes[k] : 0;
+        if (a.bytes[k] & 3) return hipErrorInvalidValue;
+        if (a.bytes[k] > most) most = a.bytes[k];
+    }
+    if (most == 0) return hipSuccess;
+    unsigned long long blocks = (most / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 }  // namespace ahv
