@@ -277,8 +277,11 @@ int ahv_forward_2d3d_f32(const ahv_aligner_weights* w, const float* layer4_src, 
  * grad_scores[B][N] = dL/dscore it writes (not accumulates)
  *   grad_vol_src [B][16][8][8][8], grad_feat_tgt [B][32][64], grad_W1 [32][384], grad_W2 [32][32], grad_b2 [32].
  * R carries no gradient (the reference samples it).  r_batch_stride as in the forward (0 = shared, N*9 = the
- * per-sample rotations of training).  The workspace holds dL/du, 8 KiB per hypothesis; sums across
- * hypotheses use float atomics, so results are reproducible to rounding, not bitwise.
+ * per-sample rotations of training).  The workspace holds dL/du (8 KiB per hypothesis), one word per sample and one
+ * partial dW1 (48 KiB) per workgroup of the persistent grid; ask ahv_score_hypotheses_backward_workspace_bytes.
+ * Sums across hypotheses use float atomics (d vol: exact fixed-point sums per workgroup, then float atomics), so
+ * results are reproducible to rounding, not bitwise.  Graph-capturable: the accumulation targets are zeroed by a
+ * kernel of the library, not by hipMemsetAsync.
  */
 size_t ahv_score_hypotheses_backward_workspace_bytes(int B, int64_t N);
 

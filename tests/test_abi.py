@@ -52,7 +52,9 @@ def test_argument_validation_needs_no_gpu(lib, ahv):
     with pytest.raises(ahv._lib.AhvError):
         ahv._lib.check(rc, "x")
     # backward entry point: workspace size is a pure function; pointer / stride / workspace checks come first
-    assert lib.ahv_score_hypotheses_backward_workspace_bytes(2, 10) == 4 * (2048 * 20 + 4)
+    # dL/du + one max|du| word per sample (padded to 16 B) + one partial dW1 per workgroup (one per CU; 1024 with no device)
+    cu = lib.ahv_device_cu_count()
+    assert lib.ahv_score_hypotheses_backward_workspace_bytes(2, 10) == 4 * (2048 * 20 + 4 + (cu if cu > 0 else 1024) * 32 * 384)
     assert lib.ahv_score_hypotheses_backward_workspace_bytes(0, 10) == 0
     bw = lib.ahv_score_hypotheses_backward_f32
     assert bw(1, 1, 1, 0, 1, 1, 1, 1, 10, 1, 16, 1 << 30, 1, 1, None, 1, 1, None) == -1 and b"weight-gradient" in lib.ahv_last_error()
