@@ -13,6 +13,7 @@
 //       per-workgroup LDS image of dV that is flushed once per sample.
 // All contractions are fp32 MFMA 16x16x4 (one float per lane and operand, so any LDS layout can feed them).
 // Accumulation across waves/workgroups uses float atomics: gradients are reproducible to rounding, not bitwise.
+// Accumulation targets are zeroed by launch_zero_fill (ahv_ops.hip), never by hipMemsetAsync (not graph-safe here).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -278,8 +279,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Kernels 2a / 2b.  Both walk the hypotheses again with du from the workspace.  They are separate launches
-// because each needs 192 registers of persistent state per wave (2a: the dW1 accumulators, 2b: the W1^T
-// fragments) next to a gather / scatter that wants ~100 more: together they spill, apart they do not.
+// because each carries persistent state per wave (2a: the dW1 accumulators, 2b: the W1^T fragments; 96 registers
+// each since the outputs are split over the two waves of a SIMD) next to a gather / scatter that wants ~100 more:
+// together they spill, apart they do not.
 //   2a  score_backward_w1_kernel      re-gathers each quarter X of the rotated volume, dW1 += du X^T
 //   2b  score_backward_volume_kernel  dX = W1^T du per quarter, dV += trilinear^T dX in an LDS image of the
 //                                     sample's volume gradient, flushed once per sample

@@ -5,13 +5,11 @@
 // (modules/modules.py:64,97); head GEMM K = 3*16*8 = 384 -> 32 channels at 64
 // positions (modules/modules.py:66-70,112-124).
 //
-// Work decomposition: ONE WAVE OWNS ONE HYPOTHESIS.  The wave keeps the whole
-// 32x384 W1 matrix as MFMA A-fragments in its own registers (192 VGPRs; the
-// kernel runs one wave per SIMD with the 512-register budget), produces the
-// rotated volume a QUARTER at a time (d in {2q,2q+1}: 128 voxels x 16 ch = 8 KiB)
-// into a private LDS buffer, and contracts that quarter against W1 with
-// v_mfma_f32_16x16x4_f32.  Waves never synchronise with each other inside the
-// hypothesis loop: no s_barrier on the hot path.
+// Work decomposition: ONE WAVE OWNS ONE HYPOTHESIS.  It produces the rotated volume a QUARTER at a time
+// (d in {2q,2q+1}: 128 voxels x 16 ch = 8 KiB) into a private LDS buffer and contracts that quarter against W1
+// with v_mfma_f32_16x16x4_f32.  Waves never synchronise with each other inside the hypothesis loop: no s_barrier
+// on the hot path.  (Where W1 lives -- LDS fragment table, two waves per SIMD -- is ahv_dual.h; the kernels that
+// kept it in 192 registers at one wave per SIMD are retired to tools/legacy/.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,4 +1,5 @@
-// ahv_dual.h -- two-waves-per-SIMD formulation of the fused scorer ("dual", score_variant 3).
+// ahv_dual.h -- two-waves-per-SIMD formulation of the fused scorer (score_hypotheses_dual_kernel, the library's
+// fp32 kernel) and the pieces the backward and forward_3d2d share with it.
 //
 // Why: on gfx950 an fp32 MFMA and VALU work never overlap (tools/valu_probe.cpp: an MFMA-only wave and
 // a VALU-only wave on one SIMD take the SUM of their times), a lone wave issues a VALU instruction only
@@ -9,7 +10,8 @@
 // (lane-linear, one conflict-free ds_read_b128 = the A operands of 4 MFMAs).
 //
 // Workgroup = 512 threads = 8 waves, one hypothesis per wave, no barrier on the hot path.
-// LDS (152 KiB): source image 40 KiB + W1 fragment table 48 KiB + 8 x 8 KiB quarter images.
+// LDS (158 KiB): source image 46 KiB (80-byte voxel rows, y rows 640 B and z planes 5 920 B apart; the pads hold
+// the target fragments) + W1 fragment table 48 KiB + 8 x 8 KiB quarter images.
 #pragma once
 #include "ahv_device.h"
 

@@ -85,7 +85,7 @@ __device__ unsigned long long g_stamps[2048 * 16];
 // ---------------------------------------------------------------------------------------
 constexpr int kDualThreads = 512;
 
-// SPLIT = true: GEMM1 on the f16 matrix pipe with hi/lo split operands (ahv_split.h, score_variant 4).
+// SPLIT = true: GEMM1 on the f16 matrix pipe with hi/lo split operands (ahv_split.h; AHV_SCORE_SPLIT_F16).
 template <bool SPLIT>
 __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,

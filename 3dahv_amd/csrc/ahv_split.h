@@ -1,8 +1,8 @@
-// ahv_split.h -- GEMM1 of the fused scorer on the f16 matrix pipe with split operands ("split",
-// score_variant 4, OPT-IN: the default stays the all-fp32 dual kernel).
+// ahv_split.h -- GEMM1 of the fused scorer on the f16 matrix pipe with split operands (OPT-IN per call through
+// AHV_SCORE_SPLIT_F16: the default stays the all-fp32 dual kernel).
 //
 // Why: fp32 MFMA tops out at 157 TFLOP/s and shares its issue slots with VALU work (ahv_dual.h), so the
-// fp32 kernel sits at ~70 % of a roofline that is itself 16x below the f16 matrix pipe.  Each fp32
+// fp32 kernel sits at ~80 % of a roofline that is itself 16x below the f16 matrix pipe.  Each fp32
 // operand x is written as hi + lo with hi = x truncated to 11 significant bits and lo = x - hi rounded
 // to f16; the three products hi*hi + hi*lo + lo*hi are accumulated in fp32 by v_mfma_f32_16x16x32_f16
 // (hi*hi is exact in fp32, the dropped lo*lo term is 2^-22 relative).  Measured against the fp32
