@@ -263,3 +263,149 @@ void ahv_oracle_geodesic_deg_f32(const float* R_pred, const float* R_gt, int64_t
         err_deg[i] = acosf(sim) * 180.0f / 3.14159265358979323846f;
     }
 }
+
+/* =====================================================================================================
+ * "_cpu" twins of the C ABI ("identical signatures with suffix _cpu operating on host
+ * pointers = the build's CPU restatement, used for ABI tests").  TEST INFRASTRUCTURE like the rest of this file:
+ * they live in libahv_oracle.so, never in libahv_hip.so, and exist so that a GPU-free test can drive the product's
+ * own ctypes signature table (3dahv_amd/_lib.py SIGNATURES) through a real computation -- argument order, integer
+ * widths, strides, the packed-key convention and its merge / reset flag -- against the golden vectors.
+ * Signatures: include/ahv.h, declaration by declaration; `stream` is ignored; return 0 or -1.
+ * ===================================================================================================== */
+#include <string.h>
+
+#define AHV_TWIN_RESET_BEST 1u
+
+/* ahv_device.h pack_key: key = ordered_u32(score) << 32 | (0xFFFFFFFF - idx); NaN ranks above +inf; -0 == +0 */
+static uint64_t twin_pack_key(float s, uint32_t idx)
+{
+    s += 0.0f;
+    uint32_t u;
+    memcpy(&u, &s, 4);
+    if (s != s) u = 0x7FC00000u;
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - idx);
+}
+
+static void twin_merge(uint64_t* best_key, int B, int64_t N, int64_t n_offset, const float* scores, unsigned flags)
+{
+    for (int b = 0; b < B; ++b) {
+        uint64_t k = (flags & AHV_TWIN_RESET_BEST) ? 0 : best_key[b];
+        for (int64_t n = 0; n < N; ++n) {
+            const uint64_t c = twin_pack_key(scores[(int64_t)b * N + n], (uint32_t)(n_offset + n));
+            if (c > k) k = c;
+        }
+        best_key[b] = k;
+    }
+}
+
+int ahv_rotate_volume_f32_cpu(const float* vol, int64_t vol_batch_stride, const float* R, int64_t N, int C, int D,
+                              int H, int W, float* out, void* stream)
+{
+    (void)stream;
+    if (N < 0 || C < 1 || D < 1 || H < 1 || W < 1) return -1;
+    if (N == 0) return 0;
+    if (!vol || !R || !out) return -1;
+    ahv_oracle_rotate_volume_f32(vol, vol_batch_stride, R, N, C, D, H, W, out);
+    return 0;
+}
+
+int ahv_forward_3d2d_f32_cpu(const float* vol, const float* W1, const float* W2, const float* b2, int64_t M,
+                             float* out, void* stream)
+{
+    (void)stream;
+    if (M < 0) return -1;
+    if (M == 0) return 0;
+    if (!vol || !W1 || !W2 || !b2 || !out) return -1;
+    ahv_oracle_forward_3d2d_f32(vol, W1, W2, b2, M, out);
+    return 0;
+}
+
+int ahv_score_features_f32_cpu(const float* f_src, const float* f_tgt, int B, int64_t N, float* scores, void* stream)
+{
+    (void)stream;
+    if (B < 0 || N < 0) return -1;
+    if (B == 0 || N == 0) return 0;
+    if (!f_src || !f_tgt || !scores) return -1;
+    ahv_oracle_score_features_f32(f_src, f_tgt, B, N, scores);
+    return 0;
+}
+
+int ahv_argmax_f32_cpu(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key, unsigned flags,
+                       void* stream)
+{
+    (void)stream;
+    if (!scores || !best_key || B < 0 || N < 0 || n_offset < 0 || n_offset + N > 4294967296ll) return -1;
+    twin_merge(best_key, B, N, n_offset, scores, flags);
+    return 0;
+}
+
+/* feat_tgt [B][32][64] is GIVEN here (forward_3d2d of the target volume), as in the product's entry point */
+int ahv_score_hypotheses_f32_cpu(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
+                                 int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
+                                 float* scores, uint64_t* best_key, unsigned flags, void* stream)
+{
+    (void)stream;
+    if (B < 0 || N < 0 || (!scores && !best_key)) return -1;
+    if (r_batch_stride != 0 && r_batch_stride < N * 9) return -1;
+    if (n_offset < 0 || n_offset + N > 4294967296ll) return -1;
+    if (best_key && (flags & AHV_TWIN_RESET_BEST))
+        for (int b = 0; b < B; ++b) best_key[b] = 0;
+    if (B == 0 || N == 0) return 0;
+    if (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2) return -1;
+    const int64_t VOL = AHV_CV * AHV_S * AHV_S * AHV_S, FEAT = AHV_O * AHV_P, CH = 256;
+    float* rot = (float*)malloc(sizeof(float) * CH * VOL);
+    float* fs = (float*)malloc(sizeof(float) * CH * FEAT);
+    float* sc = (float*)malloc(sizeof(float) * CH);
+    if (!rot || !fs || !sc) { free(rot); free(fs); free(sc); return -1; }
+    for (int b = 0; b < B; ++b)
+        for (int64_t n0 = 0; n0 < N; n0 += CH) {
+            const int64_t n = (N - n0 < CH) ? (N - n0) : CH;
+            ahv_oracle_rotate_volume_f32(vol_src + b * VOL, 0, R + b * r_batch_stride + n0 * 9, n, AHV_CV, AHV_S, AHV_S,
+                                         AHV_S, rot);
+            ahv_oracle_forward_3d2d_f32(rot, W1, W2, b2, n, fs);
+            ahv_oracle_score_features_f32(fs, feat_tgt + b * FEAT, 1, n, sc);
+            if (scores) memcpy(scores + (int64_t)b * N + n0, sc, sizeof(float) * n);
+            if (best_key) twin_merge(best_key + b, 1, n, n_offset + n0, sc, 0);
+        }
+    free(rot); free(fs); free(sc);
+    return 0;
+}
+
+/* ahv_device.h key_score / key_index; a key of 0 (nothing scored) decodes to -inf, -1 */
+int ahv_unpack_best_cpu(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
+{
+    (void)stream;
+    if (!best_key || B < 0) return -1;
+    for (int b = 0; b < B; ++b) {
+        const uint64_t k = best_key[b];
+        uint32_t u = (uint32_t)(k >> 32);
+        float s;
+        if (k == 0) {
+            s = -INFINITY;
+        } else {
+            u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+            memcpy(&s, &u, 4);
+        }
+        if (best_score) best_score[b] = s;
+        if (best_idx) best_idx[b] = k == 0 ? -1 : (int64_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu));
+    }
+    return 0;
+}
+
+int ahv_select_rotation_f32_cpu(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                                int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, void* stream)
+{
+    if (ahv_unpack_best_cpu(best_key, B, best_score, NULL, stream)) return -1;
+    for (int b = 0; b < B; ++b) {
+        const uint64_t k = best_key[b];
+        const int64_t idx = k == 0 ? -1 : (int64_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu));
+        if (best_idx) best_idx[b] = idx;
+        if (R_out) {
+            const int64_t local = idx - n_offset;
+            for (int i = 0; i < 9; ++i)
+                R_out[b * 9 + i] = (idx >= 0 && local >= 0 && local < N) ? R[b * r_batch_stride + local * 9 + i] : 0.0f;
+        }
+    }
+    return 0;
+}
