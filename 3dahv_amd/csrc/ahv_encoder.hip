@@ -192,6 +192,147 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
+// The same linear, K-PIPELINED through LDS (MODE 0 / 1; grid and LinArgs as linear_kernel, 256 threads).
+// linear_kernel requests its whole operand set at once and as MFMA fragments: the four lanes of a quad then sit
+// in four different 128-byte lines and the texture path delivers ~16 B/clk (tools/launch_floor.cpp: 128 KB re-read
+// per workgroup 3.3 us as fragments, 1.15 us row-contiguous), so a workgroup of the FF-in projection spends ~5 us
+// receiving 192 KB before its last wave can start its MFMAs, and ends with an 8-way reduction through LDS.
+// Here the workgroup walks K in stages of 64 columns: X[64][64] and W[16 NT][64] are fetched row-contiguously
+// (16 lanes = one 256-byte row segment), parked in a double-buffered LDS stage (row stride 68 floats: a fragment
+// read of 16 rows x one float4 covers all 64 banks once) while the MFMAs of the previous stage run, and wave w
+// owns output rows 16 w .. 16 w + 15 over ALL of the workgroup's columns and ALL of K -- no cross-wave reduction,
+// and the value and gate tiles of the GEGLU projection meet in one lane's registers.
+// -------------------------------------------------------------------------------------------------
+constexpr int kStageK = 64;    // K columns per stage
+constexpr int kStageLd = 68;   // floats per staged row
+
+template <int NT, int KC, bool GEGLU_OUT, int MODE = 0>
+__global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
+{
+    static_assert(MODE == 0 || MODE == 1, "MODE 2 (3-D taps) stays with linear_kernel");
+    static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
+    constexpr int NS = KC / kStageK;  // stages
+#ifndef AHV_STAGED_DEPTH
+#define AHV_STAGED_DEPTH 2
+#endif
+    constexpr int DEPTH = AHV_STAGED_DEPTH < NS ? AHV_STAGED_DEPTH : NS;  // stages requested ahead of their use
+    // two stage buffers (26 KB each at NT = 2): 2 workgroups per CU once M > 64.  (Three buffers with the next
+    // stage's fragments read ahead of the MFMAs were measured: equal at B = 1, 5-14 % slower at B = 2..8.)
+    __shared__ __attribute__((aligned(16))) float sx[2][64 * kStageLd];
+    __shared__ __attribute__((aligned(16))) float sw[2][16 * NT * kStageLd];
+    __shared__ __attribute__((aligned(16))) float comb[4 * 64 * 4];  // the second wave of each pair hands its tile over
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Two waves per SIMD (a lone wave issues an fp32 MFMA only every ~40 cycles): wave = (row tile rt, half h).
+    // NT = 2 (GEGLU): h = n-tile (0 value, 1 gate).  NT = 1: h = half of every stage's K (k-steps 2h, 2h + 1).
+    const int rt = wave & 3, half = wave >> 2;
+    AHV_ENC_STAMP(0);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxProb; ++i)
+        if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile0) pi = i;
+    const LinProb pr = a.p[pi];
+    const int tile = (int)blockIdx.x - pr.tile0;
+    const int n0 = GEGLU_OUT ? tile * 16 : tile * 16 * NT;
+    const int nstep = GEGLU_OUT ? a.geglu_h : 16;  // distance between the workgroup's n-tiles
+    const int ks = blockIdx.y;
+    const int m0 = blockIdx.z * 64;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // staging map: thread -> (row tid / 16 (+32), float4 column tid % 16); W: 16 NT rows, the first 256 NT threads
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+    const float* xg[2];
+    bool xok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = srow + 32 * j;  // row inside the 64-row tile
+        if (MODE == 0) {
+            xg[j] = pr.X + (long)(m0 + p) * a.ldx + (long)ks * KC + sc4;
+            xok[j] = true;
+        } else {  // 3x3 convolution over 8x8 tokens: this K slice is tap ks, all 256 channels
+            const int ny = (p >> 3) + ks / 3 - 1, nx = (p & 7) + ks % 3 - 1;
+            xok[j] = (unsigned)ny < 8u && (unsigned)nx < 8u;
+            xg[j] = pr.X + (long)(m0 + (xok[j] ? ny * 8 + nx : p)) * 256 + sc4;
+        }
+    }
+    const bool wload = srow < 16 * NT;
+    const int wrow = wload ? srow : 0;
+    const float* wg = pr.W + (long)(n0 + (wrow >> 4) * nstep + (wrow & 15)) * a.ldw + (long)ks * KC + sc4;
+
+    f32x4 gx[NS][2], gw[NS];
+    auto request = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            gx[st][j] = xok[j] ? *reinterpret_cast<const f32x4*>(xg[j] + kStageK * st) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wload) gw[st] = *reinterpret_cast<const f32x4*>(wg + kStageK * st);
+    };
+    auto park = [&](int st, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&sx[buf][(srow + 32 * j) * kStageLd + sc4]) = gx[st][j];
+        if (wload) *reinterpret_cast<f32x4*>(&sw[buf][srow * kStageLd + sc4]) = gw[st];
+    };
+#pragma unroll
+    for (int st = 0; st < DEPTH; ++st) request(st);
+    float gbias_v = 0.0f, gbias_g = 0.0f;  // GEGLU epilogue: this lane's column
+    if (GEGLU_OUT) {
+        gbias_v = pr.bias[n0 + r16];
+        gbias_g = pr.bias[a.geglu_h + n0 + r16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int KSTEPS = NT == 2 ? 4 : 2;        // k-steps of 16 per stage and wave
+    const int k40 = NT == 2 ? 0 : 2 * half;        // first of them
+    const int wtile = NT == 2 ? half : 0;          // n-tile of this wave
+    park(0, 0);
+    __syncthreads();
+    AHV_ENC_STAMP(3);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const int cur = st & 1;
+        if (st + DEPTH < NS) {
+            request(st + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 fx[KSTEPS], fw[KSTEPS];
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k) {
+            fx[k] = *reinterpret_cast<const f32x4*>(&sx[cur][(16 * rt + r16) * kStageLd + 16 * (k40 + k) + 4 * kq]);
+            fw[k] = *reinterpret_cast<const f32x4*>(&sw[cur][(16 * wtile + r16) * kStageLd + 16 * (k40 + k) + 4 * kq]);
+        }
+        if (st + 1 < NS) park(st + 1, cur ^ 1);  // the next stage lands in the other buffer while these MFMAs run
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[k][s4], fw[k][s4], acc, 0, 0, 0);
+        if (st + 1 < NS) __syncthreads();
+    }
+    AHV_ENC_STAMP(4);
+    // D layout: acc[r] = C[m0 + 16 rt + 4 kq + r][column r16 of this wave's n-tile]; waves 4..7 hand over
+    if (half == 1) *reinterpret_cast<f32x4*>(&comb[(rt * 64 + lane) * 4]) = acc;
+    __syncthreads();
+    if (half == 0) {
+        const f32x4 other = *reinterpret_cast<const f32x4*>(&comb[(rt * 64 + lane) * 4]);
+        if (GEGLU_OUT) {
+            float* out = pr.P + (long)(m0 + 16 * rt + 4 * kq) * a.geglu_h + n0 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)r * a.geglu_h] = (acc[r] + gbias_v) * gelu_erf(other[r] + gbias_g);
+        } else if (NT == 1) {
+            float* out = pr.P + ((long)ks * a.M + m0 + 16 * rt + 4 * kq) * pr.N + n0 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)r * pr.N] = acc[r] + other[r];
+        } else {  // two plain n-tiles
+            float* out = pr.P + ((long)ks * a.M + m0 + 16 * rt + 4 * kq) * pr.N + n0 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[(long)r * pr.N] = acc[r];
+                out[(long)r * pr.N + 16] = other[r];
+            }
+        }
+    }
+    AHV_ENC_STAMP(6);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Tiled linear for MANY rows (M >= 1024, i.e. B >= 16): C[M][N] = X[M][K] . W[N][K]^T, fp32 MFMA 16x16x4.
 // The skinny kernel above splits K over the waves of a workgroup and pays an 8-way LDS reduction per 64 x 32
 // output tile: right for 64..512 rows (weights are the traffic), 44 % of the matrix peak at 2048 rows.  Here a
@@ -699,6 +840,16 @@ static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long 
         if (i < nprob) tiles += sp.N / cols;
     }
     const dim3 grid(tiles, KS, M / 64);
+#ifndef AHV_ENC_NO_STAGED
+    if (mode != 2 && (a.Kc == 256 || (a.Kc == 512 && mode == 0)) && (!wide || (KS == 1 && a.Kc == 512))) {  // K-pipelined form (same grid)
+        if (mode == 1 && a.Kc == 256) AHV_ENC_LAUNCH((linear_staged_kernel<1, 256, false, 1>), grid, dim3(512), 0, s, a);
+        else if (mode == 0 && wide && a.Kc == 512) AHV_ENC_LAUNCH((linear_staged_kernel<2, 512, true>), grid, dim3(512), 0, s, a);
+        else if (mode == 0 && !wide && a.Kc == 512) AHV_ENC_LAUNCH((linear_staged_kernel<1, 512, false>), grid, dim3(512), 0, s, a);
+        else if (mode == 0 && !wide && a.Kc == 256) AHV_ENC_LAUNCH((linear_staged_kernel<1, 256, false>), grid, dim3(512), 0, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+#endif
     if (mode == 1 && Kw == 32) AHV_ENC_LAUNCH((linear_kernel<1, 32, false, 1>), grid, dim3(512), 0, s, a);
     else if (mode == 2 && Kw == 32) AHV_ENC_LAUNCH((linear_kernel<1, 32, false, 2>), grid, dim3(512), 0, s, a);
     else if (mode == 2 && Kw == 16) AHV_ENC_LAUNCH((linear_kernel<1, 16, false, 2>), grid, dim3(512), 0, s, a);

@@ -201,6 +201,44 @@ int main()
         snprintf(nm, sizeof nm, "re-read 128 KB per workgroup, as MFMA fragments, %d x 512", wg);
         if (chain(nm, 16, [&](int i) { const float* in; float* out; pp(i, &in, &out); hipLaunchKernelGGL(k_reread<1>, dim3(wg), dim3(512), 0, s, in, out, n, w); }, s)) return 1;
     }
+    {   // two independent dependent chains forked onto two streams inside ONE captured graph: do the branches overlap?
+        hipStream_t s1; CK(hipStreamCreate(&s1));
+        hipEvent_t fork, join; CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        float *c, *d; CK(hipMalloc(&c, n * 4)); CK(hipMalloc(&d, n * 4)); CK(hipMemset(c, 0, n * 4)); CK(hipMemset(d, 0, n * 4));
+        for (int kind = 0; kind < 3; ++kind) {
+            for (int lanes = 1; lanes <= 2; ++lanes) {
+                char nm[128];
+                snprintf(nm, sizeof nm, "%s, %d chain(s) of 64 in one graph (us per launch of ONE chain)",
+                         kind == 0 ? "load-store 128 x 512" : kind == 1 ? "stream 2 MB, 128 x 512" : "far chase x8 128 x 512", lanes);
+                auto body = [&](hipStream_t st, float* x, float* y, int i, int lane) {
+                    const float* in = (i & 1) ? y : x; float* out = (i & 1) ? x : y;
+                    if (kind == 0) hipLaunchKernelGGL(k_touch, dim3(128), dim3(512), 0, st, in, out, n);
+                    else if (kind == 1) hipLaunchKernelGGL(k_stream<2>, dim3(128), dim3(512), 0, st, in, out, n, w + (size_t)((i * 2 + lane) & 31) * 131072);
+                    else hipLaunchKernelGGL(k_chase_far<8>, dim3(128), dim3(512), 0, st, in, out, n);
+                };
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+                if (lanes == 2) { CK(hipEventRecord(fork, s)); CK(hipStreamWaitEvent(s1, fork, 0)); }
+                for (int i = 0; i < 64; ++i) {
+                    body(s, a, b, i, 0);
+                    if (lanes == 2) body(s1, c, d, i, 1);
+                }
+                if (lanes == 2) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s, join, 0)); }
+                CK(hipStreamEndCapture(s, &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, s));
+                CK(hipStreamSynchronize(s));
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge, s));
+                CK(hipEventRecord(e1, s));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("{\"chain\": \"%s\", \"launches\": %d, \"us_per_launch\": %.3f}\n", nm, 64 * lanes, ms * 1e3 / 50 / 64);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            }
+        }
+    }
     // fragment-order fetch of the same 8 MB: each workgroup owns 16 rows of a [4096][ld] matrix, ld = 8 waves x 4 steps x 16 floats
     if (chain("stream 8 MB as MFMA fragments of a row-major matrix", 8, [&](int i) { const float* in; float* out; pp(i, &in, &out); hipLaunchKernelGGL(k_stream_frag<4>, dim3(256), dim3(512), 0, s, in, out, n, w + (size_t)i * 131072 * 4, 8 * 4 * 4); }, s)) return 1;
     if (chain("stream 16 MB as MFMA fragments of a row-major matrix", 4, [&](int i) { const float* in; float* out; pp(i, &in, &out); hipLaunchKernelGGL(k_stream_frag<8>, dim3(256), dim3(512), 0, s, in, out, n, w + (size_t)i * 131072 * 8, 8 * 8 * 4); }, s)) return 1;
