@@ -690,21 +690,28 @@ struct LnArgs {
 
 // LayerNorm(256, eps 1e-5, biased variance) of (sum_ks P + bias);
 // CONCAT: out[row] = [x[row], y]   (attention.py:255-256)   else: out[row] = x[row] + y   (:257-258)
-template <bool CONCAT>
+// KS is a template parameter so that the slab loads are independent instructions issued together: with a run-time
+// trip count hipcc keeps the loop rolled and every slab costs its own memory round trip.
+template <bool CONCAT, int KS>
 __global__ __launch_bounds__(256) void ln_kernel(const LnArgs a)
 {
     const LnProb pr = a.p[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
-    f32x4 t = *reinterpret_cast<const f32x4*>(pr.bias + 4 * lane);
-    for (int ks = 0; ks < a.KS; ++ks) t += *reinterpret_cast<const f32x4*>(pr.P + ((long)ks * a.M + row) * 256 + 4 * lane);
+    f32x4 slab[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) slab[ks] = *reinterpret_cast<const f32x4*>(pr.P + ((long)ks * a.M + row) * 256 + 4 * lane);
     const f32x4 xin = *reinterpret_cast<const f32x4*>(pr.x + (long)row * 256 + 4 * lane);
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(pr.g + 4 * lane), bet = *reinterpret_cast<const f32x4*>(pr.be + 4 * lane);
+    f32x4 t = *reinterpret_cast<const f32x4*>(pr.bias + 4 * lane);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) t += slab[ks];
     const float mean = wave_sum(t[0] + t[1] + t[2] + t[3]) * (1.0f / 256.0f);
     const f32x4 d = t - mean;
     const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const f32x4 y = d * rstd * *reinterpret_cast<const f32x4*>(pr.g + 4 * lane) + *reinterpret_cast<const f32x4*>(pr.be + 4 * lane);
+    const f32x4 y = d * rstd * gam + bet;
     if (CONCAT) {
         *reinterpret_cast<f32x4*>(pr.out + (long)row * 512 + 4 * lane) = xin;
         *reinterpret_cast<f32x4*>(pr.out + (long)row * 512 + 256 + 4 * lane) = y;
@@ -786,6 +793,7 @@ struct FinArgs {
     int relu_cols, ldres, ldo, layout;
 };
 
+template <int KS>  // compile-time: every slab (and the optional operands) is requested before the first add
 __global__ __launch_bounds__(256) void finish_kernel(const FinArgs a)
 {
     const FinProb pr = a.p[blockIdx.y];
@@ -793,13 +801,20 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinArgs a)
     const int n4 = a.N >> 2;
     if (i >= (long)a.M * n4) return;
     const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
-    f32x4 v = pr.bias ? *reinterpret_cast<const f32x4*>(pr.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < a.KS; ++ks) v += *reinterpret_cast<const f32x4*>(pr.P + ((long)ks * a.M + m) * a.ldp + a.col0 + n);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 slab[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) slab[ks] = *reinterpret_cast<const f32x4*>(pr.P + ((long)ks * a.M + m) * a.ldp + a.col0 + n);
+    const f32x4 res = pr.res ? *reinterpret_cast<const f32x4*>(pr.res + (long)m * a.ldres + n) : zero;
+    const f32x4 pe = a.pe ? *reinterpret_cast<const f32x4*>(a.pe + (long)(m & 63) * a.N + n) : zero;
+    f32x4 v = pr.bias ? *reinterpret_cast<const f32x4*>(pr.bias + n) : zero;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) v += slab[ks];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (n + e < a.relu_cols) v[e] = fmaxf(v[e], 0.0f);
-    if (pr.res) v += *reinterpret_cast<const f32x4*>(pr.res + (long)m * a.ldres + n);
-    if (a.pe) v += *reinterpret_cast<const f32x4*>(a.pe + (long)(m & 63) * a.N + n);
+    v += res;
+    v += pe;
     if (a.layout == 0) {
         *reinterpret_cast<f32x4*>(pr.out + (long)m * a.ldo + n) = v;
     } else if (a.layout == 1) {
@@ -944,7 +959,7 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         LnArgs ln;
         ln.KS = 1; ln.M = M;
         for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].part, w[i]->b_out, w[i]->ln1_g, w[i]->ln1_b, x[i], ws[i].cat};
-        AHV_ENC_LAUNCH(ln_kernel<true>, dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_ENC_LAUNCH((ln_kernel<true, 1>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
         AHV_TRY(hipGetLastError(), "norm1 + concat");
     } else {
         AHV_ENC_LAUNCH(attention_kernel, dim3(2 * B, 4), dim3(256), 0, s, at);
@@ -955,7 +970,7 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         LnArgs ln;
         ln.KS = 2; ln.M = M;
         for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].part, w[i]->b_out, w[i]->ln1_g, w[i]->ln1_b, x[i], ws[i].cat};
-        AHV_ENC_LAUNCH(ln_kernel<true>, dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_ENC_LAUNCH((ln_kernel<true, 2>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
         AHV_TRY(hipGetLastError(), "norm1 + concat");
     }
     {
@@ -973,7 +988,7 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         LnArgs ln;
         ln.KS = 4; ln.M = M;
         for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
-        AHV_ENC_LAUNCH(ln_kernel<false>, dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_ENC_LAUNCH((ln_kernel<false, 4>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
         AHV_TRY(hipGetLastError(), "norm2 + residual");
     }
 #undef AHV_TRY
@@ -1044,7 +1059,12 @@ static hipError_t launch_finish(const float* const P[2], const float* const bias
     a.pe = pe; a.KS = KS; a.M = M; a.N = N; a.ldp = ldp; a.col0 = col0;
     a.relu_cols = relu_cols; a.ldres = ldres; a.ldo = ldo; a.layout = layout;
     const long n = (long)M * (N / 4);
-    AHV_ENC_LAUNCH(finish_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((n + 255) / 256), 2);
+    if (KS == 1) AHV_ENC_LAUNCH(finish_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (KS == 3) AHV_ENC_LAUNCH(finish_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (KS == 4) AHV_ENC_LAUNCH(finish_kernel<4>, grid, dim3(256), 0, s, a);
+    else if (KS == 9) AHV_ENC_LAUNCH(finish_kernel<9>, grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
