@@ -4,14 +4,14 @@
 // stream, so every GEMM is "skinny" (M = 64*B rows): its cost is streaming the weights once and the
 // launch count.  The two streams of a layer (self_1 | self_2, then cross_1 | cross_2) are independent, so
 // every launch carries BOTH blocks (and, for cross-attention, both the q and the k|v projections) as
-// separate "problems": 7 launches per half layer, 56 for the whole depth-4 encoder.
+// separate "problems": 6 launches per half layer, 48 for the whole depth-4 encoder.
 //
-//   linear_kernel       P[ks][M][N] = X[M][K-slice ks] . W[N][K-slice]^T   fp32 MFMA 16x16x4, split-K,
-//                       up to 4 problems per launch; optional fused bias + GEGLU epilogue
-//   attention_kernel    softmax(Q K^T / 8) V, one wave per (sample, head, 16 queries); scores are kept
-//                       transposed so that softmax runs down registers and P feeds the 2nd MFMA in place
-//   ln1_concat_kernel   cat[row] = [x[row], LayerNorm(sum_ks P + bias)]          (attention.py:255-256)
-//   ln2_residual_kernel out[row] = x[row] + LayerNorm(sum_ks P + bias)           (attention.py:257-258)
+//   linear_staged_kernel  P[ks][M][N] = X[M][K-slice ks] . W[N][K-slice]^T   fp32 MFMA 16x16x4, split-K, up to 4
+//                         problems per launch, K walked in stages through LDS; optional bias + GEGLU epilogue
+//   linear_kernel         the register-resident form of the same (3-D convolution taps, odd K slices)
+//   linear_tile_kernel    128 x 128 tiles for M >= 1024
+//   attention_heads_kernel  softmax(Q K^T / 8) V and the output projection, four waves per (sample, head, 16 queries)
+//   ln_kernel             LayerNorm(sum_ks P + bias) fused with cat([x, .]) or x + .   (attention.py:255-258)
 //
 // fp32 throughout (the reference runs set_float32_matmul_precision("highest")).
 #include <hip/hip_runtime.h>
@@ -452,12 +452,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Attention, 64 keys x 64 head dims; grid = (B * nprob, heads), wave = 16 queries.
-// S^T[j][i] = sum_d K[j][d] Q[i][d]  (keys on rows/registers, queries on lanes);  softmax over j runs
-// down the registers (+ lane groups l^16, l^32);  O^T[d][i] = sum_j V[j][d] P^T[j][i], whose B operand
-// is the S^T accumulator itself.
-// -------------------------------------------------------------------------------------------------
+// ---- attention: operand descriptors -----------------------------------------------------------------
 struct AttnProb {
     const float *Q, *K, *V;
     float* O;
@@ -469,95 +464,9 @@ struct AttnArgs {
     float scale;
 };
 
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a)
-{
-    const int lane = threadIdx.x & 63;
-    const int it = threadIdx.x >> 6;  // query tile of this wave
-    const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
-    const AttnProb pr = a.p[pi];
-    const int h = blockIdx.y;
-    const int c16 = lane & 15, kq = lane >> 4;
-    const float* q = pr.Q + (long)b * 64 * pr.ldq + h * 64 + (long)(it * 16 + c16) * pr.ldq + 4 * kq;
-    const float* k = pr.K + (long)b * 64 * pr.ldkv + h * 64 + (long)c16 * pr.ldkv + 4 * kq;
-    const float* v = pr.V + (long)b * 64 * pr.ldkv + h * 64 + c16;
-    // every operand is requested before the first MFMA
-    f32x4 ka[4][4], qb[4];
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-        qb[ds] = *reinterpret_cast<const f32x4*>(q + 16 * ds);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) ka[ds][jt] = *reinterpret_cast<const f32x4*>(k + (long)(jt * 16) * pr.ldkv + 16 * ds);
-    }
-    float va[4][4][4];  // [jt][r][dt]: V[jt*16 + 4kq + r][dt*16 + c16]
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) va[jt][r][dt] = v[(long)(jt * 16 + 4 * kq + r) * pr.ldkv + dt * 16];
-    f32x4 st[4];  // [jt]
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-                st[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][jt][s], qb[ds][s], st[jt], 0, 0, 0);
-    // softmax over the 64 keys of query column i = it*16 + c16
-    float m = -INFINITY;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[jt][r] *= a.scale;
-            m = fmaxf(m, st[jt][r]);
-        }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.0f;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = expf(st[jt][r] - m);
-            st[jt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    f32x4 ot[4];  // [dt]
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = st[jt][r] * inv;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[jt][r][dt], p, ot[dt], 0, 0, 0);
-        }
-    float* o = pr.O + (long)b * 64 * 256 + h * 64 + (long)(it * 16 + c16) * 256 + 4 * kq;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + dt * 16) = ot[dt];
-}
-
 // -------------------------------------------------------------------------------------------------
-// Attention + output projection in one launch, for small batches (CrossAttention.forward,
-// transformer/attention.py:214-237, up to but not including to_out's bias).  grid = (B * nprob, 4 query tiles,
-// 4 column quarters); 256 threads = one wave per HEAD.  Each wave computes its head's O^T tile exactly as
-// attention_kernel does (the three column-quarter siblings repeat it: 96 MFMAs and 36 KB of L2 reads, cheaper than
-// a launch boundary while B is small), and then contracts it with its 64-column slice of W_out:
-// D^T[n][q] = sum_d W_out[n][64 h + d] O_h[q][d].  Accumulator register r of tile dt holds
-// O[q = lane & 15][d = 16 dt + 4 kq + r], which IS the B operand of the k-step whose four k values are
-// {16 dt + 4 kq + r}, and the matching A operand is component r of ONE aligned float4 of W_out per lane and dt: no
-// lane movement, no LDS round trip.  The four heads' partial tiles meet in LDS.  Output: P[M][256] without bias
-// (ln_kernel adds it), i.e. one split-K slab.  Measured at B = 1: one launch less per block pair, 409 -> 391 us
-// per forward_2d3d replayed from a hipGraph; at B = 32 the repeated attention costs more than the launch (+4 %),
-// so run_block_pair keeps the two-kernel form there.
+// Attention + output projection in one launch (CrossAttention.forward, transformer/attention.py:214-237, up to but
+// not including to_out's bias).
 // -------------------------------------------------------------------------------------------------
 struct AttnOutProb {
     const float *Q, *K, *V;
@@ -571,85 +480,101 @@ struct AttnOutArgs {
     float scale;
 };
 
-__global__ __launch_bounds__(256) void attention_out_kernel(const AttnOutArgs a)
+// -------------------------------------------------------------------------------------------------
+// The four waves of a workgroup cooperate on ONE head of one 16-query tile: grid = (B * nprob, 4 query tiles,
+// 4 heads).  (Round 2's first form gave every wave a whole head and repeated the attention per column quarter: 192
+// dependent MFMAs per wave, 9.2 us at B = 1; this one 6.5 us.)  Wave w scores key tile w
+// (16 MFMAs), the four partial softmaxes are merged through 128 bytes of LDS with the online-softmax identity
+// (p_w = exp(s - m_w); m = max m_w; L = sum l_w exp(m_w - m); P = p_w exp(m_w - m) / L: ONE barrier), wave w forms its
+// keys' share of O^T (16 MFMAs), the shares meet in LDS, and wave w then contracts the head's O with column quarter
+// w of W_out (64 MFMAs).  96 dependent MFMAs per wave instead of 192, a quarter of the K / V loads.  The result is
+// one split-K slab PER HEAD, P[h][M][256]; ln_kernel sums the four.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs a, int M)
 {
-    __shared__ float red[4 * 64 * 17];
+    __shared__ float sm[4][16][2];                                   // per wave and query: (max, sum)
+    __shared__ __attribute__((aligned(16))) float so[4][4][64][4];   // per wave: O^T share [dt][lane][r]
     const int lane = threadIdx.x & 63;
-    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // head of this wave
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
     const AttnOutProb pr = a.p[pi];
-    const int it = blockIdx.y, nq = blockIdx.z;
+    const int it = blockIdx.y, h = blockIdx.z;
     const int c16 = lane & 15, kq = lane >> 4;
-    const float* q = pr.Q + (long)b * 64 * pr.ldq + h * 64 + (long)(it * 16 + c16) * pr.ldq + 4 * kq;
-    const float* k = pr.K + (long)b * 64 * pr.ldkv + h * 64 + (long)c16 * pr.ldkv + 4 * kq;
-    const float* v = pr.V + (long)b * 64 * pr.ldkv + h * 64 + c16;
+    const float* q = pr.Q + (long)(b * 64 + it * 16 + c16) * pr.ldq + h * 64 + 4 * kq;
+    const float* k = pr.K + (long)(b * 64 + w * 16 + c16) * pr.ldkv + h * 64 + 4 * kq;
+    const float* v = pr.V + (long)(b * 64 + w * 16 + 4 * kq) * pr.ldkv + h * 64 + c16;
     // every operand is requested before the first MFMA
-    f32x4 ka[4][4], qb[4], wf[4][4];
+    f32x4 ka[4], qb[4], wf[4][4];
+    float va[4][4];  // [r][dt]: V[16 w + 4 kq + r][16 dt + c16]
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
         qb[ds] = *reinterpret_cast<const f32x4*>(q + 16 * ds);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) ka[ds][jt] = *reinterpret_cast<const f32x4*>(k + (long)(jt * 16) * pr.ldkv + 16 * ds);
+        ka[ds] = *reinterpret_cast<const f32x4*>(k + 16 * ds);
     }
-    float va[4][4][4];  // [jt][r][dt]: V[jt*16 + 4kq + r][dt*16 + c16]
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) va[jt][r][dt] = v[(long)(jt * 16 + 4 * kq + r) * pr.ldkv + dt * 16];
+        for (int dt = 0; dt < 4; ++dt) va[r][dt] = v[(long)r * pr.ldkv + dt * 16];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-            wf[nt][dt] = *reinterpret_cast<const f32x4*>(pr.Wo + (long)(nq * 64 + nt * 16 + c16) * 256 + h * 64 + 16 * dt + 4 * kq);
+            wf[nt][dt] = *reinterpret_cast<const f32x4*>(pr.Wo + (long)(w * 64 + nt * 16 + c16) * 256 + h * 64 + 16 * dt + 4 * kq);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 st[4];  // [jt]
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // S^T[j = 16 w + 4 kq + r][i = c16]
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-                st[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][jt][s], qb[ds][s], st[jt], 0, 0, 0);
-    // softmax over the 64 keys of query column i = it*16 + c16
+        for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][s], qb[ds][s], st, 0, 0, 0);
     float m = -INFINITY;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[jt][r] *= a.scale;
-            m = fmaxf(m, st[jt][r]);
-        }
+    for (int r = 0; r < 4; ++r) {
+        st[r] *= a.scale;
+        m = fmaxf(m, st[r]);
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.0f;
+    float l = 0.0f;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int r = 0; r < 4; ++r) {
+        st[r] = expf(st[r] - m);
+        l += st[r];
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (kq == 0) {
+        sm[w][c16][0] = m;
+        sm[w][c16][1] = l;
+    }
+    __syncthreads();
+    float mg = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = expf(st[jt][r] - m);
-            st[jt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    f32x4 ot[4];  // [dt]
+    for (int u = 0; u < 4; ++u) mg = fmaxf(mg, sm[u][c16][0]);
+    float L = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) L += sm[u][c16][1] * expf(sm[u][c16][0] - mg);
+    const float f = expf(m - mg) / L;
+    // this wave's share of O^T[d = 16 dt + 4 kq + r][i = c16]
+    f32x4 ot[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int r = 0; r < 4; ++r) {
+        const float p = st[r] * f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = st[jt][r] * inv;
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r][dt], p, ot[dt], 0, 0, 0);
+    }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[jt][r][dt], p, ot[dt], 0, 0, 0);
-        }
-    // this head's share of the output projection: D^T[n][q] += W_out[n][64 h + d] O[q][d]
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&so[w][dt][lane][0]) = ot[dt];
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        ot[dt] = *reinterpret_cast<const f32x4*>(&so[0][dt][lane][0]);
+#pragma unroll
+        for (int u = 1; u < 4; ++u) ot[dt] += *reinterpret_cast<const f32x4*>(&so[u][dt][lane][0]);
+    }
+    // column quarter w of the head's output projection: D^T[n = 64 w + 16 nt + 4 kq + r][q = c16]
     f32x4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -660,16 +585,9 @@ __global__ __launch_bounds__(256) void attention_out_kernel(const AttnOutArgs a)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][dt][r], ot[dt][r], acc[nt], 0, 0, 0);
+    float* out = pr.P + ((long)h * M + b * 64 + it * 16 + c16) * 256 + w * 64 + 4 * kq;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(h * 64 + nt * 16 + 4 * kq + r) * 17 + c16] = acc[nt][r];
-    __syncthreads();
-    float* out = pr.P + ((long)b * 64 + it * 16) * 256 + nq * 64;
-    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-        const int qq = i >> 6, n = i & 63;
-        out[(long)qq * 256 + n] = red[n * 17 + qq] + red[(64 + n) * 17 + qq] + red[(128 + n) * 17 + qq] + red[(192 + n) * 17 + qq];
-    }
+    for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(out + nt * 16) = acc[nt];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -948,29 +866,18 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         AHV_TRY(launch_linear(sp, 4, 256, 256, M, 256, 1, 0, s), "q / kv projections");
         for (int i = 0; i < 2; ++i) at.p[i] = AttnProb{ws[i].qkv, ws[i].kv, ws[i].kv + 256, ws[i].att, 256, 512};
     }
-    if (B <= 4) {  // small batch: attention and the output projection in ONE launch (attention_out_kernel)
+    {   // attention and the output projection in ONE launch (attention_heads_kernel), then norm1 + concat
         AttnOutArgs ao;
         ao.B = B;
         ao.scale = at.scale;
         for (int i = 0; i < 2; ++i)
             ao.p[i] = AttnOutProb{at.p[i].Q, at.p[i].K, at.p[i].V, w[i]->w_out, ws[i].part, at.p[i].ldq, at.p[i].ldkv};
-        AHV_ENC_LAUNCH(attention_out_kernel, dim3(2 * B, 4, 4), dim3(256), 0, s, ao);
+        AHV_ENC_LAUNCH(attention_heads_kernel, dim3(2 * B, 4, 4), dim3(256), 0, s, ao, M);
         AHV_TRY(hipGetLastError(), "attention + out projection");
         LnArgs ln;
-        ln.KS = 1; ln.M = M;
+        ln.KS = 4; ln.M = M;  // one slab per head
         for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].part, w[i]->b_out, w[i]->ln1_g, w[i]->ln1_b, x[i], ws[i].cat};
-        AHV_ENC_LAUNCH((ln_kernel<true, 1>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
-        AHV_TRY(hipGetLastError(), "norm1 + concat");
-    } else {
-        AHV_ENC_LAUNCH(attention_kernel, dim3(2 * B, 4), dim3(256), 0, s, at);
-        AHV_TRY(hipGetLastError(), "attention");
-        LinSpec sp[2];
-        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].att, w[i]->w_out, ws[i].part, nullptr, 256};
-        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 2, 0, s), "out projection");
-        LnArgs ln;
-        ln.KS = 2; ln.M = M;
-        for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].part, w[i]->b_out, w[i]->ln1_g, w[i]->ln1_b, x[i], ws[i].cat};
-        AHV_ENC_LAUNCH((ln_kernel<true, 2>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        AHV_ENC_LAUNCH((ln_kernel<true, 4>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
         AHV_TRY(hipGetLastError(), "norm1 + concat");
     }
     {
