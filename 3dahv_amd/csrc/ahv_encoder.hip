@@ -318,8 +318,9 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
             for (int r = 0; r < 4; ++r) out[(long)r * a.geglu_h] = (acc[r] + gbias_v) * gelu_erf(other[r] + gbias_g);
         } else if (NT == 1) {
             float* out = pr.P + ((long)ks * a.M + m0 + 16 * rt + 4 * kq) * pr.N + n0 + r16;
+            const float bias = pr.bias ? pr.bias[n0 + r16] : 0.0f;  // a 1x1 conv's bias (single K slice only: host)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long)r * pr.N] = acc[r] + other[r];
+            for (int r = 0; r < 4; ++r) out[(long)r * pr.N] = acc[r] + other[r] + bias;
         } else {  // two plain n-tiles
             float* out = pr.P + ((long)ks * a.M + m0 + 16 * rt + 4 * kq) * pr.N + n0 + r16;
 #pragma unroll
@@ -888,14 +889,30 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         const bool tiled = tile_eligible(M, 512, 4096, 2048);
         if (tiled) AHV_TRY(launch_linear_tile(sp, 512, 512, M, 512, 1, 2048, s), "ff in + geglu (tiled)");
         else AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 2048, s), "ff in + geglu");
-        // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
-        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
-        if (tiled) AHV_TRY(launch_linear_tile(sp, 2048, 2048, M, 2048, 4, 0, s), "ff out (tiled, split-K 4)");
-        else AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
         LnArgs ln;
-        ln.KS = 4; ln.M = M;
-        for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
-        AHV_ENC_LAUNCH((ln_kernel<false, 4>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        ln.M = M;
+#ifndef AHV_FFOUT_KS8_MAX_M
+#define AHV_FFOUT_KS8_MAX_M 128
+#endif
+        if (tiled || M > AHV_FFOUT_KS8_MAX_M) {
+            // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
+            for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
+            if (tiled) AHV_TRY(launch_linear_tile(sp, 2048, 2048, M, 2048, 4, 0, s), "ff out (tiled, split-K 4)");
+            else AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
+            ln.KS = 4;
+            for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
+            AHV_ENC_LAUNCH((ln_kernel<false, 4>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        } else {
+            // B <= 2: 8 K-splits so that the 4 MB of W_ff2 stream through 256 workgroups instead of 128 (-3.6 % per
+            // forward at B = 1, even at B = 2, slower from B = 4 on); the slabs
+            // ([8][M][256]) go behind the gated activations in `part` (2048 of its 4096 floats per row are free)
+            for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].part + (size_t)M * 2048, nullptr, 256};
+            AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 8, 0, s), "ff out (split-K 8)");
+            ln.KS = 8;
+            for (int i = 0; i < 2; ++i)
+                ln.p[i] = LnProb{ws[i].part + (size_t)M * 2048, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
+            AHV_ENC_LAUNCH((ln_kernel<false, 8>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        }
         AHV_TRY(hipGetLastError(), "norm2 + residual");
     }
 #undef AHV_TRY
@@ -994,7 +1011,6 @@ int forward_2d3d(const ahv_aligner_weights* w, const float* l4_src, const float*
     PAIR(float*, E0, e[0].E0, e[1].E0);
     PAIR(float*, H1, e[0].H1, e[1].H1);
     PAIR(float*, Xin, e[0].Xin, e[1].Xin);
-    PAIR(float*, Xs, e[0].Xs, e[1].Xs);
     PAIR(float*, Vol0, e[0].Vol0, e[1].Vol0);
     PAIR(float*, H3, e[0].H3, e[1].H3);
     PAIR(float*, Skip, e[0].Skip, e[1].Skip);
@@ -1017,10 +1033,9 @@ int forward_2d3d(const ahv_aligner_weights* w, const float* l4_src, const float*
         AHV_ENC_LAUNCH(groupnorm_kernel, dim3(8, B, 2), dim3(256), 0, s, g);
         AHV_TRY(hipGetLastError(), "groupnorm");
         LinSpec sp[2];
-        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Gn, w->w_in[i], e[i].S, nullptr, 256};
-        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 1, 0, s), "proj_in");
-        PAIR(const float*, bin, w->b_in[0], w->b_in[1]);
-        AHV_TRY(launch_finish(S, bin, nullptr, Xs, nullptr, 1, M, 256, 256, 0, 0, 0, 256, 0, s), "proj_in bias");
+        // proj_in with its bias added in the linear's epilogue (one K slice): straight into the token buffer
+        for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Gn, w->w_in[i], e[i].Xs, w->b_in[i], 256};
+        AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 1, 0, s), "proj_in + bias");
         const int rc = transformer_blocks(w->blocks, w->depth, e[0].Xs, e[1].Xs, B, tws, s, what);
         if (rc) return rc;
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Xs, w->w_out[i], e[i].S, nullptr, 256};
