@@ -799,7 +799,10 @@ static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long 
 // Many-row path of two-problem plain / GEGLU linears (both streams in one launch); KS = 1 output layout.
 static bool tile_eligible(int M, int K, int N, int geglu_h)
 {
-    if (M < 1024 || (M & 127) || (K & 15)) return false;
+#ifndef AHV_TILE_MIN_M
+#define AHV_TILE_MIN_M 1024
+#endif
+    if (M < AHV_TILE_MIN_M || (M & 127) || (K & 15)) return false;
     return geglu_h > 0 ? (geglu_h % 64 == 0 && N == 2 * geglu_h) : (N % 128 == 0);
 }
 
