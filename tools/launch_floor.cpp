@@ -2,6 +2,7 @@
 // The B = 1 encoder is a chain of ~50 dependent launches whose arithmetic is a few microseconds in all; this
 // measures the floor that chain sits on.  Build: hipcc --offload-arch=gfx950 -O3 tools/launch_floor.cpp -o /tmp/launch_floor
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -238,6 +239,25 @@ int main()
                 CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
             }
         }
+    }
+    {   // host side: what issuing one launch costs the CPU (eager mode), by launch API
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        const int reps = 2000;
+        CK(hipStreamSynchronize(s));
+        auto t0 = now();
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_touch, dim3(16), dim3(256), 0, s, a, b, n);
+        auto t1 = now();
+        CK(hipStreamSynchronize(s));
+        printf("{\"host\": \"hipLaunchKernelGGL, small kernarg\", \"us_per_launch_issue\": %.3f}\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / reps);
+        hipFunction_t fn;
+        CK(hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(k_touch)));
+        const float* pa = a; float* pb = b; int nn = n;
+        void* args[3] = {&pa, &pb, &nn};
+        t0 = now();
+        for (int i = 0; i < reps; ++i) (void)hipModuleLaunchKernel(fn, 16, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+        t1 = now();
+        CK(hipStreamSynchronize(s));
+        printf("{\"host\": \"hipModuleLaunchKernel, cached function\", \"us_per_launch_issue\": %.3f}\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / reps);
     }
     // fragment-order fetch of the same 8 MB: each workgroup owns 16 rows of a [4096][ld] matrix, ld = 8 waves x 4 steps x 16 floats
     if (chain("stream 8 MB as MFMA fragments of a row-major matrix", 8, [&](int i) { const float* in; float* out; pp(i, &in, &out); hipLaunchKernelGGL(k_stream_frag<4>, dim3(256), dim3(512), 0, s, in, out, n, w + (size_t)i * 131072 * 4, 8 * 4 * 4); }, s)) return 1;
