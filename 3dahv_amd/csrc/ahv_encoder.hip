@@ -699,11 +699,14 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const GnArgs a)
 //            layout 1: channel-last volume from tokens, out[b][d][h][w][c'] with token m = (b, h*8+w), n = c'*8 + d
 //                      (the reshape(bs, 32, 8, 8, 8) of modules/modules.py:97)
 //            layout 2: NCDHW, out[b][n][voxel] with row m = (b, voxel)            (the scorer's volume layout)
+//            layout 3: columns [0, N/2) to out[m][N/2], columns [N/2, N) to out2[m][N/2]   (the 3-D res-block's first
+//                      conv carries its 1x1x1 skip as extra output columns: one pass splits them)
 struct FinProb {
     const float* P;
     const float* bias;
     const float* res;
     float* out;
+    float* out2;
 };
 struct FinArgs {
     FinProb p[2];
@@ -740,6 +743,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinArgs a)
         const int b = m >> 6, hw = m & 63, cp = n >> 3, d0 = n & 7;
 #pragma unroll
         for (int e = 0; e < 4; ++e) pr.out[(((long)b * 8 + d0 + e) * 64 + hw) * 32 + cp] = v[e];
+    } else if (a.layout == 3) {
+        const int h = a.N >> 1;
+        float* dst = n < h ? pr.out + (long)m * h + n : pr.out2 + (long)m * h + (n - h);
+        *reinterpret_cast<f32x4*>(dst) = v;
     } else {
         const int b = m >> 9, vox = m & 511;
 #pragma unroll
@@ -979,10 +986,12 @@ static EncWs carve_enc(float* ws, size_t M, int which)
 
 static hipError_t launch_finish(const float* const P[2], const float* const bias[2], const float* const res[2],
                                 float* const out[2], const float* pe, int KS, int M, int N, int ldp, int col0,
-                                int relu_cols, int ldres, int ldo, int layout, hipStream_t s)
+                                int relu_cols, int ldres, int ldo, int layout, hipStream_t s,
+                                float* const out2[2] = nullptr)
 {
     FinArgs a;
-    for (int i = 0; i < 2; ++i) a.p[i] = FinProb{P[i], bias ? bias[i] : nullptr, res ? res[i] : nullptr, out[i]};
+    for (int i = 0; i < 2; ++i)
+        a.p[i] = FinProb{P[i], bias ? bias[i] : nullptr, res ? res[i] : nullptr, out[i], out2 ? out2[i] : nullptr};
     a.pe = pe; a.KS = KS; a.M = M; a.N = N; a.ldp = ldp; a.col0 = col0;
     a.relu_cols = relu_cols; a.ldres = ldres; a.ldo = ldo; a.layout = layout;
     const long n = (long)M * (N / 4);
@@ -1052,8 +1061,8 @@ int forward_2d3d(const ahv_aligner_weights* w, const float* l4_src, const float*
         LinSpec sp[2];
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].Vol0, w->w3d_1, e[i].S, nullptr, 32};
         AHV_TRY(launch_linear(sp, 2, 32, 1024, MV, 1024, 4, 0, s, 2), "conv3d 1 + skip");
-        AHV_TRY(launch_finish(S, nullptr, nullptr, H3, nullptr, 4, MV, 16, 32, 0, 16, 0, 16, 0, s), "conv3d relu");
-        AHV_TRY(launch_finish(S, nullptr, nullptr, Skip, nullptr, 4, MV, 16, 32, 16, 0, 0, 16, 0, s), "conv3d skip");
+        // columns 0..15 = conv1 (ReLU) -> H3, columns 16..31 = the 1x1x1 skip -> Skip: one pass over the 4 slabs
+        AHV_TRY(launch_finish(S, nullptr, nullptr, H3, nullptr, 4, MV, 32, 32, 0, 16, 0, 0, 3, s, Skip), "conv3d relu | skip");
         PAIR(float*, S2, e[0].S + (size_t)MV * 32 * 4, e[1].S + (size_t)MV * 32 * 4);
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].H3, w->w3d_2, S2[i], nullptr, 16};
         AHV_TRY(launch_linear(sp, 2, 16, 512, MV, 512, 4, 0, s, 2), "conv3d 2");
