@@ -65,7 +65,7 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
 
     Per-pair results stay on the device and are fetched once per category (the reference synchronises per pair with
     ``.item()``).  ``encoder_fn(layer4_src, layer4_tgt)`` replaces ``model.forward_features`` for ``layer4`` inputs,
-    e.g. ``model.feature_aligner.graphed_forward_2d3d(2)`` to replay the encoder's 64 launches from one hipGraph.
+    e.g. ``model.feature_aligner.graphed_forward_2d3d(2)`` to replay the encoder's 63 launches from one hipGraph.
 
     ``batch_pairs`` (default: on the GPU) runs the ordered pairs of a sequence -- (0,1) and (1,0) for two frames --
     as ONE batch through the encoder and ONE fused verify launch instead of one by one as the reference does: at
