@@ -453,18 +453,6 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     }
 }
 
-// ---- attention: operand descriptors -----------------------------------------------------------------
-struct AttnProb {
-    const float *Q, *K, *V;
-    float* O;
-    long ldq, ldkv;
-};
-struct AttnArgs {
-    AttnProb p[2];
-    int B;  // samples per problem
-    float scale;
-};
-
 // -------------------------------------------------------------------------------------------------
 // Attention + output projection in one launch (CrossAttention.forward, transformer/attention.py:214-237, up to but
 // not including to_out's bias).
@@ -829,7 +817,8 @@ static hipError_t launch_linear_tile(const LinSpec* specs, long ldx, long ldw, i
 size_t transformer_workspace_floats(int B)
 {
     const size_t M = (size_t)64 * (size_t)(B > 0 ? B : 0);
-    // per stream: qkv 768 + kv 512 + attn 256 + cat 512 + split-K slabs 4096 + ping-pong tokens 256; two streams
+    // per stream: qkv 768 + kv 512 + (spare 256) + cat 512 + slabs / gated activations 4096 + ping-pong tokens 256;
+    // two streams
     return 2 * M * (768 + 512 + 256 + 512 + 4096 + 256) + 64;
 }
 
@@ -859,14 +848,15 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
     const int B = M / 64;
     hipError_t e;
 #define AHV_TRY(call, name) do { e = (call); if (e != hipSuccess) { *what = name; return (int)e; } } while (0)
-    AttnArgs at;
-    at.B = B;
-    at.scale = 0.125f;  // dim_head ** -0.5
+    AttnOutArgs ao;  // q, k, v of each stream (row strides ldq / ldkv), W_out, one output slab per head in `part`
+    ao.B = B;
+    ao.scale = 0.125f;  // dim_head ** -0.5
     if (self_attn) {
         LinSpec sp[2];
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{x[i], w[i]->w_qkv, ws[i].qkv, nullptr, 768};
         AHV_TRY(launch_linear(sp, 2, 256, 256, M, 256, 1, 0, s), "qkv projection");
-        for (int i = 0; i < 2; ++i) at.p[i] = AttnProb{ws[i].qkv, ws[i].qkv + 256, ws[i].qkv + 512, ws[i].att, 768, 768};
+        for (int i = 0; i < 2; ++i)
+            ao.p[i] = AttnOutProb{ws[i].qkv, ws[i].qkv + 256, ws[i].qkv + 512, w[i]->w_out, ws[i].part, 768, 768};
     } else {
         LinSpec sq[2], skv[2];
         for (int i = 0; i < 2; ++i) {
@@ -875,14 +865,10 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         }
         LinSpec sp[4] = {sq[0], sq[1], skv[0], skv[1]};
         AHV_TRY(launch_linear(sp, 4, 256, 256, M, 256, 1, 0, s), "q / kv projections");
-        for (int i = 0; i < 2; ++i) at.p[i] = AttnProb{ws[i].qkv, ws[i].kv, ws[i].kv + 256, ws[i].att, 256, 512};
+        for (int i = 0; i < 2; ++i)
+            ao.p[i] = AttnOutProb{ws[i].qkv, ws[i].kv, ws[i].kv + 256, w[i]->w_out, ws[i].part, 256, 512};
     }
     {   // attention and the output projection in ONE launch (attention_heads_kernel), then norm1 + concat
-        AttnOutArgs ao;
-        ao.B = B;
-        ao.scale = at.scale;
-        for (int i = 0; i < 2; ++i)
-            ao.p[i] = AttnOutProb{at.p[i].Q, at.p[i].K, at.p[i].V, w[i]->w_out, ws[i].part, at.p[i].ldq, at.p[i].ldkv};
         AHV_ENC_LAUNCH(attention_heads_kernel, dim3(2 * B, 4, 4), dim3(256), 0, s, ao, M);
         AHV_TRY(hipGetLastError(), "attention + out projection");
         LnArgs ln;
