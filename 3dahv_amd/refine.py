@@ -9,8 +9,9 @@ decoded from the packed key by ``ahv_compose_rotations_f32``; no host round trip
 (target features, 2 fused scorer launches, compose, select) replays from a graph.
 
 Multi-rank (one process per GPU): both hypothesis sets are sharded contiguously (``dist.shard_range``);
-each stage ends in the 8*B-byte packed-key all-reduce(max) of ``dist.all_reduce_best``, and the winner's
-rotation row (written by its owner rank only, zeros elsewhere) is summed.  The verify semantics per stage
+each stage ends in the 8*B-byte packed-key all-reduce(max) of ``dist.all_reduce_best`` -- two collectives per
+step; the winner's rotation row needs no exchange (every rank composes the full refinement set of the
+winner).  The verify semantics per stage
 are those of modules/model.py:183-196.  With the ``nccl`` backend (= RCCL) the collectives are enqueued on
 the capturing stream like any kernel, so the two stages AND their all-reduces replay from one hipGraph
 (SURVEY.md section 8(d) cfg 5); other backends (gloo rehearsals, CPU tests) run the step eagerly.
@@ -77,14 +78,16 @@ class CoarseToFine:
         s1, key1 = o.score_hypotheses(vol_src, f_tgt, Rc, self.W1, self.W2, self.b2, n_offset=self.c_lo,
                                       want_scores=self.want_scores)
         self._merge(key1)
-        # every rank holds the whole coarse set, so the winner (a global index) is always in range
-        R_fine = o.compose_rotations(key1, self.R_coarse, self.D[self.f_lo:self.f_hi])
+        # Every rank holds the whole coarse set AND the whole refinement set D, so after the key all-reduce each
+        # rank composes ALL N2 refinements of the winner locally (N2 * B threads) and scores its own slice of them.
+        # After the second key all-reduce every rank knows both winning indices and already holds the winning
+        # row: R_pred is a local gather -- two collectives per step, not three.
+        R_fine_all = o.compose_rotations(key1, self.R_coarse, self.D)
+        R_fine = R_fine_all if self.world == 1 else R_fine_all[:, self.f_lo:self.f_hi]
         s2, key2 = o.score_hypotheses(vol_src, f_tgt, R_fine, self.W1, self.W2, self.b2, n_offset=self.f_lo,
                                       want_scores=self.want_scores)
         self._merge(key2)
-        score, idx, R_pred = o.select_rotation(key2, R_fine, n_offset=self.f_lo)
-        if self.collectives:  # only the owner rank wrote its row, the others hold zeros
-            dist.all_reduce(R_pred, group=self.group)
+        score, idx, R_pred = o.select_rotation(key2, R_fine_all, n_offset=0)
         coarse_score, coarse_idx = o.unpack_best(key1)
         # this rank's slices of the two score sets and of the refinement set (None unless want_scores)
         self.last = {"coarse_scores": s1, "fine_scores": s2, "R_fine": R_fine if self.want_scores else None}

@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--split-f16", action="store_true",
                     help="time the opt-in split-f16 kernel (AHV_SCORE_SPLIT_F16) instead of the all-fp32 default; "
                          "by default it is only reported beside the fp32 headline")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="minimum length of the untimed, time-based pre-warm (the same step, looped until the chip's "
+                         "clock has settled: >= this many ms AND three consecutive kernel times within 1 %%; 0 disables)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -187,6 +190,11 @@ def worker(args):
     import torch
     import torch.distributed as dist
 
+    # stdout carries the ONE JSON line and nothing else: libraries that print banners from native code
+    # ("[Gloo] Rank 0 is connected ...", RCCL version lines) get stderr for the whole run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,8 +208,16 @@ def worker(args):
                          "rehearses more ranks than GPUs)" % (local_rank, ndev))
     dev = torch.device("cuda", local_rank % ndev)  # ranks share a GPU only in a gloo rehearsal
     torch.cuda.set_device(dev)
-    if world > 1:
+    # AHV_BENCH_FORCE_PG=1: a single rank still creates the process group and runs every collective of the
+    # world > 1 path (key all-reduce ring, barriers, all-gather check) -- the RCCL branch rehearsed on one GPU.
+    use_pg = world > 1 or os.environ.get("AHV_BENCH_FORCE_PG", "0") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -229,26 +245,61 @@ def worker(args):
         # unpack + gather in one launch; with sharding the owner rank holds the winning row, the others get zeros
         out["best"], out["idx"], out["R_pred"] = ops.select_rotation(key, R, n_offset=n_offset)
 
-    def step(i, ev=None):
+    ncu = lib.ahv_device_cu_count()
+
+    def step(i, ev=None, stamps=None):
         feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
         key = keys[i % ring]
         if ev is not None:
             ev[0].record()
+        # `stamps` given: the SAME kernel through the clocked entry point (one extra pointer argument; each
+        # workgroup also writes its s_memtime / s_memrealtime pair) -- the shader clock of the timed launches
         ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset, want_scores=False, best_key=key,
-                             reset_best=True, split_f16=split)
+                             reset_best=True, split_f16=split, clock_stamps=stamps)
         if ev is not None:
             ev[1].record()
-        if world > 1:
+        if use_pg:
             key.bitwise_xor_(adist._SIGN)  # unsigned order -> signed order for ReduceOp.MAX
             pending[i] = dist.all_reduce(key, op=dist.ReduceOp.MAX, async_op=True)
         if i > 0:
             finalize(i - 1)  # finish the previous step while this step's kernel runs
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
+    def new_events(n):
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+    def prewarm(min_ms, max_ms=1500.0, batch=8):
+        """Untimed, TIME-based pre-warm of the same step: the chip needs ~30 ms of this kernel to ramp its clock
+        (the first launches after an idle period run ~18 % slower), so a step-count warm-up of a
+        0.7-ms kernel sits inside the ramp.  Loops until >= min_ms have elapsed AND the last three kernel times
+        agree within 1 % (or max_ms).  Returns what it did, for the JSON line."""
+        t0, done, last = time.perf_counter(), 0, []
+        settled = False
+        while min_ms > 0:
+            evs = new_events(batch)
+            for j in range(batch):
+                step(j, evs[j])
+            finalize(batch - 1)
+            torch.cuda.synchronize()
+            done += batch
+            last = (last + [a.elapsed_time(b) for a, b in evs])[-3:]
+            elapsed = (time.perf_counter() - t0) * 1e3
+            settled = len(last) == 3 and (max(last) - min(last)) <= 0.01 * min(last)
+            stop = (elapsed >= min_ms and settled) or elapsed >= max_ms
+            if use_pg:  # every rank must run the same number of steps (each carries a collective): stop together
+                flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                stop = bool(flag.item())
+            if stop:
+                break
+        return {"prewarm_ms": (time.perf_counter() - t0) * 1e3, "prewarm_steps": done, "prewarm_settled": settled,
+                "prewarm_last_kernel_ms": [round(x, 4) for x in last]}
+
     with torch.no_grad():
+        pre = prewarm(args.prewarm_ms)
         for i in range(args.warmup):
             step(i)
         if args.warmup:
@@ -256,10 +307,11 @@ def worker(args):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        events = new_events(args.steps)
+        stamps = torch.zeros(args.steps, 4 * ncu, dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i, events[i])
+            step(i, events[i], stamps[i])
         finalize(args.steps - 1)
         torch.cuda.synchronize()
         barrier()
@@ -267,37 +319,30 @@ def worker(args):
         dt = time.perf_counter() - t0
 
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_pg:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # fused kernel, HIP events on its stream
+        # fused kernel, HIP events on its stream, every timed launch
+        kern_list = [a.elapsed_time(b) for a, b in events]
+        kern_ms = float(np.mean(kern_list))
+        # shader clock held DURING the timed launches: per workgroup (s_memtime delta) / (s_memrealtime delta at
+        # 100 MHz); median over workgroups and launches (MI355X_MICROARCH.md "DVFS give-back" item 6)
+        st = stamps.cpu().numpy().reshape(-1, 4)
+        st = st[st[:, 3] > st[:, 1]]
+        clock_ghz = float(np.median((st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]))) * 0.1 if len(st) else None
 
         # correctness of what was timed: the key equals torch.max over the materialised scores (all ranks)
         feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
         scores, key = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset, split_f16=split)
         lv, li = torch.max(scores, dim=1)
         cand = torch.stack([lv.double(), (li + n_offset).double()], dim=1)
-        if world > 1:
+        if use_pg:
             allc = [torch.zeros_like(cand) for _ in range(world)]
             dist.all_gather(allc, cand)
             cand = torch.cat(allc)
         gbest = cand[torch.argmax(cand[:, 0])]
         assert int(out["idx"].item()) == int(gbest[1].item()), (out["idx"], gbest)
         assert float(out["best"].item()) == float(gbest[0].item())
-
-        # Shader clock the chip held under THIS kernel (diagnostic entry point, same launch + per-workgroup
-        # s_memtime / s_memrealtime stamps; MI355X_MICROARCH.md "DVFS give-back" item 6): after the timed region.
-        clock_ghz = None
-        if rank == 0:
-            stamps = torch.zeros(4 * lib.ahv_device_cu_count(), dtype=torch.int64, device=dev)
-            for _ in range(20):
-                ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=keys[0],
-                                     reset_best=True, split_f16=split, clock_stamps=stamps)
-            torch.cuda.synchronize()
-            st = stamps.cpu().numpy().reshape(-1, 4)
-            st = st[st[:, 3] > st[:, 1]]
-            if len(st):
-                clock_ghz = float(np.median((st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]))) * 0.1
 
     if rank == 0:
         total_hyp = N_HYP * world * args.steps
@@ -317,19 +362,28 @@ def worker(args):
             "metric": "rotation hypotheses scored/sec (B=1)", "value": value, "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic", **pre,
             "config": {"workload": "CO3D pair (BASELINE.json configs[1]): B=1, N_hyp=50000 Haar rotations per GPU, "
                                    "source volume 16x8x8x8 (P=512 voxel sites x 16 ch), head 384->32->32, 64 positions",
                        "n_hyp_per_gpu": N_HYP, "n_hyp_total": N_HYP * world,
                        "parallelism": "hypothesis axis sharded x%d, 8-byte key all-reduce(max)" % world,
-                       "backend": "single process" if world == 1 else ("rccl" if args.backend == "nccl" else args.backend),
+                       "backend": "single process" if not use_pg else ("rccl" if args.backend == "nccl" else args.backend),
                        "step": "forward_3d2d(tgt) + fused score/argmax + select (unpack + gather R_pred)"},
+            # what the timed region computed (asserted above against torch.max over the materialised scores of
+            # all ranks): lets a forced-process-group run be compared with a single-process run
+            "result": {"best_idx": int(out["idx"].item()), "best_score": float(out["best"].item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "score_hypotheses_dual_kernel<false>", "kernel_ms": kern_ms,
+                         "kernel_ms_min": float(np.min(kern_list)), "kernel_ms_median": float(np.median(kern_list)),
+                         "kernel_ms_mean": kern_ms, "kernel_ms_per_step": [round(x, 4) for x in kern_list],
+                         "frac_at_median": FLOPS_PER_HYP * N_HYP / (float(np.median(kern_list)) * 1e-3) / 1e12
+                                           / PEAK_F32_MFMA_TFLOPS,
                          "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
                          "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP,
                          "shader_clock_ghz": clock_ghz,
+                         "shader_clock_source": "s_memtime / s_memrealtime stamps of the TIMED launches (all %d, all "
+                                                "workgroups, median)" % args.steps,
                          "frac_at_delivered_clock": (achieved / (PEAK_F32_MFMA_TFLOPS * clock_ghz / MAX_CLOCK_GHZ)
                                                      if clock_ghz else None)},
         }
@@ -369,9 +423,8 @@ def worker(args):
             res["cpu_baseline"]["gpu_vs_cpu_max_rel_err"] = rel
             res["cpu_baseline"]["gpu_speedup_over_chunk_1000"] = value / cb["chunk_1000"]["value"]
             res["cpu_baseline"]["gpu_speedup_over_unchunked"] = value / cb["unchunked"]["value"]
-        print(json.dumps(res))
-        sys.stdout.flush()
-    if world > 1:
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if use_pg:
         dist.destroy_process_group()
 
 

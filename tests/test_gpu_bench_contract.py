@@ -34,6 +34,32 @@ def test_bench_json_line():
     assert 1.0 < r["shader_clock_ghz"] <= 2.5                             # measured live under this kernel
     assert r["frac_at_delivered_clock"] >= r["frac"] - 1e-9
     assert "ms" not in d["config"] and d["config"]["backend"] == "single process"
+    # the time-based pre-warm ran (>= 60 ms of the same step) and is disclosed; the per-step list is complete
+    assert d["prewarm_ms"] >= 60.0 and d["prewarm_steps"] >= 8
+    assert len(r["kernel_ms_per_step"]) == 5
+    assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= max(r["kernel_ms_per_step"]) + 1e-6
+    assert abs(r["kernel_ms_mean"] - r["kernel_ms"]) < 1e-12
+    assert "TIMED launches" in r["shader_clock_source"]
+    assert out.stdout.strip() == lines[0]                                  # stdout = the one JSON line, nothing else
+
+
+def test_bench_rccl_branch_on_one_gpu():
+    """AHV_BENCH_FORCE_PG=1: a single rank creates the RCCL process group (device_id given) and runs every
+    collective of the world > 1 path -- the async key all-reduce ring, the barriers, the all-reduce of the time,
+    the all-gather check -- so the first multi-GPU run is not the first run of that code.  Same arg-max and score
+    as the single-process run."""
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    single = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert single.returncode == 0, single.stderr[-2000:]
+    forced = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=REPO,
+                            env=dict(env, AHV_BENCH_FORCE_PG="1"))
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    a, b = json.loads(single.stdout.strip()), json.loads(forced.stdout.strip())
+    assert a["config"]["backend"] == "single process" and b["config"]["backend"] == "rccl"
+    assert b["n_gpus"] == 1 and a["result"] == b["result"]
+    # the collectives ride beside the kernel (async all-reduce on RCCL's stream): the step may not get much slower
+    assert b["ms_per_step"] < 1.5 * a["ms_per_step"] + 0.2
 
 
 def test_bench_launches_its_own_ranks():

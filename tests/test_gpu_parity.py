@@ -278,6 +278,45 @@ def test_fused_sharded_offsets_merge(ops, G, dev, ahv):
     assert torch.equal(key, k_full)
 
 
+def test_configs3_full_size(ops, dev, ahv, oracle):
+    """BASELINE.json configs[3] at its full size on one GPU: B = 32 pairs x N = 50 000 shared hypotheses, the
+    hypothesis axis cut into 8 contiguous shards with n_offset (what the 8 ranks do).  merge_keys over the shard
+    keys == the unsharded key bit for bit; shard scores == the unsharded scores bit for bit; a 512-hypothesis slice
+    of shard 3 vs the oracle."""
+    B, N, G8 = 32, 50000, 8
+    g = load_golden("score_n128")
+    rng = np.random.default_rng(33)
+    vs = (rng.standard_normal((B, 16, 8, 8, 8)) * 1.15).astype(np.float32)
+    vt = (rng.standard_normal((B, 16, 8, 8, 8)) * 1.15).astype(np.float32)
+    Rn = ahv.rotations.haar_rotations_np(N, 34)
+    W = [to_dev(g[k], dev) for k in ("W1", "W2", "b2")]
+    vsd, vtd, R = to_dev(vs, dev), to_dev(vt, dev), to_dev(Rn, dev)
+    ft = ops.forward_3d2d(vtd, *W)
+    s_full, k_full = ops.score_hypotheses(vsd, ft, R, *W)
+    assert s_full.shape == (B, N)
+    keys = []
+    for r in range(G8):
+        lo, hi = ahv.dist.shard_range(N, r, G8)
+        assert hi - lo == N // G8
+        s, k = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo)
+        assert torch.equal(s, s_full[:, lo:hi])            # per-hypothesis results do not depend on the shard
+        keys.append(k)
+        if r == 3:
+            ref, _, _ = oracle.score_hypotheses(vs, vt, Rn[lo:lo + 512], g["W1"], g["W2"], g["b2"])
+            assert score_relerr(s[:, :512].cpu().numpy(), ref) < SCORE_RTOL
+    merged = ahv.dist.merge_keys(torch.stack(keys))
+    assert torch.equal(merged, k_full)                       # bit for bit
+    val, idx = ops.unpack_best(merged)
+    rv, ri = torch.max(s_full, dim=1)
+    assert torch.equal(idx, ri) and torch.equal(val, rv)     # == torch.max over the full score matrix, all 32 pairs
+    # the arg-max-only launch (what a rank runs in production) merges to the same keys
+    key = None
+    for r in range(G8):
+        lo, hi = ahv.dist.shard_range(N, r, G8)
+        _, key = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, want_scores=False, best_key=key)
+    assert torch.equal(key, k_full)
+
+
 def test_fused_properties_full_size(ops, G, dev, ahv):
     """Size-independent properties at BASELINE.json's full N (50 000) and the LINEMOD-grid size (200 000)."""
     ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])

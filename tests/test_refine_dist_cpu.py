@@ -1,7 +1,8 @@
 """BASELINE.json configs[4] (coarse-to-fine), multi-rank control flow on CPU: ``CoarseToFine._step`` with
 ``world > 1`` under world-size-2 gloo.  The five device ops are injected as an oracle-backed CPU backend (test
 infrastructure; the product backend is ``3dahv_amd.ops`` = HIP only), so what is under test is exactly the part
-that differs from the single-GPU path: the two sharded stages, the two packed-key all-reduces, the owner-row sum.
+that differs from the single-GPU path: the two sharded stages and the two packed-key all-reduces (the only two
+collectives of a step; the winner's row is composed locally on every rank).
 Merged keys, R_pred and indices must equal the single-rank result bit for bit."""
 import os
 
@@ -78,8 +79,16 @@ def _worker(rank, world, port, q):
     try:
         ahv = importlib.import_module("3dahv_amd")
         from oracle import oracle
-        c2f, out = _run(ahv, oracle)
+        calls = []
+        real_all_reduce = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(tuple(t.shape)), real_all_reduce(t, *a, **k))[1]
+        try:
+            c2f, out = _run(ahv, oracle)
+        finally:
+            dist.all_reduce = real_all_reduce
         assert c2f.world == world and c2f.collectives
+        # exactly TWO exchanges per step, both the 8*B-byte key all-reduce; R_pred needs none
+        assert calls == [(3,), (3,)], calls
         q.put((rank, (c2f.c_lo, c2f.c_hi, c2f.f_lo, c2f.f_hi), out,
                c2f.last["coarse_scores"].numpy(), c2f.last["fine_scores"].numpy()))
     finally:
@@ -109,7 +118,7 @@ def test_coarse_to_fine_world2_equals_single_rank(ahv, oracle):
         assert (f_lo, f_hi) == ahv.dist.shard_range(N_FINE, rank, world)
         assert np.array_equal(s1, single.last["coarse_scores"].numpy()[:, c_lo:c_hi])
         assert np.array_equal(s2, single.last["fine_scores"].numpy()[:, f_lo:f_hi])
-    # the winner's row came from exactly one rank (the others contributed zeros): R_pred is a rotation
+    # R_pred is a rotation
     Rp = ref[2]
     assert np.allclose(Rp @ Rp.transpose(0, 2, 1), np.eye(3), atol=1e-5)
     assert np.all(ref[0] >= ref[3] - 1e-6)  # D[0] = I: refinement never scores below the coarse winner
