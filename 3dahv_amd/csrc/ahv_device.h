@@ -9,7 +9,7 @@
 // (d in {2q,2q+1}: 128 voxels x 16 ch = 8 KiB) into a private LDS buffer and contracts that quarter against W1
 // with v_mfma_f32_16x16x4_f32.  Waves never synchronise with each other inside the hypothesis loop: no s_barrier
 // on the hot path.  (Where W1 lives -- LDS fragment table, two waves per SIMD -- is ahv_dual.h; the kernels that
-// kept it in 192 registers at one wave per SIMD are retired to tools/legacy/.)
+// kept it in 192 registers at one wave per SIMD are retired: git history, round 1.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

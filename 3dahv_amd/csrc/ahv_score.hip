@@ -11,8 +11,7 @@
 // one wave owns one hypothesis, no barrier on the hot path.  LDS per workgroup (158 KiB): source image
 // 46 KiB + W1 fragment table 48 KiB + 8 x 8 KiB private quarter images (ahv_dual.h).
 // Two kernels: score_hypotheses_dual_kernel<false> (all fp32, the default) and <true> (GEMM1 as split-f16
-// MFMA products, opt-in through AHV_SCORE_SPLIT_F16; ahv_split.h).  Earlier formulations live in
-// tools/legacy/ for A/B runs in tools/kbench.cpp only.
+// MFMA products, opt-in through AHV_SCORE_SPLIT_F16; ahv_split.h).
 #include "ahv_dual.h"
 #include "ahv_split.h"
 
@@ -280,7 +279,7 @@ __global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_k
 // ---- host-side launchers (called by the C ABI in ahv_abi.hip) ----------------------
 namespace ahv {
 
-// Generic launch helper (also used by tools/legacy/ahv_score_legacy.h).
+// Generic launch helper.
 template <typename K, typename... A>
 static hipError_t launch_score_kernel(K kernel, size_t lds, dim3 grid, int threads, hipStream_t stream, A... args)
 {

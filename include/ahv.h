@@ -119,7 +119,7 @@ int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt
 /*
  * Decode packed keys: best_score[b], best_idx[b] (int64, global hypothesis index).
  * Replaces the (value, index) pair of torch.max (test_co3d.py:145).  Either output may be NULL.
- * A key of 0 (nothing scored) decodes to (-inf... see ahv.h) score = NaN-free -inf and idx = -1.
+ * A key of 0 (nothing scored: N = 0) decodes to best_score = -inf and best_idx = -1.
  */
 int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream);
 

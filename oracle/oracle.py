@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libahv_oracle.so")
+# AHV_ORACLE_LIB: an alternative build of the same source (the sanitizer build, `make -C oracle asan`)
+_LIB_PATH = os.path.abspath(os.environ.get("AHV_ORACLE_LIB") or os.path.join(_HERE, "libahv_oracle.so"))
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -25,6 +26,10 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 def build(force: bool = False) -> str:
     """Compile libahv_oracle.so with gcc (a few seconds)."""
     src = os.path.join(_HERE, "ahv_oracle.c")
+    if os.environ.get("AHV_ORACLE_LIB"):
+        if not os.path.exists(_LIB_PATH):
+            raise FileNotFoundError("AHV_ORACLE_LIB=%s does not exist (make -C oracle asan)" % _LIB_PATH)
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libahv_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -4,7 +4,6 @@
 //                                   -I3dahv_amd/csrc tools/kbench.cpp -o tools/kbench
 // Run (on the GPU box):  tools/kbench [N] [iters]
 #include "../3dahv_amd/csrc/ahv_score.hip"
-#include "legacy/ahv_score_legacy.h"  // variants 0-2: A/B only, not in libahv_hip.so
 
 #include <cstdio>
 #include <cstdlib>
@@ -51,12 +50,13 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ref(N);
-    for (int variant = (argc > 3 ? atoi(argv[3]) : 0); variant < (argc > 3 ? atoi(argv[3]) + 1 : 5); ++variant) {
-        // 0-2 = legacy formulations (tools/legacy), 3 = the product's fp32 kernel, 4 = its opt-in split-f16 sibling
+    for (int variant = (argc > 3 ? atoi(argv[3]) : 3); variant < (argc > 3 ? atoi(argv[3]) + 1 : 5); ++variant) {
+        // 3 = the product's fp32 kernel, 4 = its opt-in split-f16 sibling (0-2, the retired round-1 formulations,
+        // left the tree in round 3; the numbering is kept so that old logs stay comparable)
+        if (variant < 3) { printf("variants 0-2 are retired\n"); return 1; }
         auto launch = [&]() {
-            return variant < 3 ? ahv::launch_score_legacy(variant, dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, 0)
-                               : ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu,
-                                                              variant == 4, nullptr, 0);
+            return ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, variant == 4,
+                                                nullptr, 0);
         };
         for (int rep = 0; rep < 3; ++rep) {
             for (int w = 0; w < 3; ++w)
@@ -74,10 +74,10 @@ int main(int argc, char** argv)
         }
         std::vector<float> sc(N);
         CK(hipMemcpy(sc.data(), dsc, N * 4, hipMemcpyDeviceToHost));
-        if (variant == 0) ref = sc;
+        if (variant == 3) ref = sc;
         double md = 0;
         for (long n = 0; n < N; ++n) md = std::max(md, (double)std::abs(sc[n] - ref[n]));
-        printf("variant %d: max |score - variant0| = %.3g, score[0]=%.6f\n", variant, md, sc[0]);
+        printf("variant %d: max |score - variant3| = %.3g, score[0]=%.6f\n", variant, md, sc[0]);
     }
 #ifdef AHV_STAMPS
     // stamps belong to the last variant run (3 = dual): 4 x (gather, gemm1) quarters, gemm2, score+tail
