@@ -91,6 +91,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
     DualFrags f;
     load_dual_frags(f, W2, b2, lane);
     const GatherLane glane = gather_lane(lane);
+    const GatherDst gdst = gather_dst_swizzled(lane);
     float a2t[2][4][2];  // dr = W2^T dv: A[row = o][k = o2]: [m2][r2][m] = W2[16 m2 + 4 kq + r2][16 m + row]
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2)
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
                 gather_hyp(gh, Rm, glane);
                 HatState st;
                 hat_prologue<0>(st, lds_src, gh);
-                hat_body(st, buf, lane); wave_lds_fence();
+                hat_body(st, buf, gdst); wave_lds_fence();
                 gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, lds_src, gh); }); wave_lds_fence();
-                hat_body(st, buf, lane); wave_lds_fence();
+                hat_body(st, buf, gdst); wave_lds_fence();
                 gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue<2>(st, lds_src, gh); }); wave_lds_fence();
-                hat_body(st, buf, lane); wave_lds_fence();
+                hat_body(st, buf, gdst); wave_lds_fence();
                 gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [&] { hat_prologue<3>(st, lds_src, gh); }); wave_lds_fence();
-                hat_body(st, buf, lane); wave_lds_fence();
+                hat_body(st, buf, gdst); wave_lds_fence();
                 gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence();
             }
             f32x4 v[2][4];
@@ -476,13 +477,12 @@ __device__ __forceinline__ void bwd_w1_quarter(f32x4 (&ax)[8], f32x4 (&ay)[8], f
 
 // quarter Q of the rotated volume into this wave's X image, one pass (voxel) after the other
 template <int Q>
-__device__ __forceinline__ void w1_gather(float* xbuf, const float* srcT, const GatherHyp& gh, int lane)
+__device__ __forceinline__ void w1_gather(float* xbuf, const float* srcT, const GatherHyp& gh, const GatherDst& dst)
 {
 #ifdef AHV_DIAG_W1_NO_GATHER  // diagnostic build of tools/kbench_bwd only (wrong results)
-    asm volatile("" ::"v"(xbuf), "v"(lane));
+    asm volatile("" ::"v"(xbuf), "v"(dst.o0));
 #else
-    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
-    float* d0 = xbuf + a0 * 64 + (2 * b1 + b0) * 8 + e;
+    float* d0 = xbuf + dst.o0;
     __builtin_amdgcn_s_setprio(1);  // the gathering wave is latency-bound, its partner streams MFMAs (ahv_dual.h)
     HatVoxel vx;
     hat_voxel<Q>(vx, srcT, gh, 0);
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(kW1Threads, 2) void score_backward_w1_kernel(
     float* dbuf = lds_pool + wave * kDuHalfFloats;
     float* xbuf = lds_pool + 8 * kDuHalfFloats + wave * kXwFloats;
     const GatherLane glane = gather_lane(lane);
+    const GatherDst gdst = gather_dst_linear(lane);
     f32x4 ax[8], ay[8], az[4][2];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -553,13 +554,13 @@ __global__ __launch_bounds__(kW1Threads, 2) void score_backward_w1_kernel(
             }
             GatherHyp gh;
             gather_hyp(gh, Rm, glane);
-            w1_gather<0>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            w1_gather<0>(xbuf, lds_src, gh, gdst); wave_lds_fence();
             bwd_w1_quarter<0>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
-            w1_gather<1>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            w1_gather<1>(xbuf, lds_src, gh, gdst); wave_lds_fence();
             bwd_w1_quarter<1>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
-            w1_gather<2>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            w1_gather<2>(xbuf, lds_src, gh, gdst); wave_lds_fence();
             bwd_w1_quarter<2>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
-            w1_gather<3>(xbuf, lds_src, gh, lane); wave_lds_fence();
+            w1_gather<3>(xbuf, lds_src, gh, gdst); wave_lds_fence();
             bwd_w1_quarter<3>(ax, ay, az, dbuf, xbuf, lane); wave_lds_fence();
         }
     }
@@ -763,19 +764,17 @@ constexpr int kDvRow = 17;
 constexpr int kDvCornerBytes(int n) { return (((n & 1) ? 1 : 0) + ((n & 2) ? 8 : 0) + ((n & 4) ? 64 : 0)) * kDvRow * 8; }
 
 template <int Q>
-__device__ __forceinline__ void bwd_vol_corners(float* ctab, const GatherHyp& h, int lane)
+__device__ __forceinline__ void bwd_vol_corners(float* ctab, const GatherHyp& h, const GatherDst& dst)
 {
-    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
-        hat_axis(fmaf((float)Q, h.dq[0], h.i0[0][p]), jx, wx0, wx1);
-        hat_axis(fmaf((float)Q, h.dq[1], h.i0[1][p]), jy, wy0, wy1);
-        hat_axis(fmaf((float)Q, h.dq[2], h.i0[2][p]), jz, wz0, wz1);
+        hat_axis(gather_coord<Q>(h, 0, p), jx, wx0, wx1);
+        hat_axis(gather_coord<Q>(h, 1, p), jy, wy0, wy1);
+        hat_axis(gather_coord<Q>(h, 2, p), jz, wz0, wz1);
         const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
         const float base = fmaf(jz, 64.0f * (kDvRow * 8), fmaf(jy, 8.0f * (kDvRow * 8), jx * (float)(kDvRow * 8)));  // bytes
-        const int b = 4 * p + 2 * b1 + b0;
-        float* row = ctab + (a0 * 64 + b * 8 + e) * kCtRow;
+        float* row = ctab + (p ? dst.o1 : dst.o0) * kCtRow;
         *reinterpret_cast<f32x4*>(row + 0) = f32x4{w00 * wx0, w00 * wx1, w01 * wx0, w01 * wx1};
         *reinterpret_cast<f32x4*>(row + 4) = f32x4{w10 * wx0, w10 * wx1, w11 * wx0, w11 * wx1};
         row[8] = __uint_as_float((unsigned)base);
@@ -876,6 +875,7 @@ __global__ __launch_bounds__(kVolThreads, 2) void score_backward_volume_kernel(
         for (int q = 0; q < 4; ++q) wz[q][sp] = w[256 + (8 * role + (row & 7)) * 8 + 2 * q + (row >> 3)];
     }
     const GatherLane glane = gather_lane(lane);
+    const GatherDst gdst = gather_dst_linear(lane);
 
     const long hstep = (long)gridDim.x * 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
@@ -905,22 +905,22 @@ __global__ __launch_bounds__(kVolThreads, 2) void score_backward_volume_kernel(
             load_du_regs(nxt, du_ws + ((long)b * N + hn) * 2048, lane);
             bwd_vol_dx<0>(wx, wy, wz, du, xbuf, lane);
             AHV_VOL_PRIO(1);
-            bwd_vol_corners<0>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_corners<0>(ctab, gh, gdst); wave_lds_fence();
             bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
             AHV_VOL_PRIO(0);
             bwd_vol_dx<1>(wx, wy, wz, du, xbuf, lane);
             AHV_VOL_PRIO(1);
-            bwd_vol_corners<1>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_corners<1>(ctab, gh, gdst); wave_lds_fence();
             bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
             AHV_VOL_PRIO(0);
             bwd_vol_dx<2>(wx, wy, wz, du, xbuf, lane);
             AHV_VOL_PRIO(1);
-            bwd_vol_corners<2>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_corners<2>(ctab, gh, gdst); wave_lds_fence();
             bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
             AHV_VOL_PRIO(0);
             bwd_vol_dx<3>(wx, wy, wz, du, xbuf, lane);
             AHV_VOL_PRIO(1);
-            bwd_vol_corners<3>(ctab, gh, lane); wave_lds_fence();
+            bwd_vol_corners<3>(ctab, gh, gdst); wave_lds_fence();
             bwd_vol_scatter(xbuf, ctab, lds_dv, fx_scale, role, lane); wave_lds_fence();
             AHV_VOL_PRIO(0);
             du = nxt;

@@ -104,6 +104,20 @@ __device__ __forceinline__ void gemm1_quarter_lds(f32x4 (&acc)[2][4], const floa
     }
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ReLU in ONE instruction per register: a signed-integer max of the float's bits with 0 (negative floats, -0
+// included, are negative integers; non-negative floats order like their bits).  fmaxf / fmed3 compile to v_max(x, x)
+// (canonicalise) + v_max(0, x) because the compiler cannot know that an MFMA result needs no canonicalisation, and
+// every vector instruction costs ~4 issue cycles beside the partner wave's MFMA stream (32 ReLUs per hypothesis).
+// Same value for every non-NaN input; a NaN with a clear sign bit stays a NaN (torch's relu propagates it too).
+// Not inline asm: the compiler does not pad the MFMA -> VALU read hazard in front of an instruction it cannot see
+// into (the split-f16 kernel read stale accumulators that way).
+__device__ __forceinline__ f32x4 relu4(f32x4 x)
+{
+    return __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, x), i32x4{0, 0, 0, 0}));
+}
+
 __device__ __forceinline__ void gemm2_dual(f32x4 (&v)[2][4], const f32x4 (&acc)[2][4], const DualFrags& f)
 {
 #pragma unroll
@@ -112,15 +126,18 @@ __device__ __forceinline__ void gemm2_dual(f32x4 (&v)[2][4], const f32x4 (&acc)[
         v[1][t] = f.bias[1];
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        f32x4 u[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) u[t] = relu4(acc[m][t]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float u = __builtin_amdgcn_fmed3f(acc[m][t][r], 0.0f, __builtin_inff());  // relu, one instruction
-                v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][0], u, v[0][t], 0, 0, 0);
-                v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][1], u, v[1][t], 0, 0, 0);
+                v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][0], u[t][r], v[0][t], 0, 0, 0);
+                v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][1], u[t][r], v[1][t], 0, 0, 0);
             }
+    }
 }
 
 
@@ -154,34 +171,95 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define AHV_PRIO 1
 #endif
 
+// Lane -> output voxel of a gather pass.  The 16 lanes that the LDS serves together in a ds_read_b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) own a compact 4 (x) x 2 (y) x 2 (z) block of the quarter, so that
+// after any rotation their source rows form a compact block too (fewest bank conflicts: table in ahv_device.h).
+// Group g = 2 (lane >> 5) + (second group of its half-wave), slot k = rank of the lane inside its group:
+//   x = 4 (g & 1) + (k & 3),  y = 2 (g >> 1) + ((k >> 2) & 1) [+ 4 in pass 1],  z = 2 Q + (k >> 3).
+// The two groups of a half-wave differ in x bit 2, which keeps the ds_write_b32 of the blended voxels into the
+// XOR-swizzled quarter image (qoff) on 32 distinct banks.
+struct LaneVox {
+    int e, a0, bq;  // x (0..7), z inside the quarter (0..1), y inside the pass (0..3)
+};
+
+__device__ __forceinline__ LaneVox lane_vox(int lane)
+{
+    const unsigned l = lane & 31;
+    const unsigned kFirst = 0x0FF0F00Fu;  // lanes {0-3, 12-15, 20-27} of a half-wave: the first b128 group
+    const bool first = (kFirst >> l) & 1u;
+    const int k = __builtin_popcount((first ? kFirst : ~kFirst) & ((1u << l) - 1u));  // rank inside the group
+    LaneVox v;
+    v.e = (first ? 0 : 4) + (k & 3);
+    v.bq = 2 * (lane >> 5) + ((k >> 2) & 1);
+    v.a0 = k >> 3;
+    return v;
+}
+
+// Offsets (floats) of the lane's two voxels (pass 0, pass 1) inside a channel plane of the destination image,
+// computed ONCE per kernel: passed through an empty asm so that the compiler keeps the two registers instead of
+// re-deriving the lane map inside the hypothesis loop (it did: 12 compares and 15 exec-mask updates per hypothesis).
+struct GatherDst {
+    int o0, o1;
+};
+
+// the forward's XOR-swizzled quarter image (qoff)
+__device__ __forceinline__ GatherDst gather_dst_swizzled(int lane)
+{
+    const LaneVox lv = lane_vox(lane);
+    GatherDst d = {qoff(lv.a0, lv.bq, lv.e), qoff(lv.a0, 4 + lv.bq, lv.e)};
+    asm volatile("" : "+v"(d.o0), "+v"(d.o1));
+    return d;
+}
+
+// a linear image X[c][voxel = a0 * 64 + b * 8 + e] (backward kernels)
+__device__ __forceinline__ GatherDst gather_dst_linear(int lane)
+{
+    const LaneVox lv = lane_vox(lane);
+    GatherDst d = {lv.a0 * 64 + lv.bq * 8 + lv.e, lv.a0 * 64 + (4 + lv.bq) * 8 + lv.e};
+    asm volatile("" : "+v"(d.o0), "+v"(d.o1));
+    return d;
+}
+
 struct GatherLane {
     float x4, y4, z4;  // 4 * voxel-centre coordinate of this lane's (pass 0, quarter 0) voxel: (2 i + 1) / 2 - 4
 };
 
 __device__ __forceinline__ GatherLane gather_lane(int lane)
 {
-    const int e = lane & 7, a0 = (lane >> 3) & 1, b = 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
+    const LaneVox v = lane_vox(lane);
     GatherLane g;
-    g.x4 = (float)(2 * e + 1) * 0.5f - 4.0f;
-    g.y4 = (float)(2 * b + 1) * 0.5f - 4.0f;
-    g.z4 = (float)(2 * a0 + 1) * 0.5f - 4.0f;
+    g.x4 = (float)(2 * v.e + 1) * 0.5f - 4.0f;
+    g.y4 = (float)(2 * v.bq + 1) * 0.5f - 4.0f;
+    g.z4 = (float)(2 * v.a0 + 1) * 0.5f - 4.0f;
     return g;
 }
 
 struct GatherHyp {
-    float i0[3][2];  // [axis][pass]: coordinate of the lane's voxel in quarter 0
-    float dq[3];     // per-quarter increment 2 R[axis][2]
+    f32x2 ixy[2];  // [pass]: (x, y) sample coordinates of the lane's voxel in quarter 0 (a register pair: v_pk_* operands)
+    f32x2 dqxy;    // per-quarter increment 2 R[axis][2] of x and y
+    float iz[2];   // the same for z
+    float dqz;
 };
 
 __device__ __forceinline__ void gather_hyp(GatherHyp& h, const float* Rm, const GatherLane& g)
 {
+    float i0[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float i = fmaf(Rm[3 * a + 0], g.x4, fmaf(Rm[3 * a + 1], g.y4, fmaf(Rm[3 * a + 2], g.z4, 3.5f)));
-        h.i0[a][0] = i;
-        h.i0[a][1] = fmaf(4.0f, Rm[3 * a + 1], i);
-        h.dq[a] = 2.0f * Rm[3 * a + 2];
-    }
+    for (int a = 0; a < 3; ++a)
+        i0[a] = fmaf(Rm[3 * a + 0], g.x4, fmaf(Rm[3 * a + 1], g.y4, fmaf(Rm[3 * a + 2], g.z4, 3.5f)));
+    h.ixy[0] = f32x2{i0[0], i0[1]};
+    h.ixy[1] = f32x2{fmaf(4.0f, Rm[1], i0[0]), fmaf(4.0f, Rm[4], i0[1])};
+    h.dqxy = f32x2{2.0f * Rm[2], 2.0f * Rm[5]};
+    h.iz[0] = i0[2];
+    h.iz[1] = fmaf(4.0f, Rm[7], i0[2]);
+    h.dqz = 2.0f * Rm[8];
+}
+
+// sample coordinate of the lane's voxel (pass p of quarter Q) along axis a (0 = x, 1 = y, 2 = z)
+template <int Q>
+__device__ __forceinline__ float gather_coord(const GatherHyp& h, int a, int p)
+{
+    return a == 2 ? fmaf((float)Q, h.dqz, h.iz[p]) : fmaf((float)Q, h.dqxy[a], h.ixy[p][a]);
 }
 
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
@@ -203,23 +281,45 @@ struct HatVoxel {
 
 __device__ __forceinline__ constexpr int hat_off(int n)
 {
-    return ((n & 1) ? 4 * kSrcStride : 0) + ((n & 2) ? 4 * 8 * kSrcStride : 0) + ((n & 4) ? 4 * kSrcPlaneRows * kSrcStride : 0);
+    return ((n & 1) ? 4 * kSrcStride : 0) + ((n & 2) ? 4 * kSrcRowsY * kSrcStride : 0) + ((n & 4) ? 4 * kSrcPlaneRows * kSrcStride : 0);
 }
 
 template <int Q>
 __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const GatherHyp& h, int p)
 {
     float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
-    hat_axis(fmaf((float)Q, h.dq[0], h.i0[0][p]), jx, wx0, wx1);
-    hat_axis(fmaf((float)Q, h.dq[1], h.i0[1][p]), jy, wy0, wy1);
-    hat_axis(fmaf((float)Q, h.dq[2], h.i0[2][p]), jz, wz0, wz1);
+    // x and y ride on packed instructions where one exists (coordinate, offset from the base row, offset - 1);
+    // floor, med3 and the |.|-with-clamp subtraction have no packed form
+    const f32x2 ixy = Q == 0 ? h.ixy[p] : __builtin_elementwise_fma(f32x2{(float)Q, (float)Q}, h.dqxy, h.ixy[p]);
+    jx = __builtin_amdgcn_fmed3f(floorf(ixy[0]), 0.0f, 6.0f);
+    jy = __builtin_amdgcn_fmed3f(floorf(ixy[1]), 0.0f, 6.0f);
+    const f32x2 uxy = ixy - f32x2{jx, jy};
+    const f32x2 txy = uxy - f32x2{1.0f, 1.0f};
+    wx0 = clamp01(1.0f - fabsf(uxy[0]));
+    wy0 = clamp01(1.0f - fabsf(uxy[1]));
+    wx1 = clamp01(1.0f - fabsf(txy[0]));
+    wy1 = clamp01(1.0f - fabsf(txy[1]));
+    hat_axis(Q == 0 ? h.iz[p] : fmaf((float)Q, h.dqz, h.iz[p]), jz, wz0, wz1);
+#ifndef AHV_SCALAR_WEIGHTS  // A/B knob of tools/kbench: measured 0.7081 -> 0.7033 ms per 50 000 hypotheses
+    // the outer product of the three weight pairs on v_pk_mul_f32 (6 instead of 12 multiplications, same products)
+    const f32x2 wy = {wy0, wy1}, wx = {wx0, wx1};
+    const f32x2 w0y = wz0 * wy, w1y = wz1 * wy;
+    const f32x2 a = w0y[0] * wx, b = w0y[1] * wx, c = w1y[0] * wx, d = w1y[1] * wx;
+    v.w[0] = a[0]; v.w[1] = a[1]; v.w[2] = b[0]; v.w[3] = b[1];
+    v.w[4] = c[0]; v.w[5] = c[1]; v.w[6] = d[0]; v.w[7] = d[1];
+#else
     const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
     v.w[0] = w00 * wx0; v.w[1] = w00 * wx1; v.w[2] = w01 * wx0; v.w[3] = w01 * wx1;
     v.w[4] = w10 * wx0; v.w[5] = w10 * wx1; v.w[6] = w11 * wx0; v.w[7] = w11 * wx1;
+#endif
     // byte offset of row (jz, jy, jx): exact in fp32 (< 2^24), one conversion
     const float af = fmaf(jz, (float)(4 * kSrcPlaneRows * kSrcStride),
-                          fmaf(jy, (float)(4 * 8 * kSrcStride), jx * (float)(4 * kSrcStride)));
+                          fmaf(jy, (float)(4 * kSrcRowsY * kSrcStride), jx * (float)(4 * kSrcStride)));
     v.base = reinterpret_cast<const char*>(srcT) + (unsigned)af;
+#ifdef AHV_DIAG_LINEAR_GATHER  // diagnostic only (wrong results): row = lane, so every b128 lane group of every corner
+    // request covers the 16 slots once -- the conflict-free bound of the gather (tools/kbench, profiles/r03_scorer_segments.txt)
+    v.base = reinterpret_cast<const char*>(srcT) + (threadIdx.x & 63) * (4 * kSrcStride);
+#endif
 }
 
 // Quarter Q of the rotated volume into `buf`.  The two voxels of a lane (passes 0, 1) are blended as ONE stream
@@ -304,14 +404,13 @@ struct HatSteps<16, ROW> {
 };
 
 // the 16 blend steps of a quarter whose prologue has been issued
-__device__ __forceinline__ void hat_body(HatState& st, float* buf, int lane)
+__device__ __forceinline__ void hat_body(HatState& st, float* buf, const GatherDst& dst)
 {
-    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
     f32x2 o[8];
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-    HatSteps<0>::run(st, o, buf + qoff(a0, 2 * b1 + b0, e), buf + qoff(a0, 4 + 2 * b1 + b0, e));
+    HatSteps<0>::run(st, o, buf + dst.o0, buf + dst.o1);
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -319,12 +418,10 @@ __device__ __forceinline__ void hat_body(HatState& st, float* buf, int lane)
 
 // the same into a LINEAR image X[c][voxel = a0*64 + b*8 + e] with ROW floats per channel plane (backward kernels)
 template <int ROW>
-__device__ __forceinline__ void hat_body_linear(HatState& st, float* img, int lane)
+__device__ __forceinline__ void hat_body_linear(HatState& st, float* img, const GatherDst& dst)
 {
-    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
     f32x2 o[8];
-    float* d0 = img + a0 * 64 + (2 * b1 + b0) * 8 + e;
-    HatSteps<0, ROW>::run(st, o, d0, d0 + 32);
+    HatSteps<0, ROW>::run(st, o, img + dst.o0, img + dst.o1);
 }
 
 }  // namespace ahv

@@ -35,19 +35,24 @@ __device__ __forceinline__ float swap_add16(float a, float b)
 // col), so the normalisation runs once per lane.  Result uniform (read from lane 63).
 __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x4 (&tg)[4][2], int lane)
 {
+    // sums of squares and dot products on v_pk_fma_f32: even and odd registers accumulate side by side and meet in
+    // one addition (32 packed instead of 64 scalar FMAs per hypothesis; the order of the eight additions differs from
+    // a sequential sum in the last bit at most)
     float ss[4], dt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        ss[t] = 0.0f;
-        dt[t] = 0.0f;
+        f32x2 s2 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f};
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = v[m2][t][r];
-                ss[t] += x * x;
-                dt[t] += x * tg[t][m2][r];
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 x = {v[m2][t][2 * hh], v[m2][t][2 * hh + 1]};
+                const f32x2 g = {tg[t][m2][2 * hh], tg[t][m2][2 * hh + 1]};
+                s2 = __builtin_elementwise_fma(x, x, s2);
+                d2 = __builtin_elementwise_fma(x, g, d2);
             }
+        ss[t] = s2[0] + s2[1];
+        dt[t] = d2[0] + d2[1];
     }
     // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: with
     // (first, second) = (tile i, tile i+2) every lane then holds, in the two registers, its own half-sum of the
@@ -71,6 +76,8 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
 // Diagnostic build only (tools/kbench.cpp): per-wave cycle sums of the loop segments.  The stamps
 // leave the kernel through this buffer alone; no output value depends on them.
 __device__ unsigned long long g_stamps[2048 * 16];
+// per workgroup: 100 MHz real-time stamps at kernel entry, hypothesis-loop start and end, and the XCC id
+__device__ unsigned long long g_wgstamps[1024 * 4];
 #define AHV_STAMP(var)                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
@@ -102,6 +109,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     float* buf = lds_q + wave * kQuarterFloats;
 
     static_assert(kSplitTableBytes == sizeof(float) * kW1TableFloats && kSplitImageBytes == sizeof(float) * kQuarterFloats, "LDS budget");
+#ifdef AHV_STAMPS
+    const unsigned long long wg_t_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wg_t_loop = 0;
+#endif
     int w1_exp = 0;
     if (SPLIT) {
         float m = 0.0f;
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     DualFrags f0;
     load_dual_frags(f0, W2, b2, lane);
     const GatherLane glane = gather_lane(lane);
+    const GatherDst gdst = gather_dst_swizzled(lane);
     const long hstep = (long)gridDim.x * 8;
     // Diagnostic entry point only (clk != NULL): shader-clock and 100 MHz real-time stamps around this
     // workgroup's whole hypothesis loop.  The stamps go to `clk` alone; no output depends on them.
@@ -160,15 +172,21 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             for (int i = 0; i < AHV_DUAL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
         }
 #endif
+#ifdef AHV_STAMPS
+        wg_t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
         unsigned long long best = 0ull;
         const float* Rb = R + (long)b * r_batch_stride;
         // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): the last, partial round of
         // the persistent grid then spreads over ALL CUs with few waves each (a lone wave on a SIMD runs
         // ~1.6x faster than a pair) instead of filling some CUs completely and leaving the rest idle.
         long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
-        float Rn[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rn[i] = Rb[(h < N ? h : 0) * 9 + i];
+        // The rotation of the NEXT hypothesis travels as ONE vector load (lane i < 9 fetches element i) and is
+        // broadcast with v_readlane at the top of the next iteration.  Not as scalar loads: SMEM shares lgkmcnt
+        // with the LDS and returns out of order, so the first LDS wait behind an s_load has to wait for the s_load
+        // too -- a first-touch read of R from HBM (~2 us) in front of every hypothesis' first gather step.
+        const int rl = lane < 9 ? lane : 8;
+        float Rn = Rb[(h < N ? h : 0) * 9 + rl];
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -178,11 +196,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Rm[i] = Rn[i];
+            for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rn), i));
             {
                 const long hn = (h + hstep < N) ? h + hstep : h;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) Rn[i] = Rb[hn * 9 + i];
+                Rn = Rb[hn * 9 + rl];
             }
             f32x4 acc[2][4];
 #pragma unroll
@@ -215,13 +232,14 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 gather_hyp(gh, Rm, glane);
                 HatState st;
                 hat_prologue<0>(st, srcT, gh);
-                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(1)
+                hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(1)
                 gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(2)
-                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(3)
+
+                hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(3)
                 gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue<2>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(4)
-                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(5)
+                hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(5)
                 gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [&] { hat_prologue<3>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(6)
-                hat_body(st, buf, lane); wave_lds_fence(); AHV_TS(7)
+                hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(7)
                 gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             }
 
@@ -251,6 +269,16 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         }
 #endif
         if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
+#ifdef AHV_STAMPS
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* o = g_wgstamps + 4 * (blockIdx.x & 1023);
+            o[0] = wg_t_entry;
+            o[1] = wg_t_loop;
+            o[2] = __builtin_amdgcn_s_memrealtime();
+            o[3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20);  // HW_REG_XCC_ID, bits 3:0
+        }
+#endif
     }
     if (clk != nullptr) {
         __syncthreads();

@@ -94,7 +94,7 @@ __device__ __forceinline__ int stage_src_volume_scaled(float* srcT, const float*
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int i = tid + 512 * k, c = i >> 9, v = i & 511;
-        srcT[((v >> 6) * kSrcPlaneRows + (v & 63)) * kSrcStride + c] = x[k] * scale;
+        srcT[((v >> 6) * kSrcPlaneRows + ((v >> 3) & 7) * kSrcRowsY + (v & 7)) * kSrcStride + c] = x[k] * scale;
     }
     return e;
 }

@@ -217,6 +217,7 @@ def test_eval_co3d_tool_end_to_end_on_gpu(ahv, tmp_path, capsys):
     the synthetic CO3D dataset with a randomly initialised Lightning-style checkpoint and the synthetic backbone:
     yaml -> checkpoint -> annotations -> HIP encoder + fused verify per pair -> co3d_result.txt."""
     import importlib.util
+    import os
     import yaml
     from .conftest import REPO
     from .test_co3d_cpu import write_dataset

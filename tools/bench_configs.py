@@ -106,6 +106,40 @@ if not only or "enc" in only:
         print(json.dumps({"config": "encoder forward_2d3d", "B": B, "hip_us": ms_hip * 1e3, "torch_ops_us": ms_torch * 1e3,
                           "max_rel_diff": rel}))
 
+if "enchost" in only:
+    # HOST time of forward_2d3d at B = 1 (the packed-weight version check cost ~350 us of Python
+    # per call): perf_counter around calls that only enqueue (no sync inside the loop), eager and graphed; GPU time of
+    # the same loops from events; the version check alone.
+    torch.manual_seed(0)
+    fa = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).to(dev).eval()
+    a, b = torch.randn(1, 768, 8, 8, device=dev), torch.randn(1, 768, 8, 8, device=dev)
+
+    def host_us(fn, iters=300):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        host = (time.perf_counter() - t0) / iters * 1e6
+        torch.cuda.synchronize()
+        return host, e0.elapsed_time(e1) / iters * 1e3
+
+    with torch.no_grad():
+        h_e, g_e = host_us(lambda: fa.forward_2d3d(a, b, random_mask=False, mask_ratio=0.0))
+    run = fa.graphed_forward_2d3d(1)
+    h_g, g_g = host_us(lambda: run(a, b))
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        ahv.aligner._packed_aligner(fa, dev)
+    chk = (time.perf_counter() - t0) / 2000 * 1e6
+    print(json.dumps({"config": "encoder forward_2d3d B=1 host time", "eager": {"host_us_per_call": h_e, "gpu_us_per_call": g_e},
+                      "hipgraph": {"host_us_per_call": h_g, "gpu_us_per_call": g_g},
+                      "packed_weight_version_check_us": chk, "parameters_checked": len(list(fa.parameters()))}))
+
 if not only or "train" in only:
     # training-size scorer step (reference config.yaml: TRAIN.BS 12, DATA.NUM_ROTA 3000, per-sample rotations):
     # forward + backward of the (B,N) similarities, HIP fused kernels vs autograd over stock PyTorch-ROCm operators

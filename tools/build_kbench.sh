@@ -5,3 +5,7 @@ cd "$(dirname "$0")/.."
 F="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I3dahv_amd/csrc -Iinclude -Itools"
 timeout 900 hipcc $F tools/kbench.cpp -o tools/kbench
 timeout 900 hipcc $F -DAHV_STAMPS tools/kbench.cpp -o tools/kbench_stamps
+# conflict-free bound of the gather (wrong results; timing and stamps only)
+timeout 900 hipcc $F -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_lin
+timeout 900 hipcc $F -DAHV_STAMPS -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_stamps_lin
+timeout 900 hipcc $F -DAHV_PK_WEIGHTS tools/kbench.cpp -o tools/kbench_pkw

@@ -5,6 +5,7 @@
 // Run (on the GPU box):  tools/kbench [N] [iters]
 #include "../3dahv_amd/csrc/ahv_score.hip"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -90,6 +91,22 @@ int main(int argc, char** argv)
     for (int i = 0; i < 10; ++i) tot += sum[i] / sum[10];
     for (int i = 0; i < 10; ++i) printf("  %-10s %8.0f ticks/hyp (%.1f%%)\n", names[i], sum[i] / sum[10], 100 * sum[i] / sum[10] / tot);
     printf("  total      %8.0f ticks/hyp per wave (two waves share a SIMD), rounds/wave %.1f\n", tot, sum[10] / 2048);
+    // per-workgroup real-time stamps (100 MHz) of the last launch: prologue length, loop length, finish spread per XCC
+    std::vector<unsigned long long> wg(1024 * 4);
+    CK(hipMemcpyFromSymbol(wg.data(), HIP_SYMBOL(ahv::g_wgstamps), wg.size() * 8));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    int nwg = 0;
+    for (int w = 0; w < 1024; ++w) if (wg[4 * w + 2]) { t0 = std::min(t0, wg[4 * w]); t1 = std::max(t1, wg[4 * w + 2]); ++nwg; }
+    double pro = 0, loop = 0, idle = 0, entry = 0;
+    double xs[16] = {0}, xe[16] = {0}; int xn[16] = {0};
+    for (int w = 0; w < 1024; ++w) if (wg[4 * w + 2]) {
+        pro += (wg[4 * w + 1] - wg[4 * w]) * 0.01; loop += (wg[4 * w + 2] - wg[4 * w + 1]) * 0.01;
+        idle += (t1 - wg[4 * w + 2]) * 0.01; entry += (wg[4 * w] - t0) * 0.01;
+        const int x = (int)(wg[4 * w + 3] & 15); xs[x] += (wg[4 * w + 2] - wg[4 * w + 1]) * 0.01; xe[x] += (t1 - wg[4 * w + 2]) * 0.01; ++xn[x];
+    }
+    printf("  workgroups %d: first entry -> last exit %.1f us; mean entry delay %.1f us, prologue %.1f us, loop %.1f us, idle at the end %.1f us\n",
+           nwg, (t1 - t0) * 0.01, entry / nwg, pro / nwg, loop / nwg, idle / nwg);
+    for (int x = 0; x < 16; ++x) if (xn[x]) printf("    XCC %d: %d workgroups, mean loop %.1f us, mean idle at the end %.1f us\n", x, xn[x], xs[x] / xn[x], xe[x] / xn[x]);
 #endif
     return 0;
 }
