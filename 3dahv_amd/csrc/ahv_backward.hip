@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
     int B, long N, const float* __restrict__ grad_scores, float* __restrict__ du_ws,
     unsigned* __restrict__ du_max_bits, float* __restrict__ grad_feat_tgt, float* __restrict__ grad_W2, float* __restrict__ grad_b2)
 {
-    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(1024))) float lds_src[kSrcFloats];  // at LDS address 0: see ahv_score.hip
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
     __shared__ __attribute__((aligned(16))) float lds_q[4 * kQuarterFloats];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kW1Threads, 2) void score_backward_w1_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ R, long r_batch_stride, int B, long N,
     const float* __restrict__ du_ws, float* __restrict__ dw1_partials)
 {
-    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    __shared__ __attribute__((aligned(1024))) float lds_src[kSrcFloats];  // at LDS address 0: see ahv_score.hip
     // per wave: du rows 16 role .. 16 role + 15 (local rows 0 .. 15) and the X image; after the hypothesis loop the
     // same pool is the scratch of the in-workgroup reduction of the accumulators
     __shared__ __attribute__((aligned(16))) float lds_pool[8 * kDuHalfFloats + 8 * kXwFloats];

@@ -34,11 +34,33 @@ __device__ __forceinline__ float w1_table_entry(const float* __restrict__ W1, in
     return w[256 + (2 * cp + (kq >> 1)) * 8 + 2 * q + (kq & 1)];
 }
 
+// Table slot of W1[o][k] (the inverse of w1_table_entry).
+__device__ __forceinline__ int w1_table_slot(int o, int k)
+{
+    const int m = o >> 4, row = o & 15, slab = k >> 7, kk = k & 127;
+    if (slab < 2) {
+        const int c = kk >> 3, hh = (kk >> 2) & 1, kq = kk & 3;
+        return ((16 * slab + c) * 64 + 16 * kq + row) * 4 + 2 * hh + m;
+    }
+    const int cc = kk >> 3, d = kk & 7;  // channel, depth
+    const int q = d >> 1, kq = 2 * (cc & 1) + (d & 1), cp = cc >> 1;
+    return ((32 + 4 * q + (cp >> 1)) * 64 + 16 * kq + row) * 4 + 2 * (cp & 1) + m;
+}
+
+// W1 [32][384] -> fragment table.  Read as 16-byte rows (six per thread of a 512-thread workgroup, all in flight at
+// once) and scattered into LDS; the gather form (one 4-byte load per table entry, 24 dependent-address iterations
+// per thread) took most of the kernel's 7-us prologue.
 __device__ __forceinline__ void stage_w1_table(float* table, const float* __restrict__ W1, int tid, int nthreads)
 {
-    for (int i = tid; i < kW1TableFloats; i += nthreads) {
-        const int j = i & 3, lane = (i >> 2) & 63, g = i >> 8;
-        table[i] = w1_table_entry(W1, g, lane, j);
+    if ((reinterpret_cast<unsigned long long>(W1) & 15ull) == 0) {
+        for (int i = tid; i < 32 * 96; i += nthreads) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + 4 * i);
+            const int o = i / 96, k = 4 * (i - 96 * o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) table[w1_table_slot(o, k + e)] = w[e];
+        }
+    } else {  // a view that starts off a 16-byte boundary: same map, one float at a time
+        for (int i = tid; i < 32 * 384; i += nthreads) table[w1_table_slot(i / 384, i % 384)] = W1[i];
     }
 }
 

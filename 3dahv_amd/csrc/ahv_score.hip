@@ -99,7 +99,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const float* __restrict__ b2, int B, long N, float* __restrict__ scores,
     unsigned long long* __restrict__ best_key, unsigned long long* __restrict__ clk)
 {
-    __shared__ __attribute__((aligned(16))) float lds_src[kSrcFloats];
+    // The source image goes FIRST in LDS (the backend lays the arrays out by descending alignment): the gather builds
+    // a row's byte offset in fp32 and converts it once, so with the image at LDS address 0 the offset IS the address
+    // (it sat at 0x1c000, too far for the 16-bit immediate of ds_read: one v_add_u32 per voxel).
+    __shared__ __attribute__((aligned(1024))) float lds_src[kSrcFloats];
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
     __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
     const int tid = threadIdx.x;

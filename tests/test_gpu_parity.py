@@ -173,6 +173,21 @@ def test_fused_n128_config1(ops, G, g128):
     assert val.item() == scores[0, idx.item()].item()  # the key carries the exact fp32 score
 
 
+def test_head_weights_off_a_16_byte_boundary(ops, G, g128, dev):
+    """W1 handed over as a contiguous view that starts 4 bytes into its storage (the staging code reads 16-byte
+    rows when it can and single floats when it cannot): same scores, fused and op-level."""
+    store = torch.empty(32 * 384 + 1, dtype=torch.float32, device=dev)
+    W1u = store[1:].view(32, 384)
+    W1u.copy_(G["W1"])
+    assert W1u.data_ptr() % 16 == 4 and W1u.is_contiguous()
+    ft = ops.forward_3d2d(G["vol_tgt"], W1u, G["W2"], G["b2"])
+    assert torch.equal(ft, ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"]))
+    s_u, k_u = ops.score_hypotheses(G["vol_src"], ft, G["R"], W1u, G["W2"], G["b2"])
+    s_a, k_a = ops.score_hypotheses(G["vol_src"], ft, G["R"], G["W1"], G["W2"], G["b2"])
+    assert torch.equal(s_u, s_a) and torch.equal(k_u, k_a)
+    assert score_relerr(s_u.cpu().numpy(), g128["scores"]) < SCORE_RTOL
+
+
 def test_fused_n4096(ops, G, dev):
     g = load_golden("score_n4096")
     scores, val, idx = fused(ops, G, to_dev(g["R"], dev))
