@@ -390,10 +390,22 @@ __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, co
     hat_voxel<Q>(st.vx[1], srcT, h, 1);
 }
 
-// ROW = floats between the channel planes of the destination image (128: the forward's swizzled quarter image)
-template <int S, int ROW = 128>
+// Where a blended voxel goes.  ROW = floats between the channel planes of the destination image (128: the
+// forward's swizzled quarter image).  The split-f16 kernel has a store of its own (HatStoreSplit, ahv_split.h).
+template <int ROW>
+struct HatStoreF32 {
+    float* d[2];  // the lane's voxel of pass 0 / pass 1 in channel plane 0
+    __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
+    {
+        float* dst = d[p];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c * ROW] = o[c >> 1][c & 1];
+    }
+};
+
+template <int S, typename Store>
 struct HatSteps {
-    static __device__ __forceinline__ void run(HatState& st, f32x2 (&o)[8], float* dst0, float* dst1)
+    static __device__ __forceinline__ void run(HatState& st, f32x2 (&o)[8], const Store& store)
     {
         constexpr int p = S >> 3, n = S & 7;
         __builtin_amdgcn_sched_barrier(0);
@@ -412,27 +424,24 @@ struct HatSteps {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (S + kHatDepth < 16) hat_request<(S + kHatDepth < 16 ? S + kHatDepth : 0)>(st);
-        if (n == 7) {
-            float* dst = p ? dst1 : dst0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) dst[c * ROW] = o[c >> 1][c & 1];
-        }
-        HatSteps<S + 1, ROW>::run(st, o, dst0, dst1);
+        if (n == 7) store(p, o);
+        HatSteps<S + 1, Store>::run(st, o, store);
     }
 };
-template <int ROW>
-struct HatSteps<16, ROW> {
-    static __device__ __forceinline__ void run(HatState&, f32x2 (&)[8], float*, float*) {}
+template <typename Store>
+struct HatSteps<16, Store> {
+    static __device__ __forceinline__ void run(HatState&, f32x2 (&)[8], const Store&) {}
 };
 
 // the 16 blend steps of a quarter whose prologue has been issued
 __device__ __forceinline__ void hat_body(HatState& st, float* buf, const GatherDst& dst)
 {
     f32x2 o[8];
+    const HatStoreF32<128> store = {{buf + dst.o0, buf + dst.o1}};
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-    HatSteps<0>::run(st, o, buf + dst.o0, buf + dst.o1);
+    HatSteps<0, HatStoreF32<128>>::run(st, o, store);
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -443,7 +452,8 @@ template <int ROW>
 __device__ __forceinline__ void hat_body_linear(HatState& st, float* img, const GatherDst& dst)
 {
     f32x2 o[8];
-    HatSteps<0, ROW>::run(st, o, img + dst.o0, img + dst.o1);
+    const HatStoreF32<ROW> store = {{img + dst.o0, img + dst.o1}};
+    HatSteps<0, HatStoreF32<ROW>>::run(st, o, store);
 }
 
 }  // namespace ahv

@@ -126,9 +126,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         stage_w1_table(lds_w1, W1, tid, kDualThreads);
     }
     DualFrags f0;
-    load_dual_frags(f0, W2, b2, lane);
+    if (!SPLIT) load_dual_frags(f0, W2, b2, lane);
     const GatherLane glane = gather_lane(lane);
     const GatherDst gdst = gather_dst_swizzled(lane);
+    const SplitDst sdst = split_dst(lane);
     const long hstep = (long)gridDim.x * 8;
     // Diagnostic entry point only (clk != NULL): shader-clock and 100 MHz real-time stamps around this
     // workgroup's whole hypothesis loop.  The stamps go to `clk` alone; no output depends on them.
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         __syncthreads();
         DualFrags f = f0;
         if (SPLIT) {
+            load_dual_frags(f, W2, b2, lane);  // re-read per sample: keeping an unscaled copy costs 16 registers the gather needs
             const int v_exp = stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid);
             const float unscale = ldexpf(1.0f, -(w1_exp + v_exp));  // exact; relu commutes with it
 #pragma unroll
@@ -220,14 +222,21 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             if constexpr (SPLIT) {
                 char* cbuf = reinterpret_cast<char*>(buf);
                 const f16x8* w1s = reinterpret_cast<const f16x8*>(lds_w1);
-                tri_quarter_split<0>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(1)
-                gemm1_quarter_split<0>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(2)
-                tri_quarter_split<1>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(3)
-                gemm1_quarter_split<1>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(4)
-                tri_quarter_split<2>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(5)
-                gemm1_quarter_split<2>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(6)
-                tri_quarter_split<3>(cbuf, srcT, Rm, lane); wave_lds_fence(); AHV_TS(7)
-                gemm1_quarter_split<3>(acc, w1s, cbuf, lane); wave_lds_fence(); AHV_TS(8)
+                GatherHyp gh;
+                gather_hyp(gh, Rm, glane);
+                HatState st;
+                hat_prologue<0>(st, srcT, gh);
+                hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(1)
+                gemm1_quarter_split<0>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(2)
+                hat_prologue<1>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
+                hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(3)
+                gemm1_quarter_split<1>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(4)
+                hat_prologue<2>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
+                hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(5)
+                gemm1_quarter_split<2>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(6)
+                hat_prologue<3>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
+                hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(7)
+                gemm1_quarter_split<3>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             } else {
                 // gather quarter q (16 blend steps) -> GEMM1 on it; the head of quarter q+1's gather (coordinates,
                 // weights, first row requests) is issued from inside GEMM q, ahead of its last MFMA chunks

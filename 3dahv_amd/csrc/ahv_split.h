@@ -114,38 +114,61 @@ __device__ __forceinline__ unsigned pk_rtz(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-template <int Q>
-__device__ __forceinline__ void tri_quarter_split(char* img, const float* srcT, const float* Rm, int lane)
+// The gather is the fp32 kernel's (ahv_dual.h: hat weights on a clamped base row, one base address per voxel, a
+// request ring six rows deep, the 4 x 2 x 2-box lane map); only the store differs: the sixteen blended channels are
+// split into hi (the top 11 significant bits, exactly an f16 in the normal range) and lo (the rest) and leave as
+// four ds_write_b128.  An 8-lane store group still holds e = 0..7 of one (a0, b) under the box map, so the
+// swizzle found for the x-run map keeps its store behaviour.
+struct SplitDst {
+    int chunk[4];  // byte offsets of [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of the lane's pass-0 voxel (pass 1: + 4096)
+};
+
+__device__ __forceinline__ SplitDst split_dst(int lane)
 {
-    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
-    const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
-    const float z = (2.0f * (2 * Q + a0) + 1.0f) * 0.125f - 1.0f;
-    const int bl = 2 * b1 + b0;
-    char* row = img + (a0 + 2 * e + 16 * bl) * 64;
-    const int s = split_swz(bl, e);  // b = 4p + bl: pass p does not change b & 1
+    const LaneVox lv = lane_vox(lane);
+    SplitDst d;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float y = (2.0f * (4 * p + bl) + 1.0f) * 0.125f - 1.0f;
-        TriCoefP k;
-        tri_coef_ptr(k, srcT, Rm, x, y, z);
-        float o[16];
-        tri_blend_ptr(o, k);
-        unsigned hi[8], lo[8];
+    for (int c = 0; c < 4; ++c) d.chunk[c] = split_addr(lv.a0, lv.bq, lv.e, c);  // b = 4 p + bq: the pass keeps b & 1
+    asm volatile("" : "+v"(d.chunk[0]), "+v"(d.chunk[1]), "+v"(d.chunk[2]), "+v"(d.chunk[3]));
+    return d;
+}
+
+struct HatStoreSplit {
+    char* img;
+    SplitDst d;
+    __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
+    {
+        // eight channels at a time, each half stored before the next is converted: the request ring of the other pass
+        // is live here and sixteen conversion temporaries on top of it do not fit in 256 registers
+        char* dst = img + p * (64 * 64);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // hi = the top 11 significant bits (exactly an f16 in the normal range), lo = the rest.
-            const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[2 * i]) & 0xFFFFE000u);
-            const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[2 * i + 1]) & 0xFFFFE000u);
-            hi[i] = pk_rtz(h0, h1);
-            lo[i] = pk_rtz(o[2 * i] - h0, o[2 * i + 1] - h1);
+        for (int half = 0; half < 2; ++half) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // scalars first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this
+                // hipcc (ROCm 7.2) whatever the index
+                const float x0 = o[4 * half + i][0], x1 = o[4 * half + i][1];
+                const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xFFFFE000u);
+                const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xFFFFE000u);
+                hi[i] = pk_rtz(h0, h1);
+                lo[i] = pk_rtz(x0 - h0, x1 - h1);
+            }
+            *reinterpret_cast<u32x4*>(dst + d.chunk[half]) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(dst + d.chunk[2 + half]) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            __builtin_amdgcn_sched_barrier(0);
         }
-        char* dst = row + p * (64 * 64);
-        *reinterpret_cast<u32x4*>(dst + ((0 ^ s) << 4)) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-        *reinterpret_cast<u32x4*>(dst + ((1 ^ s) << 4)) = u32x4{hi[4], hi[5], hi[6], hi[7]};
-        *reinterpret_cast<u32x4*>(dst + ((2 ^ s) << 4)) = u32x4{lo[0], lo[1], lo[2], lo[3]};
-        *reinterpret_cast<u32x4*>(dst + ((3 ^ s) << 4)) = u32x4{lo[4], lo[5], lo[6], lo[7]};
-        __builtin_amdgcn_sched_barrier(0);  // keep the second pass's 32 row loads out of the first pass
     }
+};
+
+// the 16 blend steps of a quarter whose prologue (hat_prologue, ahv_dual.h) has been issued
+__device__ __forceinline__ void hat_body_split(HatState& st, char* img, const SplitDst& dst)
+{
+    f32x2 o[8];
+    const HatStoreSplit store = {img, dst};
+    __builtin_amdgcn_s_setprio(1);
+    HatSteps<0, HatStoreSplit>::run(st, o, store);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- GEMM1 on one quarter: 72 x v_mfma_f32_16x16x32_f16 -----------------------------------------
@@ -190,8 +213,10 @@ __device__ __forceinline__ void split_mfma(f32x4 (&acc)[2][4], const SplitStep& 
 // Twelve k-steps, software-pipelined by hand one step deep: the operands of step S+1 are requested before
 // the six MFMAs of step S are issued, and sched_barrier keeps the compiler from hoisting every load of the
 // quarter to the top (which costs ~100 registers and spills).
-template <int Q>
-__device__ __forceinline__ void gemm1_quarter_split(f32x4 (&acc)[2][4], const f16x8* table, const char* img, int lane)
+// `hook` runs once, ahead of the MFMAs of step 8 (the next quarter's gather prologue, as in gemm1_quarter_pipe).
+template <int Q, typename Hook>
+__device__ __forceinline__ void gemm1_quarter_split(f32x4 (&acc)[2][4], const f16x8* table, const char* img, int lane,
+                                                    Hook hook)
 {
     const int n = lane & 15, kq = lane >> 4;
     const int i0 = n >> 3, j = n & 7, kh = kq >> 1, kc = kq & 1;
@@ -205,6 +230,7 @@ __device__ __forceinline__ void gemm1_quarter_split(f32x4 (&acc)[2][4], const f1
     __builtin_amdgcn_sched_barrier(0);                               \
     if (S + 2 < 12) split_load<Q, (S + 2 < 12 ? S + 2 : 0)>(s0, T, img, i0, j, kh, kc); \
     if (S + 2 == 8) { az[0] = s0.a[0]; az[1] = s0.a[1]; az[2] = s0.a[2]; az[3] = s0.a[3]; } \
+    if (S == 8) hook();                                              \
     __builtin_amdgcn_sched_barrier(0);                               \
     split_mfma<Q, S + 1>(acc, s1, az);                               \
     __builtin_amdgcn_sched_barrier(0);

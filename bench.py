@@ -36,6 +36,8 @@ FLOPS_PER_HYP = 1_839_104      # trilinear 131072 + GEMM
 HBM_BYTES_PER_HYP = 36         # the timed launch keeps only the arg-max (want_scores=False): 36 B of R in
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (at the 2.4 GHz maximum clock)
 MAX_CLOCK_GHZ = 2.4
+PEAK_LDS_TBPS = 256 * 256 * 2.4e9 / 1e12   # 157.3: 256 B/clk/CU (ds_read_b128), 256 CUs, 2.4 GHz
+SPLIT_LDS_BYTES_PER_HYP = 262144 + 32768 + 98304 + 147456 + 8192   # split-f16 kernel, see its lds_roofline entry
 TRAFFIC_JSON = os.path.join("profiles", "traffic.json")
 
 
@@ -411,7 +413,18 @@ def worker(args):
                         "operands, f32 accumulate",
                 "kernel_ms": ms4, "hypotheses_per_s_kernel_only": N_HYP / (ms4 * 1e-3),
                 "max_abs_score_diff_vs_f32_kernel": float((s4 - scores).abs().max().item()),
-                "same_argmax": bool(torch.equal(ops.unpack_best(k4)[1], ops.unpack_best(key)[1]))}
+                "same_argmax": bool(torch.equal(ops.unpack_best(k4)[1], ops.unpack_best(key)[1])),
+                # its real roof is the LDS, not the f16 matrix pipe (288 f16 MFMAs per hypothesis ~ 15 % of the time):
+                # bytes one hypothesis moves through the LDS in this formulation / the guide's LDS rate
+                "lds_roofline": {"bound": "lds", "bytes_per_hypothesis": SPLIT_LDS_BYTES_PER_HYP,
+                                 "bytes_breakdown": "gather 8 voxels x 8 corners x 4 ds_read_b128 per lane 262144 + image "
+                                                    "stores 32768 + B fragments 98304 + W1 fragments 147456 + target 8192",
+                                 "achieved": SPLIT_LDS_BYTES_PER_HYP * N_HYP / (ms4 * 1e-3) / 1e12,
+                                 "peak": PEAK_LDS_TBPS, "unit": "TB/s",
+                                 "frac": SPLIT_LDS_BYTES_PER_HYP * N_HYP / (ms4 * 1e-3) / 1e12 / PEAK_LDS_TBPS,
+                                 "note": "peak = 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS); bank "
+                                         "conflicts of the rotated gather (1.64 LDS cycles per conflict-free cycle, "
+                                         "simulated and measured) are inside the achieved figure"}}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_scores = cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R)
             res["cpu_baseline"] = cb

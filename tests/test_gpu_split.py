@@ -148,3 +148,43 @@ def test_split_selector_is_per_call_and_per_context(ops, ahv, dev):
     rc = lib.ahv_score_hypotheses_f32(vs.data_ptr(), ft.data_ptr(), R.data_ptr(), 0, 0, W1.data_ptr(), W2.data_ptr(),
                                       b2.data_ptr(), 1, 128, None, key.data_ptr(), 4, None)
     assert rc == -1 and b"unknown flags" in lib.ahv_last_error()
+
+
+def _golden_inputs(dev):
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return g128, [t(g128[k]) for k in ("vol_src", "vol_tgt", "W1", "W2", "b2")]
+
+
+def test_split_n50k_config2_digest(ops, ahv, dev):
+    """The reference-generated digest of BASELINE.json configs[1] (N = 50 000: arg-max index, top-16 order, every
+    97th score) through the split-f16 kernel: same bar as the fp32 kernel (tests/test_gpu_parity.py)."""
+    import hashlib
+    g = load_golden("score_n50k_digest")
+    g128, (vs, vt, W1, W2, b2) = _golden_inputs(dev)
+    Rn = ahv.rotations.haar_rotations_np(int(g["n"]), int(g["seed"]))
+    assert hashlib.sha256(Rn.tobytes()).hexdigest() == str(g["R_sha256"])
+    R = torch.from_numpy(Rn).to(dev)
+    s4, i4 = scores_with(ops, None, 4, vs, vt, R, W1, W2, b2)
+    s32, i32 = scores_with(ops, None, 3, vs, vt, R, W1, W2, b2)
+    s = s4[0].cpu().numpy()
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-2)))
+    assert i4.item() == int(g["best_idx"][0]) == i32.item()               # bit-exact arg-max
+    assert rel(s[::97], g["every97_score"]) < 1e-4 and rel(s[g["top16_idx"]], g["top16_score"]) < 1e-4
+    assert list(np.argsort(-s, kind="stable")[:16]) == list(g["top16_idx"])
+    assert (s4 - s32).abs().max().item() < 1e-6
+    # arg-max-only launch returns the same key
+    ft = ops.forward_3d2d(vt, W1, W2, b2)
+    _, k_only = ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False, split_f16=True)
+    assert ops.unpack_best(k_only)[1].item() == i4.item()
+
+
+def test_split_edge_rotations(ops, dev):
+    """The 33 edge rotations (identity, the 24 cube rotations, 45-degree turns, a non-orthonormal matrix, 0.5 I and
+    2 I: zeros padding and out-of-range coordinates) through the split-f16 kernel."""
+    g = load_golden("edge_rotations")
+    _, (vs, vt, W1, W2, b2) = _golden_inputs(dev)
+    R = torch.from_numpy(np.ascontiguousarray(g["R"])).to(dev)
+    s4, i4 = scores_with(ops, None, 4, vs, vt, R, W1, W2, b2)
+    assert np.max(np.abs(s4.cpu().numpy() - g["scores"])) < 2e-6
+    assert i4.item() == int(g["best_idx"][0])
