@@ -307,3 +307,39 @@ def test_graphed_train_step_matches_eager(ahv, dev):
     cos = torch.nn.functional.cosine_similarity(up1, up2, dim=0).item()
     assert cos > 0.999 and up1.abs().max().item() > 1e-5, cos
     assert (up1 - up2).abs().max().item() < 6e-4
+
+
+def test_backward_at_the_co3d_training_size(ops, ahv, dev):
+    """The reference's CO3D training size (train_estimator_co3d.py:12-15: NUM_ROTA = 9000, BS = 32; per-sample
+    rotation sets, modules/model_co3d.py:41-61): 288 000 hypotheses forward + backward in one call.
+      * workspace = the size the ABI reports (2.36 GB: 8 KiB of dL/du per hypothesis);
+      * a 2 x 1100 sub-problem EMBEDDED in the batch (samples 5 and 17, hypotheses 3000..4099; dL/dscore = 0
+        everywhere else) meets the kink-aware fp64 reference, and samples without upstream gradient get exact zeros;
+      * with dL/dscore on all 288 000 hypotheses the gradients are finite and ADDITIVE over a split of the hypothesis
+        axis (the 64-bit fixed-point image of dV and its per-sample headroom guard at 9000 hypotheses per sample)."""
+    B, N = 32, 9000
+    lib = ahv._lib.load()
+    cu = lib.ahv_device_cu_count()
+    assert lib.ahv_score_hypotheses_backward_workspace_bytes(B, N) == 4 * (2048 * B * N + 4 + cu * 32 * 384)
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, B, N, True, 77)
+    sub_b, lo, hi = [5, 17], 3000, 4100
+    gsub = torch.zeros_like(gs)
+    for b in sub_b:
+        gsub[b, lo:hi] = gs[b, lo:hi]
+    got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gsub)
+    others = [b for b in range(B) if b not in sub_b]
+    assert got[0][others].abs().max().item() == 0.0 and got[1][others].abs().max().item() == 0.0
+    sub = (got[0][sub_b], got[1][sub_b], got[2], got[3], got[4])
+    errs, n_amb, combo = kink_aware_errors(sub, vs[sub_b], ft[sub_b], R[sub_b][:, lo:hi].contiguous(), W1, W2, b2,
+                                           gs[sub_b][:, lo:hi].contiguous())
+    print("embedded 2 x 1100:", ["%.1e" % e for e in errs], "near-kink:", n_amb, "flipped:", combo)
+    assert max(errs) < GRAD_RTOL, (errs, n_amb)
+    # every hypothesis carries gradient: finite, and the sum of the two half-batches of hypotheses
+    full = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    assert all(torch.isfinite(g).all().item() for g in full)
+    half = N // 2
+    ga = ops.score_hypotheses_backward(vs, ft, R[:, :half].contiguous(), W1, W2, b2, gs[:, :half].contiguous())
+    gb = ops.score_hypotheses_backward(vs, ft, R[:, half:].contiguous(), W1, W2, b2, gs[:, half:].contiguous())
+    for name, f, a, b_ in zip(["vol_src", "feat_tgt", "W1", "W2", "b2"], full, ga, gb):
+        err = relerr(f, (a.double() + b_.double()))
+        assert err < 2e-5, (name, err)     # fp32 accumulation order differs between one pass and two

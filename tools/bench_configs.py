@@ -189,6 +189,27 @@ if not only or "train" in only:
                       "hip_bwd_only_ms": ms_bwd, "torch_autograd_ms": ms_torch, "speedup": ms_torch / ms_hip,
                       "max_rel_grad_diff_vs_torch_fp32": rel, "hyp_per_s_fwd_bwd": B * N / ms_hip * 1e3}))
 
+if "train9000" in only:
+    # the reference's CO3D training size (train_estimator_co3d.py:12-15: NUM_ROTA = 9000, BS = 32): 288 000 hypothesis
+    # evaluations forward + backward per step, per-sample rotation sets; HIP kernels only (the all-torch graph needs
+    # ~37 GB of activations at this size)
+    B, N = 32, 9000
+    g9 = torch.Generator().manual_seed(9)
+    vs9 = (torch.randn(B, 16, 8, 8, 8, generator=g9) * 1.15).to(dev)
+    vt9 = (torch.randn(B, 16, 8, 8, 8, generator=g9) * 1.15).to(dev)
+    R9 = ops.random_rotations(B * N, seed=9, device=dev).reshape(B, N, 3, 3)
+    gs9 = torch.randn(B, N, generator=g9).to(dev)
+    ft9 = ops.forward_3d2d(vt9, W1, W2, b2)
+    lib = ahv._lib.load()
+    ms_fwd = timeit(lambda: ops.score_hypotheses(vs9, ft9, R9, W1, W2, b2), 5)
+    ms_bwd = timeit(lambda: ops.score_hypotheses_backward(vs9, ft9, R9, W1, W2, b2, gs9), 5)
+    FLOPS_BWD = 5.4e6  # algorithmic work of the backward per hypothesis
+    print(json.dumps({"config": "training scorer step, CO3D training size", "B": B, "N": N, "hip_fwd_only_ms": ms_fwd,
+                      "hip_bwd_only_ms": ms_bwd, "hyp_per_s_fwd_bwd": B * N / (ms_fwd + ms_bwd) * 1e3,
+                      "fwd_frac_fp32_mfma_peak": B * N * FLOPS / ms_fwd / 1e9 / 157.3,
+                      "bwd_tflops": B * N * FLOPS_BWD / ms_bwd / 1e9,
+                      "backward_workspace_GB": lib.ahv_score_hypotheses_backward_workspace_bytes(B, N) / 1e9}))
+
 if not only or "trainstep" in only:
     # whole training_step (modules/model_co3d.py:71-91) at the reference's batch: where the time goes
     cfg = {"RUN_NAME": "t", "DATA": {"NUM_ROTA": 3000, "BG": True, "SIZE_THR": 25, "OBJ_SIZE": 256, "ACC_THR": 30, "VIEW_THR": 90},

@@ -9,3 +9,4 @@ timeout 900 hipcc $F -DAHV_STAMPS tools/kbench.cpp -o tools/kbench_stamps
 timeout 900 hipcc $F -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_lin
 timeout 900 hipcc $F -DAHV_STAMPS -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_stamps_lin
 timeout 900 hipcc $F -DAHV_PK_WEIGHTS tools/kbench.cpp -o tools/kbench_pkw
+timeout 900 hipcc $F tools/kbench_bwd.cpp -o tools/kbench_bwd
