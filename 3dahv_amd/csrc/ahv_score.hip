@@ -78,6 +78,7 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
 __device__ unsigned long long g_stamps[2048 * 16];
 // per workgroup: 100 MHz real-time stamps at kernel entry, hypothesis-loop start and end, and the XCC id
 __device__ unsigned long long g_wgstamps[1024 * 4];
+__device__ unsigned long long g_wgclk[1024 * 2];  // s_memtime at loop start / end of the same workgroups
 #define AHV_STAMP(var)                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #endif
 #ifdef AHV_STAMPS
         wg_t_loop = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wg_c_loop = __builtin_amdgcn_s_memtime();
 #endif
         unsigned long long best = 0ull;
         const float* Rb = R + (long)b * r_batch_stride;
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             o[1] = wg_t_loop;
             o[2] = __builtin_amdgcn_s_memrealtime();
             o[3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20);  // HW_REG_XCC_ID, bits 3:0
+            g_wgclk[2 * (blockIdx.x & 1023)] = wg_c_loop;
+            g_wgclk[2 * (blockIdx.x & 1023) + 1] = __builtin_amdgcn_s_memtime();
         }
 #endif
     }

@@ -106,6 +106,14 @@ int main(int argc, char** argv)
     }
     printf("  workgroups %d: first entry -> last exit %.1f us; mean entry delay %.1f us, prologue %.1f us, loop %.1f us, idle at the end %.1f us\n",
            nwg, (t1 - t0) * 0.01, entry / nwg, pro / nwg, loop / nwg, idle / nwg);
+    {   // shader clock held during the loop: s_memtime ticks per 10-ns real-time tick, median over workgroups
+        std::vector<unsigned long long> ck(1024 * 2);
+        CK(hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(ahv::g_wgclk), ck.size() * 8));
+        std::vector<double> ghz;
+        for (int w = 0; w < 1024; ++w) if (wg[4 * w + 2] > wg[4 * w + 1]) ghz.push_back((double)(ck[2 * w + 1] - ck[2 * w]) / (double)(wg[4 * w + 2] - wg[4 * w + 1]) * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty()) printf("  shader clock during the loop (s_memtime / s_memrealtime): median %.3f GHz, min %.3f, max %.3f\n", ghz[ghz.size() / 2], ghz.front(), ghz.back());
+    }
     for (int x = 0; x < 16; ++x) if (xn[x]) printf("    XCC %d: %d workgroups, mean loop %.1f us, mean idle at the end %.1f us\n", x, xn[x], xs[x] / xn[x], xe[x] / xn[x]);
 #endif
     return 0;
