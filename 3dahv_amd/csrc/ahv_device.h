@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ahv_lds.h"
+
 namespace ahv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -259,29 +259,30 @@ __device__ __forceinline__ GatherLane gather_lane(int lane)
 struct GatherHyp {
     f32x2 ixy[2];  // [pass]: (x, y) sample coordinates of the lane's voxel in quarter 0 (a register pair: v_pk_* operands)
     f32x2 dqxy;    // per-quarter increment 2 R[axis][2] of x and y
-    float iz[2];   // the same for z
+    f32x2 izp;     // z of pass 0 and pass 1 (a pair too: the two voxels of a lane are set up together)
     float dqz;
 };
 
 __device__ __forceinline__ void gather_hyp(GatherHyp& h, const float* Rm, const GatherLane& g)
 {
-    float i0[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-        i0[a] = fmaf(Rm[3 * a + 0], g.x4, fmaf(Rm[3 * a + 1], g.y4, fmaf(Rm[3 * a + 2], g.z4, 3.5f)));
-    h.ixy[0] = f32x2{i0[0], i0[1]};
-    h.ixy[1] = f32x2{fmaf(4.0f, Rm[1], i0[0]), fmaf(4.0f, Rm[4], i0[1])};
-    h.dqxy = f32x2{2.0f * Rm[2], 2.0f * Rm[5]};
-    h.iz[0] = i0[2];
-    h.iz[1] = fmaf(4.0f, Rm[7], i0[2]);
-    h.dqz = 2.0f * Rm[8];
+    // x and y as one packed chain (rows 0 and 1 of R), z on its own
+    const f32x2 i0xy = __builtin_elementwise_fma(
+        f32x2{Rm[0], Rm[3]}, f32x2{g.x4, g.x4},
+        __builtin_elementwise_fma(f32x2{Rm[1], Rm[4]}, f32x2{g.y4, g.y4},
+                                  __builtin_elementwise_fma(f32x2{Rm[2], Rm[5]}, f32x2{g.z4, g.z4}, f32x2{3.5f, 3.5f})));
+    const float i0z = fmaf(Rm[6], g.x4, fmaf(Rm[7], g.y4, fmaf(Rm[8], g.z4, 3.5f)));
+    h.ixy[0] = i0xy;
+    h.ixy[1] = __builtin_elementwise_fma(f32x2{4.0f, 4.0f}, f32x2{Rm[1], Rm[4]}, i0xy);
+    h.dqxy = f32x2{Rm[2], Rm[5]} + f32x2{Rm[2], Rm[5]};
+    h.izp = f32x2{i0z, fmaf(4.0f, Rm[7], i0z)};
+    h.dqz = Rm[8] + Rm[8];
 }
 
 // sample coordinate of the lane's voxel (pass p of quarter Q) along axis a (0 = x, 1 = y, 2 = z)
 template <int Q>
 __device__ __forceinline__ float gather_coord(const GatherHyp& h, int a, int p)
 {
-    return a == 2 ? fmaf((float)Q, h.dqz, h.iz[p]) : fmaf((float)Q, h.dqxy[a], h.ixy[p][a]);
+    return a == 2 ? fmaf((float)Q, h.dqz, h.izp[p]) : fmaf((float)Q, h.dqxy[a], h.ixy[p][a]);
 }
 
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
@@ -321,7 +322,7 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
     wy0 = clamp01(1.0f - fabsf(uxy[1]));
     wx1 = clamp01(1.0f - fabsf(txy[0]));
     wy1 = clamp01(1.0f - fabsf(txy[1]));
-    hat_axis(Q == 0 ? h.iz[p] : fmaf((float)Q, h.dqz, h.iz[p]), jz, wz0, wz1);
+    hat_axis(Q == 0 ? h.izp[p] : fmaf((float)Q, h.dqz, h.izp[p]), jz, wz0, wz1);
 #ifndef AHV_SCALAR_WEIGHTS  // A/B knob of tools/kbench: measured 0.7081 -> 0.7033 ms per 50 000 hypotheses
     // the outer product of the three weight pairs on v_pk_mul_f32 (6 instead of 12 multiplications, same products)
     const f32x2 wy = {wy0, wy1}, wx = {wx0, wx1};
@@ -341,6 +342,45 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
 #ifdef AHV_DIAG_LINEAR_GATHER  // diagnostic only (wrong results): row = lane, so every b128 lane group of every corner
     // request covers the 16 slots once -- the conflict-free bound of the gather (tools/kbench, profiles/r03_scorer_segments.txt)
     v.base = reinterpret_cast<const char*>(srcT) + (threadIdx.x & 63) * (4 * kSrcStride);
+#endif
+}
+
+// Both voxels of a lane (pass 0, pass 1) at once: x / y stay packed over the axes, and what is per-voxel scalar work in
+// hat_voxel -- the z coordinate, its offset and offset - 1, and the row address -- is packed over the two passes
+// (3 + 3 instructions per pair instead of per voxel).  Same arithmetic per element as hat_voxel.
+template <int Q>
+__device__ __forceinline__ void hat_voxel_pair(HatVoxel& v0, HatVoxel& v1, const float* srcT, const GatherHyp& h)
+{
+    const f32x2 qq = {(float)Q, (float)Q};
+    const f32x2 ia = Q == 0 ? h.ixy[0] : __builtin_elementwise_fma(qq, h.dqxy, h.ixy[0]);
+    const f32x2 ib = Q == 0 ? h.ixy[1] : __builtin_elementwise_fma(qq, h.dqxy, h.ixy[1]);
+    const f32x2 iz = Q == 0 ? h.izp : __builtin_elementwise_fma(qq, f32x2{h.dqz, h.dqz}, h.izp);
+    const float jxa = __builtin_amdgcn_fmed3f(floorf(ia[0]), 0.0f, 6.0f), jya = __builtin_amdgcn_fmed3f(floorf(ia[1]), 0.0f, 6.0f);
+    const float jxb = __builtin_amdgcn_fmed3f(floorf(ib[0]), 0.0f, 6.0f), jyb = __builtin_amdgcn_fmed3f(floorf(ib[1]), 0.0f, 6.0f);
+    const float jza = __builtin_amdgcn_fmed3f(floorf(iz[0]), 0.0f, 6.0f), jzb = __builtin_amdgcn_fmed3f(floorf(iz[1]), 0.0f, 6.0f);
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 ua = ia - f32x2{jxa, jya}, ub = ib - f32x2{jxb, jyb}, uz = iz - f32x2{jza, jzb};
+    const f32x2 ta = ua - one, tb = ub - one, tz = uz - one;
+    auto weights = [](HatVoxel& v, float ux, float uy, float uzz, float tx, float ty, float tzz) {
+        const float wx0 = clamp01(1.0f - fabsf(ux)), wy0 = clamp01(1.0f - fabsf(uy)), wz0 = clamp01(1.0f - fabsf(uzz));
+        const float wx1 = clamp01(1.0f - fabsf(tx)), wy1 = clamp01(1.0f - fabsf(ty)), wz1 = clamp01(1.0f - fabsf(tzz));
+        const f32x2 wy = {wy0, wy1}, wx = {wx0, wx1};
+        const f32x2 w0y = wz0 * wy, w1y = wz1 * wy;
+        const f32x2 a = w0y[0] * wx, b = w0y[1] * wx, c = w1y[0] * wx, d = w1y[1] * wx;
+        v.w[0] = a[0]; v.w[1] = a[1]; v.w[2] = b[0]; v.w[3] = b[1];
+        v.w[4] = c[0]; v.w[5] = c[1]; v.w[6] = d[0]; v.w[7] = d[1];
+    };
+    weights(v0, ua[0], ua[1], uz[0], ta[0], ta[1], tz[0]);
+    weights(v1, ub[0], ub[1], uz[1], tb[0], tb[1], tz[1]);
+    // byte offsets of the two rows (jz, jy, jx): exact in fp32 (< 2^24)
+    const f32x2 af = __builtin_elementwise_fma(
+        f32x2{jza, jzb}, f32x2{(float)(4 * kSrcPlaneRows * kSrcStride), (float)(4 * kSrcPlaneRows * kSrcStride)},
+        __builtin_elementwise_fma(f32x2{jya, jyb}, f32x2{(float)(4 * kSrcRowsY * kSrcStride), (float)(4 * kSrcRowsY * kSrcStride)},
+                                  f32x2{jxa, jxb} * f32x2{(float)(4 * kSrcStride), (float)(4 * kSrcStride)}));
+    v0.base = reinterpret_cast<const char*>(srcT) + (unsigned)af[0];
+    v1.base = reinterpret_cast<const char*>(srcT) + (unsigned)af[1];
+#ifdef AHV_DIAG_LINEAR_GATHER
+    v0.base = v1.base = reinterpret_cast<const char*>(srcT) + (threadIdx.x & 63) * (4 * kSrcStride);
 #endif
 }
 
@@ -385,9 +425,14 @@ struct HatRequests<END, END> {
 template <int Q>
 __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
 {
+#ifdef AHV_HAT_SINGLE_VOXELS  // A/B knob of tools/kbench: the two voxels set up one after the other
     hat_voxel<Q>(st.vx[0], srcT, h, 0);
     HatRequests<0, kHatDepth>::run(st);
     hat_voxel<Q>(st.vx[1], srcT, h, 1);
+#else
+    hat_voxel_pair<Q>(st.vx[0], st.vx[1], srcT, h);
+    HatRequests<0, kHatDepth>::run(st);
+#endif
 }
 
 // Where a blended voxel goes.  ROW = floats between the channel planes of the destination image (128: the

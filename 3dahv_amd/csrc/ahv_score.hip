@@ -67,7 +67,14 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
     // same one level down: rows of 16 lanes, odd rows keep the second tile of their pair
     const float s1 = swap_add16(s2[0], s2[1]);
     const float d1 = swap_add16(d2[0], d2[1]);
+    // <v, tg> / max(|v|, 1e-12) (F.normalize's eps) as <v, tg> * rsq(max(|v|^2, 1e-24)): v_max + v_rsq + v_mul instead of a
+    // correctly rounded sqrt and an IEEE division (~20 instructions of scaling and fix-up); v_rsq_f32 is good to 1 ulp,
+    // the cosine to ~2e-7 relative, three orders inside the parity bar
+#ifdef AHV_NO_RSQ
     const float c = d1 / fmaxf(sqrtf(s1), 1e-12f);
+#else
+    const float c = d1 * __builtin_amdgcn_rsqf(fmaxf(s1, 1e-24f));
+#endif
     const float tot = wave_sum_dpp(c);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63)) * (1.0f / 64.0f);
 }
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     float* buf = lds_q + wave * kQuarterFloats;
 
     static_assert(kSplitTableBytes == sizeof(float) * kW1TableFloats && kSplitImageBytes == sizeof(float) * kQuarterFloats, "LDS budget");
+
 #ifdef AHV_STAMPS
     const unsigned long long wg_t_entry = __builtin_amdgcn_s_memrealtime();
     unsigned long long wg_t_loop = 0;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             f32x4 x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = ft[(16 * m2 + 4 * (l >> 4) + r) * 64 + 16 * t + (l & 15)];
-            *reinterpret_cast<f32x4*>(lds_src + tid * kSrcStride + 16) = x;
+            lds_store128(lds_src + tid * kSrcStride + 16, x);
         }
         __syncthreads();
 

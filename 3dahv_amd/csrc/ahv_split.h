@@ -75,7 +75,7 @@ __device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __rest
             const _Float16 hi = (_Float16)x;
             v[j] = part ? (_Float16)(x - (float)hi) : hi;
         }
-        table[i] = v;
+        lds_store128(table + i, v);  // the next iteration's conversions reuse v's registers (ahv_lds.h)
     }
 }
 
@@ -154,8 +154,9 @@ struct HatStoreSplit {
                 hi[i] = pk_rtz(h0, h1);
                 lo[i] = pk_rtz(x0 - h0, x1 - h1);
             }
-            *reinterpret_cast<u32x4*>(dst + d.chunk[half]) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-            *reinterpret_cast<u32x4*>(dst + d.chunk[2 + half]) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            // lds_store128: the next half's conversions reuse these registers at once (ahv_lds.h)
+            lds_store128(dst + d.chunk[half], u32x4{hi[0], hi[1], hi[2], hi[3]});
+            lds_store128(dst + d.chunk[2 + half], u32x4{lo[0], lo[1], lo[2], lo[3]});
             __builtin_amdgcn_sched_barrier(0);
         }
     }

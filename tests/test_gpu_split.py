@@ -188,3 +188,33 @@ def test_split_edge_rotations(ops, dev):
     s4, i4 = scores_with(ops, None, 4, vs, vt, R, W1, W2, b2)
     assert np.max(np.abs(s4.cpu().numpy() - g["scores"])) < 2e-6
     assert i4.item() == int(g["best_idx"][0])
+
+
+def test_split_first_launches_in_a_fresh_process():
+    """Regression for the LDS store-data hazard of gfx950 (3dahv_amd/csrc/ahv_lds.h): a VALU write to the data registers
+    of a ds_write_b128 within two wait states of the store reached the LDS instead of the stored value.  It showed only
+    in the FIRST launches of a process (low clock), on the younger wave of each SIMD, in round 0: ~1 % of the scores of
+    the split-f16 kernel came out 1e-3 off, and nothing after a few launches.  So: a fresh process, the split kernel
+    first, three launches, every score against the fp32 kernel."""
+    import os
+    import subprocess
+    import sys
+    from .conftest import REPO
+    code = r'''
+import importlib, numpy as np, torch, sys
+sys.path.insert(0, %r)
+ahv = importlib.import_module("3dahv_amd"); ops = ahv.ops
+g = np.load(%r)
+dev = torch.device("cuda:0"); T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+vs, vt, W1, W2, b2 = [T(g[k]) for k in ("vol_src", "vol_tgt", "W1", "W2", "b2")]
+ft = ops.forward_3d2d(vt, W1, W2, b2)
+R = T(ahv.rotations.haar_rotations_np(4096, 1))
+runs = [ops.score_hypotheses(vs, ft, R, W1, W2, b2, split_f16=True)[0].clone() for _ in range(3)]
+ref = ops.score_hypotheses(vs, ft, R, W1, W2, b2)[0]
+print("MAXERR", max(float((s - ref).abs().max()) for s in runs))
+''' % (REPO, os.path.join(REPO, "tests", "golden", "score_n128.npz"))
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert out.returncode == 0, out.stderr[-2000:]
+        err = float([l for l in out.stdout.splitlines() if l.startswith("MAXERR")][0].split()[1])
+        assert err < 1e-6, err
