@@ -425,13 +425,14 @@ struct HatRequests<END, END> {
 template <int Q>
 __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
 {
-#ifdef AHV_HAT_SINGLE_VOXELS  // A/B knob of tools/kbench: the two voxels set up one after the other
+#ifdef AHV_HAT_VOXEL_PAIR  // A/B knob of tools/kbench: 24 instructions fewer per hypothesis and SLOWER (0.6911 vs 0.6880 ms
+    // per 50 000 hypotheses, same box): the first six row requests then wait for the set-up of BOTH voxels
+    hat_voxel_pair<Q>(st.vx[0], st.vx[1], srcT, h);
+    HatRequests<0, kHatDepth>::run(st);
+#else
     hat_voxel<Q>(st.vx[0], srcT, h, 0);
     HatRequests<0, kHatDepth>::run(st);
     hat_voxel<Q>(st.vx[1], srcT, h, 1);
-#else
-    hat_voxel_pair<Q>(st.vx[0], st.vx[1], srcT, h);
-    HatRequests<0, kHatDepth>::run(st);
 #endif
 }
 
