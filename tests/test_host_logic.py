@@ -81,3 +81,30 @@ def test_shard_range_partitions(ahv):
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         ahv.dist.shard_range(10, 2, 2)
+
+
+def test_lds_conflict_simulation_backs_the_table_in_ahv_device_h():
+    """tools/lds_conflict_sim.py: the simulated bank-conflict factors quoted in 3dahv_amd/csrc/ahv_device.h (and measured on
+    the GPU: SQ_LDS_BANK_CONFLICT 1 477 -> 684 cycles per hypothesis) -- x-run lane map at (8, 74) rows 2.43, the box map
+    at (9, 76) rows 1.64 -- and the lane -> voxel map itself (a bijection of the quarter, as lane_vox computes it)."""
+    import importlib.util
+    import os
+    import numpy as np
+    from .conftest import REPO
+    spec = importlib.util.spec_from_file_location("lds_conflict_sim", os.path.join(REPO, "tools", "lds_conflict_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    R = sim.haar(300, np.random.default_rng(0))
+    assert abs(sim.factor(sim.lane_map_xrun(), 8, 74, R) - 2.43) < 0.06
+    assert abs(sim.factor(sim.lane_map_box(), 9, 76, R) - 1.64) < 0.06
+    box = sim.lane_map_box()
+    for Q in range(4):
+        vox = {tuple(v) for p in range(2) for v in box[Q, p].astype(int).tolist()}
+        assert vox == {(x, y, z) for x in range(8) for y in range(8) for z in (2 * Q, 2 * Q + 1)}
+    # lane_vox of ahv_dual.h, restated: first-group mask 0x0FF0F00F, rank inside the group by popcount
+    for lane in range(64):
+        l, first = lane & 31, (0x0FF0F00F >> (lane & 31)) & 1
+        mask = (0x0FF0F00F if first else ~0x0FF0F00F & 0xFFFFFFFF) & ((1 << l) - 1)
+        k = bin(mask).count("1")
+        want = ((0 if first else 4) + (k & 3), 2 * (lane >> 5) + ((k >> 2) & 1), k >> 3)
+        assert tuple(box[0, 0, lane].astype(int)) == want, lane
