@@ -197,7 +197,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) own a compact 4 (x) x 2 (y) x 2 (z) block of the quarter, so that
 // after any rotation their source rows form a compact block too (fewest bank conflicts: table in ahv_device.h).
 // Group g = 2 (lane >> 5) + (second group of its half-wave), slot k = rank of the lane inside its group:
-//   x = 4 (g & 1) + (k & 3),  y = 2 (g >> 1) + ((k >> 2) & 1) [+ 4 in pass 1],  z = 2 Q + (k >> 3).
+//   z = 2 Q + (k & 1),  x = 4 (g & 1) + ((k >> 1) & 3),  y = 2 (g >> 1) + (k >> 3) [+ 4 in pass 1].
+// z is the FASTEST bit of k so that 16 contiguous lanes (a ds_write_b64 group) hold both z of their voxels: the split-f16
+// kernel's image stores (ahv_split.h, pairs of ds_write_b64) are then 2-way instead of 4-way bank conflicts.
 // The two groups of a half-wave differ in x bit 2, which keeps the ds_write_b32 of the blended voxels into the
 // XOR-swizzled quarter image (qoff) on 32 distinct banks.
 struct LaneVox {
@@ -211,9 +213,9 @@ __device__ __forceinline__ LaneVox lane_vox(int lane)
     const bool first = (kFirst >> l) & 1u;
     const int k = __builtin_popcount((first ? kFirst : ~kFirst) & ((1u << l) - 1u));  // rank inside the group
     LaneVox v;
-    v.e = (first ? 0 : 4) + (k & 3);
-    v.bq = 2 * (lane >> 5) + ((k >> 2) & 1);
-    v.a0 = k >> 3;
+    v.a0 = k & 1;
+    v.e = (first ? 0 : 4) + ((k >> 1) & 3);
+    v.bq = 2 * (lane >> 5) + (k >> 3);
     return v;
 }
 

@@ -117,8 +117,8 @@ __device__ __forceinline__ unsigned pk_rtz(float a, float b)
 // The gather is the fp32 kernel's (ahv_dual.h: hat weights on a clamped base row, one base address per voxel, a
 // request ring six rows deep, the 4 x 2 x 2-box lane map); only the store differs: the sixteen blended channels are
 // split into hi (the top 11 significant bits, exactly an f16 in the normal range) and lo (the rest) and leave as
-// four ds_write_b128.  An 8-lane store group still holds e = 0..7 of one (a0, b) under the box map, so the
-// swizzle found for the x-run map keeps its store behaviour.
+// 16-byte stores issued as pairs of ds_write_b64 (ahv_lds.h).  A 16-lane store group holds e = 0..7 x a0 = 0..1 of one b
+// under the box map (z is the fastest bit inside a box), so every store is a 2-way bank conflict at worst.
 struct SplitDst {
     int chunk[4];  // byte offsets of [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of the lane's pass-0 voxel (pass 1: + 4096)
 };

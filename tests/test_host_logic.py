@@ -106,5 +106,5 @@ def test_lds_conflict_simulation_backs_the_table_in_ahv_device_h():
         l, first = lane & 31, (0x0FF0F00F >> (lane & 31)) & 1
         mask = (0x0FF0F00F if first else ~0x0FF0F00F & 0xFFFFFFFF) & ((1 << l) - 1)
         k = bin(mask).count("1")
-        want = ((0 if first else 4) + (k & 3), 2 * (lane >> 5) + ((k >> 2) & 1), k >> 3)
+        want = ((0 if first else 4) + ((k >> 1) & 3), 2 * (lane >> 5) + (k >> 3), k & 1)
         assert tuple(box[0, 0, lane].astype(int)) == want, lane

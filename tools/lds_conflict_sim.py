@@ -56,7 +56,7 @@ def lane_map_box():
         for p in range(2):
             for g in range(4):
                 for k, lane in enumerate(GROUPS[g]):
-                    m[Q, p, lane] = (4 * (g & 1) + (k & 3), 2 * (g >> 1) + ((k >> 2) & 1) + 4 * p, 2 * Q + (k >> 3))
+                    m[Q, p, lane] = (4 * (g & 1) + ((k >> 1) & 3), 2 * (g >> 1) + (k >> 3) + 4 * p, 2 * Q + (k & 1))
     return m
 
 
