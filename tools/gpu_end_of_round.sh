@@ -1,20 +1,20 @@
 #!/bin/bash
-# Round-3 GPU pass C (end of round): full tests, bench (driver command + long run), rocprof of bench (trace + PMC),
+# End-of-round GPU pass (through gpurun: bash tools/gpu_end_of_round.sh): full tests, bench (driver command + long run), rocprof of bench (trace + PMC),
 # secondary configs, encoder and training profiles.
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03z
+O=gpurun_out/${1:-eor}
 mkdir -p $O
 echo "== pytest" && timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -4 $O/pytest.log
 echo "== bench 20/5" && timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err; echo rc=$?
 echo "== bench 200/20" && timeout -k 10 600 python3 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_200_20.json 2> $O/bench_200_20.err; echo rc=$?
 echo "== bench forced pg" && AHV_BENCH_FORCE_PG=1 timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_forced_pg.json 2> $O/bench_forced_pg.err; echo rc=$?
-echo "== profile bench" && timeout -k 10 900 bash tools/profile_bench.sh r03c > $O/profile.log 2>&1; echo rc=$?
+echo "== profile bench" && timeout -k 10 900 bash tools/profile_bench.sh ${1:-eor} > $O/profile.log 2>&1; echo rc=$?
 echo "== secondary" && timeout -k 10 600 python3 tools/bench_configs.py 3 4 5 > $O/secondary.jsonl 2> $O/secondary.err; echo rc=$?
 echo "== pairs" && timeout -k 10 600 python3 tools/bench_configs.py pairs > $O/pairs.jsonl 2> $O/pairs.err; echo rc=$?
 echo "== enc" && timeout -k 10 300 python3 tools/bench_configs.py enc enchost > $O/enc.jsonl 2> $O/enc.err; echo rc=$?
 echo "== train" && timeout -k 10 600 python3 tools/bench_configs.py train train9000 > $O/train.jsonl 2> $O/train.err; echo rc=$?
 echo "== kbench_enc" && timeout -k 10 300 tools/kbench_enc.bin 1 --each > $O/enc_marginal.txt 2>&1; echo rc=$?
-echo "== profile train" && timeout -k 10 600 bash tools/profile_train.sh r03 > $O/profile_train.log 2>&1; echo rc=$?
-echo "== profile encoder" && timeout -k 10 600 bash tools/profile_encoder.sh r03 > $O/profile_encoder.log 2>&1; echo rc=$?
+echo "== profile train" && timeout -k 10 600 bash tools/profile_train.sh ${1:-eor} > $O/profile_train.log 2>&1; echo rc=$?
+echo "== profile encoder" && timeout -k 10 600 bash tools/profile_encoder.sh ${1:-eor} > $O/profile_encoder.log 2>&1; echo rc=$?
 echo done
