@@ -314,7 +314,7 @@ __device__ __forceinline__ void store_du_image(float* dbuf, const DuImage& d, in
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
-        lds_store128(dbuf + o * kDuStride + pos, d.v[i]);
+        *reinterpret_cast<f32x4*>(dbuf + o * kDuStride + pos) = d.v[i];
     }
 }
 
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kW1Threads, 2) void score_backward_w1_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // this hypothesis's du rows, requested one iteration ago
                 const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
-                lds_store128(dbuf + o * kDuStride + pos, duh[i]);
+                *reinterpret_cast<f32x4*>(dbuf + o * kDuStride + pos) = duh[i];
             }
             {   // the next hypothesis's travel meanwhile
                 const long hn = (h + hstep < N) ? h + hstep : h;
@@ -775,8 +775,8 @@ __device__ __forceinline__ void bwd_vol_corners(float* ctab, const GatherHyp& h,
         const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
         const float base = fmaf(jz, 64.0f * (kDvRow * 8), fmaf(jy, 8.0f * (kDvRow * 8), jx * (float)(kDvRow * 8)));  // bytes
         float* row = ctab + (p ? dst.o1 : dst.o0) * kCtRow;
-        lds_store128(row + 0, f32x4{w00 * wx0, w00 * wx1, w01 * wx0, w01 * wx1});
-        lds_store128(row + 4, f32x4{w10 * wx0, w10 * wx1, w11 * wx0, w11 * wx1});
+        *reinterpret_cast<f32x4*>(row + 0) = f32x4{w00 * wx0, w00 * wx1, w01 * wx0, w01 * wx1};
+        *reinterpret_cast<f32x4*>(row + 4) = f32x4{w10 * wx0, w10 * wx1, w11 * wx0, w11 * wx1};
         row[8] = __uint_as_float((unsigned)base);
     }
 }

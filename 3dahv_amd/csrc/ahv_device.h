@@ -14,7 +14,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "ahv_lds.h"
 
 namespace ahv {
 

@@ -223,15 +223,17 @@ __device__ __forceinline__ LaneVox lane_vox(int lane)
 // computed ONCE per kernel: passed through an empty asm so that the compiler keeps the two registers instead of
 // re-deriving the lane map inside the hypothesis loop (it did: 12 compares and 15 exec-mask updates per hypothesis).
 struct GatherDst {
-    int o0, o1;
+    int o0, o1;  // pass 0 / pass 1 voxel of the lane
+    int m0, m1;  // pass 0 / pass 1 voxel of the lane in a MIRRORED quarter: (7 - x, 7 - y, 1 - z)
 };
 
 // the forward's XOR-swizzled quarter image (qoff)
 __device__ __forceinline__ GatherDst gather_dst_swizzled(int lane)
 {
     const LaneVox lv = lane_vox(lane);
-    GatherDst d = {qoff(lv.a0, lv.bq, lv.e), qoff(lv.a0, 4 + lv.bq, lv.e)};
-    asm volatile("" : "+v"(d.o0), "+v"(d.o1));
+    GatherDst d = {qoff(lv.a0, lv.bq, lv.e), qoff(lv.a0, 4 + lv.bq, lv.e), qoff(1 - lv.a0, 3 - lv.bq, 7 - lv.e),
+                   qoff(1 - lv.a0, 7 - lv.bq, 7 - lv.e)};
+    asm volatile("" : "+v"(d.o0), "+v"(d.o1), "+v"(d.m0), "+v"(d.m1));
     return d;
 }
 
@@ -239,8 +241,9 @@ __device__ __forceinline__ GatherDst gather_dst_swizzled(int lane)
 __device__ __forceinline__ GatherDst gather_dst_linear(int lane)
 {
     const LaneVox lv = lane_vox(lane);
-    GatherDst d = {lv.a0 * 64 + lv.bq * 8 + lv.e, lv.a0 * 64 + (4 + lv.bq) * 8 + lv.e};
-    asm volatile("" : "+v"(d.o0), "+v"(d.o1));
+    GatherDst d = {lv.a0 * 64 + lv.bq * 8 + lv.e, lv.a0 * 64 + (4 + lv.bq) * 8 + lv.e,
+                   (1 - lv.a0) * 64 + (3 - lv.bq) * 8 + 7 - lv.e, (1 - lv.a0) * 64 + (7 - lv.bq) * 8 + 7 - lv.e};
+    asm volatile("" : "+v"(d.o0), "+v"(d.o1));  // the linear images (backward) do not use the mirrored slots
     return d;
 }
 
@@ -298,6 +301,26 @@ __device__ __forceinline__ void hat_axis(float i, float& jf, float& w0, float& w
     w1 = clamp01(1.0f - fabsf(u - 1.0f));
 }
 
+// A hazard of gfx950 that neither hipcc nor the guides know (found in round 3; profiles/r03_pk_opsel_hazard.txt holds the
+// experiments).  A packed-fp32 VALU instruction whose LOW result lane reads the HIGH half of a source pair -- op_sel:[..1..],
+// which is what hipcc emits to broadcast the odd element of a register pair, e.g. v_pk_fma_f32 o, row, w[2:3] op_sel:[0,1,0] --
+// can lose that operand in lanes 48-63 (the product comes out 0) when an XDL MFMA (v_mfma_f32_16x16x32_f16) of EITHER wave
+// of the SIMD starts on a matrix pipe that has been idle for ~24 cycles or more: an instruction-fetch stall, a branch or an
+// s_nop between two MFMAs is enough.  High lane <- low half (op_sel_hi:[..0..]) and the straight forms are not affected, and
+// neither is a kernel whose MFMAs are all fp32 (v_mfma_f32_16x16x4_f32 does not overlap VALU work at all: bit-identical
+// results with 8..64-cycle gaps forced between its MFMAs).  In the split-f16 scorer this showed up as ~1 % of the first
+// hypotheses of a process' first launch being 1e-3 off -- the cold instruction cache supplies the gaps -- and with gaps forced
+// between the MFMAs as 80 % of all scores wrong.
+// A kernel that issues XDL MFMAs therefore keeps every scalar it broadcasts over a register pair in the LOW half: low_half(x)
+// hides x from hipcc, which then has to hold it in a register of its own and broadcasts it with op_sel_hi:[..0..].
+__device__ __forceinline__ float low_half(float x)
+{
+#ifndef AHV_DIAG_NO_LOW_HALF  // tools/first_launch_sweep.sh builds the unprotected kernel once, to show the hazard itself
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
 // Weights and base row of one voxel (pass p of quarter Q).
 struct HatVoxel {
     float w[8];        // corner weights, order (dz, dy, dx)
@@ -309,7 +332,8 @@ __device__ __forceinline__ constexpr int hat_off(int n)
     return ((n & 1) ? 4 * kSrcStride : 0) + ((n & 2) ? 4 * kSrcRowsY * kSrcStride : 0) + ((n & 4) ? 4 * kSrcPlaneRows * kSrcStride : 0);
 }
 
-template <int Q>
+// XDL: the kernel issues XDL MFMAs (see low_half).
+template <int Q, bool XDL = false>
 __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const GatherHyp& h, int p)
 {
     float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
@@ -329,7 +353,8 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
     // the outer product of the three weight pairs on v_pk_mul_f32 (6 instead of 12 multiplications, same products)
     const f32x2 wy = {wy0, wy1}, wx = {wx0, wx1};
     const f32x2 w0y = wz0 * wy, w1y = wz1 * wy;
-    const f32x2 a = w0y[0] * wx, b = w0y[1] * wx, c = w1y[0] * wx, d = w1y[1] * wx;
+    const float s0 = XDL ? low_half(w0y[1]) : w0y[1], s1 = XDL ? low_half(w1y[1]) : w1y[1];
+    const f32x2 a = w0y[0] * wx, b = s0 * wx, c = w1y[0] * wx, d = s1 * wx;
     v.w[0] = a[0]; v.w[1] = a[1]; v.w[2] = b[0]; v.w[3] = b[1];
     v.w[4] = c[0]; v.w[5] = c[1]; v.w[6] = d[0]; v.w[7] = d[1];
 #else
@@ -403,28 +428,58 @@ struct HatState {
     f32x4 ring[kHatDepth][4];
 };
 
-template <int S>
+// MIR: the quarter being gathered is the point mirror of the one whose voxels st.vx was set up for (hat_mirror below):
+// its pass-p voxel is the mirror of the other quarter's pass-(1 - p) voxel.
+template <int S, bool MIR = false>
 __device__ __forceinline__ void hat_request(HatState& st)
 {
-    const f32x4* row = reinterpret_cast<const f32x4*>(st.vx[S >> 3].base + hat_off(S & 7));
+    const f32x4* row = reinterpret_cast<const f32x4*>(st.vx[MIR ? 1 - (S >> 3) : (S >> 3)].base + hat_off(S & 7));
 #pragma unroll
     for (int j = 0; j < 4; ++j) st.ring[S % kHatDepth][j] = row[j];
 }
 
-template <int S, int END>
+template <int S, int END, bool MIR = false>
 struct HatRequests {
     static __device__ __forceinline__ void run(HatState& st)
     {
-        hat_request<S>(st);
-        HatRequests<S + 1, END>::run(st);
+        hat_request<S, MIR>(st);
+        HatRequests<S + 1, END, MIR>::run(st);
     }
 };
-template <int END>
-struct HatRequests<END, END> {
+template <int END, bool MIR>
+struct HatRequests<END, END, MIR> {
     static __device__ __forceinline__ void run(HatState&) {}
 };
 
-template <int Q>
+// Point symmetry.  The sample coordinate of the voxel mirrored through the volume's centre is i' = 7 - i on every axis
+// (i = 4 (R p) + 3.5 and p' = -p), so its clamped base row is 6 - j and, the hat function being even, its corner weights
+// are the SAME eight numbers in reverse corner order: w'[n] = w[7 - n].  The mirror of the pass-p voxel of quarter Q
+// that a lane owns is the pass-(1 - p) voxel (7 - x, 7 - y, 7 - z) of quarter 3 - Q.  So the quarters are gathered in the
+// order 0, 3, 1, 2 and the second quarter of each pair costs TWO instructions of set-up (the mirrored base addresses)
+// instead of ~60: the weights are read in reverse, the two voxels swap passes, and the lane writes the mirrored voxels'
+// slots of the image (GatherDst::m0 / m1).  Where i sits within an ulp of an integer the mirrored floor may differ from
+// a direct evaluation by one row with weights (1, 0) against (0, 1): the same sample to rounding.
+constexpr int kSrcMirrorBytes = 6 * 4 * kSrcStride * (kSrcPlaneRows + kSrcRowsY + 1);  // byte offset of row (6, 6, 6)
+
+__device__ __forceinline__ void hat_mirror(HatState& st, const float* srcT)
+{
+    const char* top = reinterpret_cast<const char*>(srcT) + kSrcMirrorBytes;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) st.vx[k].base = top - (st.vx[k].base - reinterpret_cast<const char*>(srcT));
+#ifdef AHV_DIAG_LINEAR_GATHER
+#pragma unroll
+    for (int k = 0; k < 2; ++k) st.vx[k].base = reinterpret_cast<const char*>(srcT) + (threadIdx.x & 63) * (4 * kSrcStride);
+#endif
+}
+
+// head of the mirrored quarter's gather (the counterpart of hat_prologue)
+__device__ __forceinline__ void hat_prologue_mirror(HatState& st, const float* srcT)
+{
+    hat_mirror(st, srcT);
+    HatRequests<0, kHatDepth, true>::run(st);
+}
+
+template <int Q, bool XDL = false>
 __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
 {
 #ifdef AHV_HAT_VOXEL_PAIR  // A/B knob of tools/kbench: 24 instructions fewer per hypothesis and SLOWER (0.6911 vs 0.6880 ms
@@ -432,9 +487,9 @@ __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, co
     hat_voxel_pair<Q>(st.vx[0], st.vx[1], srcT, h);
     HatRequests<0, kHatDepth>::run(st);
 #else
-    hat_voxel<Q>(st.vx[0], srcT, h, 0);
+    hat_voxel<Q, XDL>(st.vx[0], srcT, h, 0);
     HatRequests<0, kHatDepth>::run(st);
-    hat_voxel<Q>(st.vx[1], srcT, h, 1);
+    hat_voxel<Q, XDL>(st.vx[1], srcT, h, 1);
 #endif
 }
 
@@ -442,6 +497,7 @@ __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, co
 // forward's swizzled quarter image).  The split-f16 kernel has a store of its own (HatStoreSplit, ahv_split.h).
 template <int ROW>
 struct HatStoreF32 {
+    static constexpr bool kXdlKernel = false;  // fp32 MFMAs only (see low_half)
     float* d[2];  // the lane's voxel of pass 0 / pass 1 in channel plane 0
     __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
     {
@@ -451,13 +507,16 @@ struct HatStoreF32 {
     }
 };
 
-template <int S, typename Store>
+template <int S, typename Store, bool MIR = false>
 struct HatSteps {
     static __device__ __forceinline__ void run(HatState& st, f32x2 (&o)[8], const Store& store)
     {
         constexpr int p = S >> 3, n = S & 7;
+        constexpr int vi = MIR ? 1 - p : p, wi = MIR ? 7 - n : n;  // mirrored quarter: the other voxel, weights reversed
         __builtin_amdgcn_sched_barrier(0);
-        const f32x2 wn = {st.vx[p].w[n], st.vx[p].w[n]};
+        // the odd weights sit in the high half of their register pair (XDL kernels: see low_half)
+        const float wsc = (Store::kXdlKernel && (wi & 1)) ? low_half(st.vx[vi].w[wi]) : st.vx[vi].w[wi];
+        const f32x2 wn = {wsc, wsc};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 v = st.ring[S % kHatDepth][j];
@@ -471,25 +530,26 @@ struct HatSteps {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (S + kHatDepth < 16) hat_request<(S + kHatDepth < 16 ? S + kHatDepth : 0)>(st);
+        if (S + kHatDepth < 16) hat_request<(S + kHatDepth < 16 ? S + kHatDepth : 0), MIR>(st);
         if (n == 7) store(p, o);
-        HatSteps<S + 1, Store>::run(st, o, store);
+        HatSteps<S + 1, Store, MIR>::run(st, o, store);
     }
 };
-template <typename Store>
-struct HatSteps<16, Store> {
+template <typename Store, bool MIR>
+struct HatSteps<16, Store, MIR> {
     static __device__ __forceinline__ void run(HatState&, f32x2 (&)[8], const Store&) {}
 };
 
-// the 16 blend steps of a quarter whose prologue has been issued
+// the 16 blend steps of a quarter whose prologue has been issued (MIR: hat_prologue_mirror)
+template <bool MIR = false>
 __device__ __forceinline__ void hat_body(HatState& st, float* buf, const GatherDst& dst)
 {
     f32x2 o[8];
-    const HatStoreF32<128> store = {{buf + dst.o0, buf + dst.o1}};
+    const HatStoreF32<128> store = {{buf + (MIR ? dst.m0 : dst.o0), buf + (MIR ? dst.m1 : dst.o1)}};
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
-    HatSteps<0, HatStoreF32<128>>::run(st, o, store);
+    HatSteps<0, HatStoreF32<128>, MIR>::run(st, o, store);
 #if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif

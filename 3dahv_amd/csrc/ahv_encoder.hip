@@ -18,7 +18,6 @@
 #include <stdint.h>
 
 #include "../../include/ahv.h"
-#include "ahv_lds.h"
 
 // Every launch in this file goes through AHV_ENC_LAUNCH so that tools/kbench_enc.cpp (built with -DAHV_ENC_PROBE) can
 // cut a forward after k launches -- the marginal cost of every launch with no profiler attached -- and collect an
@@ -269,8 +268,8 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
     };
     auto park = [&](int st, int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds_store128(&sx[buf][(srow + 32 * j) * kStageLd + sc4], gx[st][j]);
-        if (wload) lds_store128(&sw[buf][srow * kStageLd + sc4], gw[st]);
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&sx[buf][(srow + 32 * j) * kStageLd + sc4]) = gx[st][j];
+        if (wload) *reinterpret_cast<f32x4*>(&sw[buf][srow * kStageLd + sc4]) = gw[st];
     };
 #pragma unroll
     for (int st = 0; st < DEPTH; ++st) request(st);
@@ -309,7 +308,7 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
     }
     AHV_ENC_STAMP(4);
     // D layout: acc[r] = C[m0 + 16 rt + 4 kq + r][column r16 of this wave's n-tile]; waves 4..7 hand over
-    if (half == 1) lds_store128(&comb[(rt * 64 + lane) * 4], acc);
+    if (half == 1) *reinterpret_cast<f32x4*>(&comb[(rt * 64 + lane) * 4]) = acc;
     __syncthreads();
     if (half == 0) {
         const f32x4 other = *reinterpret_cast<const f32x4*>(&comb[(rt * 64 + lane) * 4]);
@@ -391,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        lds_store128(&sA[0][(srow + 64 * i) * 16 + 4 * sch], ga[i]);
-        lds_store128(&sB[0][(srow + 64 * i) * 16 + 4 * sch], gb[i]);
+        *reinterpret_cast<f32x4*>(&sA[0][(srow + 64 * i) * 16 + 4 * sch]) = ga[i];
+        *reinterpret_cast<f32x4*>(&sB[0][(srow + 64 * i) * 16 + 4 * sch]) = gb[i];
     }
     __syncthreads();
     const int nk = a.K / 16;
@@ -421,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
         if (kt + 1 < nk) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                lds_store128(&sA[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch], ga[i]);
-                lds_store128(&sB[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch], gb[i]);
+                *reinterpret_cast<f32x4*>(&sA[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch]) = ga[i];
+                *reinterpret_cast<f32x4*>(&sB[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch]) = gb[i];
             }
         }
         __syncthreads();
@@ -556,7 +555,7 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
         for (int dt = 0; dt < 4; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r][dt], p, ot[dt], 0, 0, 0);
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) lds_store128(&so[w][dt][lane][0], ot[dt]);
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&so[w][dt][lane][0]) = ot[dt];
     __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512) void forward_3d2d_small_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) lds_store128(part[wave][m * 4 + t][lane], acc[m][t]);
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(part[wave][m * 4 + t][lane]) = acc[m][t];
     __syncthreads();
     if (wave >= 4) return;
     const int t = wave;  // this wave finishes positions 16t .. 16t+15

@@ -33,6 +33,7 @@ __device__ __forceinline__ float swap_add16(float a, float b)
 // test_co3d.py:143) as a reduce-scatter: a lane holds 8 of the 32 channels of position (16t + lane&15) for the
 // four tiles t; after two exchange steps lane (col, kq) owns the complete sums of ONE position (tile kq, column
 // col), so the normalisation runs once per lane.  Result uniform (read from lane 63).
+template <bool XDL>  // XDL: the kernel issues XDL MFMAs (low_half, ahv_dual.h)
 __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x4 (&tg)[4][2], int lane)
 {
     // sums of squares and dot products on v_pk_fma_f32: even and odd registers accumulate side by side and meet in
@@ -51,8 +52,9 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
                 s2 = __builtin_elementwise_fma(x, x, s2);
                 d2 = __builtin_elementwise_fma(x, g, d2);
             }
-        ss[t] = s2[0] + s2[1];
-        dt[t] = d2[0] + d2[1];
+        // hipcc adds the halves of a pair with v_pk_add_f32 op_sel:[0,1]: the low lane reads a high half
+        ss[t] = s2[0] + (XDL ? low_half(s2[1]) : s2[1]);
+        dt[t] = d2[0] + (XDL ? low_half(d2[1]) : d2[1]);
     }
     // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: with
     // (first, second) = (tile i, tile i+2) every lane then holds, in the two registers, its own half-sum of the
@@ -113,6 +115,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     __shared__ __attribute__((aligned(1024))) float lds_src[kSrcFloats];
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
     __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
+#ifdef AHV_DIAG_CODE_SHIFT  // diagnostic builds only (tools/first_launch.cpp): moves all the code below by 4 bytes per unit,
+    // i.e. to another position inside the 64-byte instruction-fetch lines
+    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(AHV_DIAG_CODE_SHIFT));
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             f32x4 x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = ft[(16 * m2 + 4 * (l >> 4) + r) * 64 + 16 * t + (l & 15)];
-            lds_store128(lds_src + tid * kSrcStride + 16, x);
+            *reinterpret_cast<f32x4*>(lds_src + tid * kSrcStride + 16) = x;
         }
         __syncthreads();
 
@@ -235,16 +241,16 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 GatherHyp gh;
                 gather_hyp(gh, Rm, glane);
                 HatState st;
-                hat_prologue<0>(st, srcT, gh);
+                hat_prologue<0, true>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(1)
                 gemm1_quarter_split<0>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(2)
-                hat_prologue<1>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
+                hat_prologue<1, true>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(3)
                 gemm1_quarter_split<1>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(4)
-                hat_prologue<2>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
+                hat_prologue<2, true>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(5)
                 gemm1_quarter_split<2>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(6)
-                hat_prologue<3>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
+                hat_prologue<3, true>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(7)
                 gemm1_quarter_split<3>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             } else {
@@ -253,16 +259,16 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 GatherHyp gh;
                 gather_hyp(gh, Rm, glane);
                 HatState st;
+                // quarters in the order 0, 3, 1, 2: quarter 3 - Q is the point mirror of quarter Q and reuses its set-up
                 hat_prologue<0>(st, srcT, gh);
                 hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(1)
-                gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(2)
-
-                hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(3)
-                gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue<2>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(4)
+                gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue_mirror(st, srcT); }); wave_lds_fence(); AHV_TS(2)
+                hat_body<true>(st, buf, gdst); wave_lds_fence(); AHV_TS(3)
+                gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(4)
                 hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(5)
-                gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [&] { hat_prologue<3>(st, srcT, gh); }); wave_lds_fence(); AHV_TS(6)
-                hat_body(st, buf, gdst); wave_lds_fence(); AHV_TS(7)
-                gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
+                gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue_mirror(st, srcT); }); wave_lds_fence(); AHV_TS(6)
+                hat_body<true>(st, buf, gdst); wave_lds_fence(); AHV_TS(7)
+                gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             }
 
             f32x4 v[2][4];
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2)
                     tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
-            const float s = hyp_score_rs(v, tg, lane);
+            const float s = hyp_score_rs<SPLIT>(v, tg, lane);
             if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
             const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
             best = key > best ? key : best;

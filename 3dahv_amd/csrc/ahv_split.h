@@ -75,7 +75,7 @@ __device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __rest
             const _Float16 hi = (_Float16)x;
             v[j] = part ? (_Float16)(x - (float)hi) : hi;
         }
-        lds_store128(table + i, v);  // the next iteration's conversions reuse v's registers (ahv_lds.h)
+        table[i] = v;
     }
 }
 
@@ -117,7 +117,7 @@ __device__ __forceinline__ unsigned pk_rtz(float a, float b)
 // The gather is the fp32 kernel's (ahv_dual.h: hat weights on a clamped base row, one base address per voxel, a
 // request ring six rows deep, the 4 x 2 x 2-box lane map); only the store differs: the sixteen blended channels are
 // split into hi (the top 11 significant bits, exactly an f16 in the normal range) and lo (the rest) and leave as
-// 16-byte stores issued as pairs of ds_write_b64 (ahv_lds.h).  A 16-lane store group holds e = 0..7 x a0 = 0..1 of one b
+// 16-byte stores.  A 16-lane store group holds e = 0..7 x a0 = 0..1 of one b
 // under the box map (z is the fastest bit inside a box), so every store is a 2-way bank conflict at worst.
 struct SplitDst {
     int chunk[4];  // byte offsets of [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of the lane's pass-0 voxel (pass 1: + 4096)
@@ -134,6 +134,7 @@ __device__ __forceinline__ SplitDst split_dst(int lane)
 }
 
 struct HatStoreSplit {
+    static constexpr bool kXdlKernel = true;  // GEMM1 runs on XDL MFMAs here: broadcast scalars stay in low halves (low_half, ahv_dual.h)
     char* img;
     SplitDst d;
     __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
@@ -154,9 +155,8 @@ struct HatStoreSplit {
                 hi[i] = pk_rtz(h0, h1);
                 lo[i] = pk_rtz(x0 - h0, x1 - h1);
             }
-            // lds_store128: the next half's conversions reuse these registers at once (ahv_lds.h)
-            lds_store128(dst + d.chunk[half], u32x4{hi[0], hi[1], hi[2], hi[3]});
-            lds_store128(dst + d.chunk[2 + half], u32x4{lo[0], lo[1], lo[2], lo[3]});
+            *reinterpret_cast<u32x4*>(dst + d.chunk[half]) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(dst + d.chunk[2 + half]) = u32x4{lo[0], lo[1], lo[2], lo[3]};
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -198,6 +198,14 @@ __device__ __forceinline__ void split_load(SplitStep& o, const f16x8* T, const c
     }
 }
 
+// Stress knob of tools/first_launch.cpp, never set in the product: AHV_DIAG_MFMA_GAP="s_nop 7" leaves the matrix pipe idle
+// between any two MFMAs, which is what exposes the packed-fp32 op_sel hazard (low_half, ahv_dual.h) on every hypothesis
+// instead of on the few that meet an instruction-fetch stall in a process' first launch.
+#ifdef AHV_DIAG_MFMA_GAP
+#define AHV_MFMA_GAP __builtin_amdgcn_sched_barrier(0); asm volatile(AHV_DIAG_MFMA_GAP ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#else
+#define AHV_MFMA_GAP
+#endif
 template <int Q, int S>
 __device__ __forceinline__ void split_mfma(f32x4 (&acc)[2][4], const SplitStep& o, const f16x8 (&az)[4])
 {
@@ -206,8 +214,11 @@ __device__ __forceinline__ void split_mfma(f32x4 (&acc)[2][4], const SplitStep& 
     for (int m = 0; m < 2; ++m) {
         const f16x8 ah = S < 8 ? o.a[2 * m] : az[2 * m], al = S < 8 ? o.a[2 * m + 1] : az[2 * m + 1];
         acc[m][t] = AHV_MFMA_F16(al, o.bh, acc[m][t]);
+        AHV_MFMA_GAP
         acc[m][t] = AHV_MFMA_F16(ah, o.bl, acc[m][t]);
+        AHV_MFMA_GAP
         acc[m][t] = AHV_MFMA_F16(ah, o.bh, acc[m][t]);
+        AHV_MFMA_GAP
     }
 }
 

@@ -1,0 +1,85 @@
+// first_launch.cpp -- developer diagnostic for the split-f16 scorer (not part of the product).
+// Scores the same rotations with the split kernel in a process' FIRST launch and in later ones and compares each with
+// the fp32 kernel (run afterwards, so that the split kernel really is the first thing the process launches).
+// Together with two build knobs it is the regression check for the packed-fp32 op_sel hazard (low_half, ahv_dual.h):
+//   -DAHV_DIAG_CODE_SHIFT=k            moves the kernel's code by 4k bytes inside the 64-byte fetch lines (k = 0..15: the
+//                                      first-launch failures came and went with the position of the MFMA groups in them)
+//   -DAHV_DIAG_MFMA_GAP='"s_nop 7"'    leaves the matrix pipe idle between any two MFMAs of the split GEMM (turned ~1 % of
+//                                      the first launch's first hypotheses into 80 % of all scores before the fix)
+// tools/first_launch_sweep.sh builds and runs the lot.  Usage: first_launch [N] [sequence of A/B launches, default ABAAB]
+#include "../3dahv_amd/csrc/ahv_score.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+
+int main(int argc, char** argv)
+{
+    const long N = argc > 1 ? atol(argv[1]) : 8192;  // two sets of N/2 rotations: A and B
+    const char* seq = argc > 2 ? argv[2] : "ABAAB";
+    std::mt19937 rng(0);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> vol(8192), ft(2048), R(N * 9), W1(32 * 384), W2(1024), b2(32);
+    for (auto& x : vol) x = 1.15f * nd(rng);
+    for (auto& x : ft) x = nd(rng) / 5.6f;
+    for (auto& x : W1) x = nd(rng) * 0.03f;
+    for (auto& x : W2) x = nd(rng) * 0.1f;
+    for (auto& x : b2) x = nd(rng) * 0.1f;
+    for (long n = 0; n < N; ++n) {  // Haar rotations from normalised Gaussian quaternions
+        double q[4], s = 0;
+        for (double& c : q) { c = nd(rng); s += c * c; }
+        const double t = 2.0 / s, r = q[0], i = q[1], j = q[2], k = q[3];
+        const double m[9] = {1 - t * (j * j + k * k), t * (i * j - k * r), t * (i * k + j * r),
+                             t * (i * j + k * r), 1 - t * (i * i + k * k), t * (j * k - i * r),
+                             t * (i * k - j * r), t * (j * k + i * r), 1 - t * (i * i + j * j)};
+        for (int e = 0; e < 9; ++e) R[n * 9 + e] = (float)m[e];
+    }
+    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dsc;
+    uint64_t* dkey;
+    CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
+    CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
+    CK(hipMalloc(&dsc, N * 4)); CK(hipMalloc(&dkey, 8));
+    CK(hipMemcpy(dvol, vol.data(), vol.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dft, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW1, W1.data(), W1.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW2, W2.data(), W2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dkey, 0, 8));
+    int cu = 0;
+    CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0));
+    auto launch = [&](bool split, long off) {
+        return ahv::launch_score_hypotheses(dvol, dft, dR + off * 9, 0, 0, dW1, dW2, db2, 1, N / 2, dsc, dkey, cu, split, nullptr, 0);
+    };
+    const int L = (int)strlen(seq);
+    std::vector<std::vector<float>> res(L, std::vector<float>(N / 2));
+    for (int k = 0; k < L; ++k) {
+        CK(launch(true, seq[k] == 'A' ? 0 : N / 2));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(res[k].data(), dsc, N / 2 * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<float> refA(N / 2), refB(N / 2);
+    CK(launch(false, 0)); CK(hipDeviceSynchronize()); CK(hipMemcpy(refA.data(), dsc, N / 2 * 4, hipMemcpyDeviceToHost));
+    CK(launch(false, N / 2)); CK(hipDeviceSynchronize()); CK(hipMemcpy(refB.data(), dsc, N / 2 * 4, hipMemcpyDeviceToHost));
+    long total = 0;
+    for (int k = 0; k < L; ++k) {
+        const std::vector<float>& r = seq[k] == 'A' ? refA : refB;
+        double m = 0;
+        long nb = 0, young = 0, r0 = 0;
+        for (long n = 0; n < N / 2; ++n) {
+            const double d = std::abs(res[k][n] - r[n]);
+            m = std::max(m, d);
+            if (!(d <= 1e-5)) { ++nb; young += ((n / cu) % 8) >= 4; r0 += n < 8 * cu; }
+        }
+        total += nb;
+        printf("launch %d (%c): split vs fp32 max |diff| %.3g, %ld of %ld beyond 1e-5 (%ld in waves 4-7, %ld in the waves' first hypothesis)\n",
+               k, seq[k], m, nb, N / 2, young, r0);
+    }
+    printf("%s\n", total ? "FAIL" : "OK");
+    return total ? 1 : 0;
+}
