@@ -144,15 +144,16 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
                 GatherHyp gh;
                 gather_hyp(gh, Rm, glane);
                 HatState st;
+                // quarters in the scorer's order 0, 3, 1, 2 (quarter 3 - Q is the point mirror of Q and reuses its set-up)
                 hat_prologue<0>(st, lds_src, gh);
                 hat_body(st, buf, gdst); wave_lds_fence();
-                gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, lds_src, gh); }); wave_lds_fence();
+                gemm1_quarter_pipe<0>(acc, lds_w1, buf, lane, [&] { hat_prologue_mirror(st, lds_src); }); wave_lds_fence();
+                hat_body<true>(st, buf, gdst); wave_lds_fence();
+                gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [&] { hat_prologue<1>(st, lds_src, gh); }); wave_lds_fence();
                 hat_body(st, buf, gdst); wave_lds_fence();
-                gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue<2>(st, lds_src, gh); }); wave_lds_fence();
-                hat_body(st, buf, gdst); wave_lds_fence();
-                gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [&] { hat_prologue<3>(st, lds_src, gh); }); wave_lds_fence();
-                hat_body(st, buf, gdst); wave_lds_fence();
-                gemm1_quarter_pipe<3>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence();
+                gemm1_quarter_pipe<1>(acc, lds_w1, buf, lane, [&] { hat_prologue_mirror(st, lds_src); }); wave_lds_fence();
+                hat_body<true>(st, buf, gdst); wave_lds_fence();
+                gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence();
             }
             f32x4 v[2][4];
             gemm2_dual(v, acc, f);
