@@ -241,18 +241,20 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 GatherHyp gh;
                 gather_hyp(gh, Rm, glane);
                 HatState st;
+                // quarters in the order 0, 3, 1, 2 (point mirror, as in the fp32 path); the prologues run between the GEMMs:
+                // the request ring does not fit beside the GEMM's operands
                 hat_prologue<0, true>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(1)
                 gemm1_quarter_split<0>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(2)
-                hat_prologue<1, true>(st, srcT, gh);  // not from inside the GEMM: the request ring does not fit beside its operands
-                hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(3)
-                gemm1_quarter_split<1>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(4)
-                hat_prologue<2, true>(st, srcT, gh);
+                hat_prologue_mirror(st, srcT);
+                hat_body_split<true>(st, cbuf, sdst); wave_lds_fence(); AHV_TS(3)
+                gemm1_quarter_split<3>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(4)
+                hat_prologue<1, true>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(5)
-                gemm1_quarter_split<2>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(6)
-                hat_prologue<3, true>(st, srcT, gh);
-                hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(7)
-                gemm1_quarter_split<3>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
+                gemm1_quarter_split<1>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(6)
+                hat_prologue_mirror(st, srcT);
+                hat_body_split<true>(st, cbuf, sdst); wave_lds_fence(); AHV_TS(7)
+                gemm1_quarter_split<2>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             } else {
                 // gather quarter q (16 blend steps) -> GEMM1 on it; the head of quarter q+1's gather (coordinates,
                 // weights, first row requests) is issued from inside GEMM q, ahead of its last MFMA chunks

@@ -120,7 +120,8 @@ __device__ __forceinline__ unsigned pk_rtz(float a, float b)
 // 16-byte stores.  A 16-lane store group holds e = 0..7 x a0 = 0..1 of one b
 // under the box map (z is the fastest bit inside a box), so every store is a 2-way bank conflict at worst.
 struct SplitDst {
-    int chunk[4];  // byte offsets of [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of the lane's pass-0 voxel (pass 1: + 4096)
+    int chunk[4];    // byte offsets of [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of the lane's pass-0 voxel (pass 1: + 4096)
+    int chunk_m[4];  // the same for the lane's voxel in a MIRRORED quarter, (7 - x, 7 - y, 1 - z) (hat_mirror, ahv_dual.h)
 };
 
 __device__ __forceinline__ SplitDst split_dst(int lane)
@@ -128,11 +129,16 @@ __device__ __forceinline__ SplitDst split_dst(int lane)
     const LaneVox lv = lane_vox(lane);
     SplitDst d;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) d.chunk[c] = split_addr(lv.a0, lv.bq, lv.e, c);  // b = 4 p + bq: the pass keeps b & 1
+    for (int c = 0; c < 4; ++c) {
+        d.chunk[c] = split_addr(lv.a0, lv.bq, lv.e, c);  // b = 4 p + bq: the pass keeps b & 1
+        d.chunk_m[c] = split_addr(1 - lv.a0, 3 - lv.bq, 7 - lv.e, c);
+    }
     asm volatile("" : "+v"(d.chunk[0]), "+v"(d.chunk[1]), "+v"(d.chunk[2]), "+v"(d.chunk[3]));
+    asm volatile("" : "+v"(d.chunk_m[0]), "+v"(d.chunk_m[1]), "+v"(d.chunk_m[2]), "+v"(d.chunk_m[3]));
     return d;
 }
 
+template <bool MIR>
 struct HatStoreSplit {
     static constexpr bool kXdlKernel = true;  // GEMM1 runs on XDL MFMAs here: broadcast scalars stay in low halves (low_half, ahv_dual.h)
     char* img;
@@ -155,20 +161,21 @@ struct HatStoreSplit {
                 hi[i] = pk_rtz(h0, h1);
                 lo[i] = pk_rtz(x0 - h0, x1 - h1);
             }
-            *reinterpret_cast<u32x4*>(dst + d.chunk[half]) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-            *reinterpret_cast<u32x4*>(dst + d.chunk[2 + half]) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            *reinterpret_cast<u32x4*>(dst + (MIR ? d.chunk_m[half] : d.chunk[half])) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4*>(dst + (MIR ? d.chunk_m[2 + half] : d.chunk[2 + half])) = u32x4{lo[0], lo[1], lo[2], lo[3]};
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 };
 
 // the 16 blend steps of a quarter whose prologue (hat_prologue, ahv_dual.h) has been issued
+template <bool MIR = false>
 __device__ __forceinline__ void hat_body_split(HatState& st, char* img, const SplitDst& dst)
 {
     f32x2 o[8];
-    const HatStoreSplit store = {img, dst};
+    const HatStoreSplit<MIR> store = {img, dst};
     __builtin_amdgcn_s_setprio(1);
-    HatSteps<0, HatStoreSplit>::run(st, o, store);
+    HatSteps<0, HatStoreSplit<MIR>, MIR>::run(st, o, store);
     __builtin_amdgcn_s_setprio(0);
 }
 
