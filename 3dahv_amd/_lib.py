@@ -16,6 +16,10 @@ LIB_PATH = os.path.join(CSRC, "libahv_hip.so")
 
 AHV_SCORE_RESET_BEST = 1
 AHV_SCORE_SPLIT_F16 = 2
+AHV_SCORE_NO_TEAMS = 4
+AHV_SCORE_SPARE_CUS_SHIFT = 8
+AHV_SELECT_RESET_KEY = 1
+AHV_KEY_EMPTY = -(1 << 63)
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -30,7 +34,9 @@ SIGNATURES = {
     "ahv_score_hypotheses_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32, _vp]),
     "ahv_score_hypotheses_clocked_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32,
                                                 _vp, _vp]),
+    "ahv_verify_pair_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
     "ahv_unpack_best": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ahv_reset_best": (_int, [_vp, _int, _vp]),
     "ahv_rotate_volume_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
     "ahv_rotate_volume_backward_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
     "ahv_forward_3d2d_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -38,7 +44,7 @@ SIGNATURES = {
     "ahv_argmax_f32": (_int, [_vp, _int, _i64, _i64, _vp, _u32, _vp]),
     "ahv_random_rotations_f32": (_int, [ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
     "ahv_so3_grid_f32": (_int, [_i64, _i64, _i64, _vp, _vp]),
-    "ahv_select_rotation_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
+    "ahv_select_rotation_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _u32, _vp]),
     "ahv_compose_rotations_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp]),
 }
 

@@ -7,12 +7,10 @@
 #include <cstring>
 
 #include "../../include/ahv.h"
+#include "ahv_launch.h"
 
 namespace ahv {
-hipError_t launch_score_hypotheses(const float*, const float*, const float*, int64_t, int64_t, const float*,
-                                   const float*, const float*, int, int64_t, float*, uint64_t*, int, bool, uint64_t*,
-                                   hipStream_t);
-hipError_t launch_unpack_best(const uint64_t*, int, float*, int64_t*, hipStream_t);
+hipError_t launch_unpack_best(const int64_t*, int, float*, int64_t*, hipStream_t);
 hipError_t launch_rotate_volume(const float*, int64_t, const float*, int64_t, int, int, int, int, float*, int,
                                 hipStream_t);
 hipError_t launch_rotate_volume_backward(const float*, int64_t, const float*, int64_t, int, int, int, int, float*, int,
@@ -20,11 +18,12 @@ hipError_t launch_rotate_volume_backward(const float*, int64_t, const float*, in
 hipError_t launch_forward_3d2d(const float*, const float*, const float*, const float*, int64_t, float*, int,
                                hipStream_t);
 hipError_t launch_score_features(const float*, const float*, int, int64_t, float*, int, hipStream_t);
-hipError_t launch_argmax(const float*, int, int64_t, int64_t, uint64_t*, int, hipStream_t);
-hipError_t launch_compose_rotations(const uint64_t*, const float*, int64_t, int64_t, int64_t, const float*, int64_t,
+hipError_t launch_argmax(const float*, int, int64_t, int64_t, int64_t*, int, hipStream_t);
+hipError_t launch_compose_rotations(const int64_t*, const float*, int64_t, int64_t, int64_t, const float*, int64_t,
                                     int, float*, hipStream_t);
-hipError_t launch_select_rotation(const uint64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*,
-                                  int64_t*, hipStream_t);
+hipError_t launch_select_rotation(int64_t*, const float*, int64_t, int64_t, int64_t, int, float*, float*, int64_t*, bool,
+                                  hipStream_t);
+hipError_t launch_fill_keys(int64_t*, int, hipStream_t);
 hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 hipError_t launch_so3_grid(int64_t, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
@@ -76,7 +75,7 @@ int cu_count()
 
 extern "C" {
 
-int ahv_abi_version(void) { return (1 << 16) | 0; }
+int ahv_abi_version(void) { return (2 << 16) | 0; }
 
 const char* ahv_last_error(void) { return g_err; }
 
@@ -95,53 +94,83 @@ static hipError_t zero_span(void* p, size_t bytes, hipStream_t s)
     return ahv::launch_zero_fill(ptrs, n, 1, s);
 }
 
-static int score_common(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
-                        int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
-                        float* scores, uint64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream)
+// tgt = target features (tgt_is_volume = false) or the target volume (ahv_verify_pair_f32)
+static int score_common(const char* who, const float* vol_src, const float* tgt, bool tgt_is_volume, const float* R,
+                        int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2, const float* b2, int B,
+                        int64_t N, float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags,
+                        uint64_t* clock_stamps, void* stream)
 {
-    if (B < 0 || N < 0) return fail(AHV_EINVAL, "score: negative size (B=%d, N=%lld)", B, (long long)N);
-    if (B > 0 && N > 0 && (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2))
-        return fail(AHV_EINVAL, "score: null input pointer");
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "%s: negative size (B=%d, N=%lld)", who, B, (long long)N);
+    if (B > 0 && N > 0 && (!vol_src || !tgt || !R || !W1 || !W2 || !b2))
+        return fail(AHV_EINVAL, "%s: null input pointer", who);
     if (r_batch_stride != 0 && r_batch_stride < N * 9)
-        return fail(AHV_EINVAL, "score: r_batch_stride %lld must be 0 or >= N*9", (long long)r_batch_stride);
+        return fail(AHV_EINVAL, "%s: r_batch_stride %lld must be 0 or >= N*9", who, (long long)r_batch_stride);
     if (n_offset < 0 || n_offset + N > 4294967296ll)
-        return fail(AHV_EINVAL, "score: n_offset + N must fit in 32 bits");
-    if (flags & ~(AHV_SCORE_RESET_BEST | AHV_SCORE_SPLIT_F16)) return fail(AHV_EINVAL, "score: unknown flags 0x%x", flags);
+        return fail(AHV_EINVAL, "%s: n_offset + N must fit in 32 bits", who);
+    if (flags & ~(AHV_SCORE_RESET_BEST | AHV_SCORE_SPLIT_F16 | AHV_SCORE_NO_TEAMS | AHV_SCORE_SPARE_CUS_MASK))
+        return fail(AHV_EINVAL, "%s: unknown flags 0x%x", who, flags);
+    const bool split = (flags & AHV_SCORE_SPLIT_F16) != 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (best_key && (flags & AHV_SCORE_RESET_BEST) && B > 0) {
-        hipError_t e = zero_span(best_key, sizeof(uint64_t) * (size_t)B, s);
-        if (e != hipSuccess) return hip_fail("score: zero fill (best_key)", e);
+        hipError_t e = ahv::launch_fill_keys(best_key, B, s);
+        if (e != hipSuccess) return hip_fail("score: key reset", e);
     }
-    if (B == 0 || N == 0) return AHV_OK;
     const int cu = cu_count();
     if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
-    hipError_t e = ahv::launch_score_hypotheses(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N,
-                                                scores, best_key, cu, (flags & AHV_SCORE_SPLIT_F16) != 0,
-                                                clock_stamps, s);
+    if (tgt_is_volume && split) {
+        // the split-f16 kernel takes ready-made target features: two launches, through the caller's buffer
+        if (B > 0 && !feat_tgt_out)
+            return fail(AHV_EINVAL, "%s: AHV_SCORE_SPLIT_F16 needs feat_tgt_out (the target features go through it)", who);
+        if (B > 0) {
+            hipError_t e = ahv::launch_forward_3d2d(tgt, W1, W2, b2, B, feat_tgt_out, cu, s);
+            if (e != hipSuccess) return hip_fail("verify_pair: forward_3d2d launch", e);
+        }
+        tgt = feat_tgt_out;
+        tgt_is_volume = false;
+        feat_tgt_out = nullptr;
+    }
+    if (B == 0) return AHV_OK;
+    if (N == 0 && !(tgt_is_volume && feat_tgt_out)) return AHV_OK;  // nothing to score (verify_pair still owes the features)
+    ahv::ScoreLaunch a;
+    a.vol_src = vol_src; a.tgt = tgt; a.tgt_is_volume = tgt_is_volume; a.R = R;
+    a.r_batch_stride = r_batch_stride; a.n_offset = n_offset; a.W1 = W1; a.W2 = W2; a.b2 = b2; a.B = B; a.N = N;
+    a.scores = scores; a.best_key = best_key; a.feat_tgt_out = feat_tgt_out; a.num_cu = cu;
+    a.spare_cu = (int)((flags & AHV_SCORE_SPARE_CUS_MASK) >> AHV_SCORE_SPARE_CUS_SHIFT);
+    a.split_f16 = split; a.no_teams = (flags & AHV_SCORE_NO_TEAMS) != 0; a.clock_stamps = clock_stamps;
+    hipError_t e = ahv::launch_score_hypotheses(a, s);
     if (e != hipSuccess) return hip_fail("score: launch", e);
     return AHV_OK;
 }
 
 int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
                              int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2,
-                             const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
+                             const float* b2, int B, int64_t N, float* scores, int64_t* best_key,
                              unsigned flags, void* stream)
 {
-    return score_common(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key, flags,
-                        nullptr, stream);
+    return score_common("score", vol_src, feat_tgt, false, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key,
+                        nullptr, flags, nullptr, stream);
 }
 
 int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt, const float* R,
                                      int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2,
-                                     const float* b2, int B, int64_t N, float* scores, uint64_t* best_key,
+                                     const float* b2, int B, int64_t N, float* scores, int64_t* best_key,
                                      unsigned flags, uint64_t* clock_stamps, void* stream)
 {
     if (!clock_stamps) return fail(AHV_EINVAL, "score_clocked: null clock_stamps");
-    return score_common(vol_src, feat_tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key, flags,
-                        clock_stamps, stream);
+    return score_common("score_clocked", vol_src, feat_tgt, false, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores,
+                        best_key, nullptr, flags, clock_stamps, stream);
 }
 
-int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
+int ahv_verify_pair_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,
+                        int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
+                        float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags, uint64_t* clock_stamps,
+                        void* stream)
+{
+    return score_common("verify_pair", vol_src, vol_tgt, true, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores,
+                        best_key, feat_tgt_out, flags, clock_stamps, stream);
+}
+
+int ahv_unpack_best(const int64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
 {
     if (!best_key) return fail(AHV_EINVAL, "unpack: null best_key");
     if (B < 0) return fail(AHV_EINVAL, "unpack: negative B");
@@ -217,7 +246,7 @@ int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_
     return AHV_OK;
 }
 
-int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+int ahv_compose_rotations_f32(const int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
                                  int64_t N, const float* D, int64_t N2, int B, float* out, void* stream)
 {
     if (B < 0 || N < 0 || N2 < 0) return fail(AHV_EINVAL, "compose_rotations: negative size");
@@ -231,16 +260,27 @@ int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t 
     return AHV_OK;
 }
 
-int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
-                            int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, void* stream)
+int ahv_reset_best(int64_t* best_key, int B, void* stream)
+{
+    if (B < 0) return fail(AHV_EINVAL, "reset_best: negative B");
+    if (B == 0) return AHV_OK;
+    if (!best_key) return fail(AHV_EINVAL, "reset_best: null best_key");
+    hipError_t e = ahv::launch_fill_keys(best_key, B, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("reset_best: launch", e);
+    return AHV_OK;
+}
+
+int ahv_select_rotation_f32(int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset, int64_t N,
+                            int B, float* R_out, float* best_score, int64_t* best_idx, unsigned flags, void* stream)
 {
     if (B < 0 || N < 0) return fail(AHV_EINVAL, "select_rotation: negative size");
+    if (flags & ~AHV_SELECT_RESET_KEY) return fail(AHV_EINVAL, "select_rotation: unknown flags 0x%x", flags);
     if (B == 0) return AHV_OK;
     if (!best_key) return fail(AHV_EINVAL, "select_rotation: null best_key");
     if (R_out && (!R || N == 0)) return fail(AHV_EINVAL, "select_rotation: R_out needs a rotation set");
     if (r_batch_stride != 0 && r_batch_stride < N * 9) return fail(AHV_EINVAL, "select_rotation: bad r_batch_stride");
-    hipError_t e = ahv::launch_select_rotation(best_key, R, r_batch_stride, n_offset, N, B, R_out, best_score,
-                                               best_idx, static_cast<hipStream_t>(stream));
+    hipError_t e = ahv::launch_select_rotation(best_key, R, r_batch_stride, n_offset, N, B, R_out, best_score, best_idx,
+                                               (flags & AHV_SELECT_RESET_KEY) != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("select_rotation: launch", e);
     return AHV_OK;
 }
@@ -361,7 +401,7 @@ int ahv_so3_grid_f32(int64_t n_total, int64_t offset, int64_t N, float* out, voi
     return AHV_OK;
 }
 
-int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key, unsigned flags,
+int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, int64_t* best_key, unsigned flags,
                    void* stream)
 {
     if (!scores || !best_key) return fail(AHV_EINVAL, "argmax: null pointer");
@@ -371,8 +411,8 @@ int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint
     if (flags & ~AHV_SCORE_RESET_BEST) return fail(AHV_EINVAL, "argmax: unknown flags 0x%x", flags);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((flags & AHV_SCORE_RESET_BEST) && B > 0) {
-        hipError_t e = zero_span(best_key, sizeof(uint64_t) * (size_t)B, s);
-        if (e != hipSuccess) return hip_fail("argmax: zero fill (best_key)", e);
+        hipError_t e = ahv::launch_fill_keys(best_key, B, s);
+        if (e != hipSuccess) return hip_fail("argmax: key reset", e);
     }
     if (B == 0 || N == 0) return AHV_OK;
     const int cu = cu_count();

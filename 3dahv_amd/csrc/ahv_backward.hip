@@ -821,11 +821,8 @@ __device__ __forceinline__ void bwd_vol_scatter(const float* xbuf, const float* 
 }
 
 constexpr int kVolThreads = 512;
-#ifdef AHV_VOL_NOPRIO
-#define AHV_VOL_PRIO(x)
-#else  // the scattering wave (VALU + LDS latency) issues first, its partner streams MFMAs: same reasoning as the forward's gather
+// the scattering wave (VALU + LDS latency) issues first, its partner streams MFMAs: same reasoning as the forward's gather
 #define AHV_VOL_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 
 __global__ __launch_bounds__(kVolThreads, 2) void score_backward_volume_kernel(
     const float* __restrict__ R, long r_batch_stride, const float* __restrict__ W1, int B, long N,

@@ -343,29 +343,36 @@ __device__ __forceinline__ void gemm2(f32x4 (&v)[2][4], const f32x4 (&acc)[2][4]
 }
 
 // ---- packed (score, index) keys ---------------------------------------------------
-// key = ordered_u32(score) << 32 | (0xFFFFFFFF - idx): unsigned max = largest score,
-// lowest index among equals (torch.max, test_co3d.py:145).  NaN orders above +inf.
-__device__ __forceinline__ unsigned long long pack_key(float s, unsigned idx)
+// key = ordered_i32(score) << 32 | (0xFFFFFFFF - idx) as a SIGNED 64-bit integer: signed max = largest score,
+// lowest index among equals (torch.max, test_co3d.py:145).  NaN orders above +inf.  Signed order so that the key is
+// what an int64 MAX all-reduce (RCCL, gloo, torch.max) wants as it is -- no re-biasing launch on either side of the
+// collective.  kKeyEmpty (INT64_MIN) is below every real key: "nothing scored yet".
+typedef long long key_t;
+constexpr key_t kKeyEmpty = (key_t)0x8000000000000000ull;
+
+__device__ __forceinline__ key_t pack_key(float s, unsigned idx)
 {
     s += 0.0f;  // -0 -> +0 so that equal values compare equal
     unsigned u = __float_as_uint(s);
     if (s != s) u = 0x7FC00000u;  // canonical quiet NaN: ranks highest
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+    u = (u & 0x80000000u) ? (u ^ 0x7FFFFFFFu) : u;  // negative floats: larger magnitude = smaller integer
+    return (key_t)(((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx));
 }
 
-__device__ __forceinline__ float key_score(unsigned long long key)
+__device__ __forceinline__ float key_score(key_t key)
 {
-    unsigned u = (unsigned)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    unsigned u = (unsigned)((unsigned long long)key >> 32);
+    u = (u & 0x80000000u) ? (u ^ 0x7FFFFFFFu) : u;
     return __uint_as_float(u);
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+__device__ __forceinline__ long key_index(key_t key) { return (long)(0xFFFFFFFFu - (unsigned)((unsigned long long)key & 0xFFFFFFFFull)); }
+
+__device__ __forceinline__ key_t wave_max_key(key_t k)
 {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
-        const unsigned long long o = __shfl_xor(k, s, 64);
+        const key_t o = __shfl_xor(k, s, 64);
         k = o > k ? o : k;
     }
     return k;

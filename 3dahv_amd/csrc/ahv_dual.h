@@ -184,14 +184,11 @@ __device__ __forceinline__ void gemm2_dual(f32x4 (&v)[2][4], const f32x4 (&acc)[
 //    through op_sel): half the blend instructions, same FMA order per channel, bit-identical sums.
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Wave priority during the gather (A/B knob of tools/kbench; 1 = shipped).  The two waves of a SIMD run the same
-// program with no barrier; the one that is gathering is latency-bound (LDS round trips, short VALU bursts)
-// while its partner streams MFMAs, so letting the gathering wave issue FIRST whenever it is ready shortens
-// its critical path at no cost to the matrix pipe: measured -3.4 % kernel time (0 / 1 / GEMM-high / all-but-GEMM
-// high: 0.743 / 0.718 / 0.734 / 0.727 ms per 50 000 hypotheses).
-#ifndef AHV_PRIO
-#define AHV_PRIO 1
-#endif
+// Wave priority: s_setprio 1 during the gather (hat_body).  The two waves of a SIMD run the same program with no
+// barrier; the one that is gathering is latency-bound (LDS round trips, short VALU bursts) while its partner streams
+// MFMAs, so letting the gathering wave issue FIRST whenever it is ready shortens its critical path at no cost to the
+// matrix pipe: measured -3.4 % kernel time (none / gather / GEMM-high / all-but-GEMM high: 0.743 / 0.718 / 0.734 /
+// 0.727 ms per 50 000 hypotheses, round 2).
 
 // Lane -> output voxel of a gather pass.  The 16 lanes that the LDS serves together in a ds_read_b128
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) own a compact 4 (x) x 2 (y) x 2 (z) block of the quarter, so that
@@ -335,14 +332,13 @@ __device__ __forceinline__ constexpr int hat_off(int n)
     return ((n & 1) ? 4 * kSrcStride : 0) + ((n & 2) ? 4 * kSrcRowsY * kSrcStride : 0) + ((n & 4) ? 4 * kSrcPlaneRows * kSrcStride : 0);
 }
 
-// XDL: the kernel issues XDL MFMAs (see low_half).
-template <int Q, bool XDL = false>
-__device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const GatherHyp& h, int p)
+// Weights and base row from the sample coordinates (x, y) and z.  XDL: the kernel issues XDL MFMAs (see low_half).
+template <bool XDL>
+__device__ __forceinline__ void hat_voxel_at(HatVoxel& v, const float* srcT, f32x2 ixy, float iz)
 {
     float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
     // x and y ride on packed instructions where one exists (coordinate, offset from the base row, offset - 1);
     // floor, med3 and the |.|-with-clamp subtraction have no packed form
-    const f32x2 ixy = Q == 0 ? h.ixy[p] : __builtin_elementwise_fma(f32x2{(float)Q, (float)Q}, h.dqxy, h.ixy[p]);
     jx = __builtin_amdgcn_fmed3f(floorf(ixy[0]), 0.0f, 6.0f);
     jy = __builtin_amdgcn_fmed3f(floorf(ixy[1]), 0.0f, 6.0f);
     const f32x2 uxy = ixy - f32x2{jx, jy};
@@ -351,20 +347,15 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
     wy0 = clamp01(1.0f - fabsf(uxy[1]));
     wx1 = clamp01(1.0f - fabsf(txy[0]));
     wy1 = clamp01(1.0f - fabsf(txy[1]));
-    hat_axis(Q == 0 ? h.izp[p] : fmaf((float)Q, h.dqz, h.izp[p]), jz, wz0, wz1);
-#ifndef AHV_SCALAR_WEIGHTS  // A/B knob of tools/kbench: measured 0.7081 -> 0.7033 ms per 50 000 hypotheses
-    // the outer product of the three weight pairs on v_pk_mul_f32 (6 instead of 12 multiplications, same products)
+    hat_axis(iz, jz, wz0, wz1);
+    // the outer product of the three weight pairs on v_pk_mul_f32 (6 instead of 12 multiplications, same products;
+    // 0.7081 -> 0.7033 ms per 50 000 hypotheses against scalar multiplications, round 3)
     const f32x2 wy = {wy0, wy1}, wx = {wx0, wx1};
     const f32x2 w0y = wz0 * wy, w1y = wz1 * wy;
     const float s0 = XDL ? low_half(w0y[1]) : w0y[1], s1 = XDL ? low_half(w1y[1]) : w1y[1];
     const f32x2 a = w0y[0] * wx, b = s0 * wx, c = w1y[0] * wx, d = s1 * wx;
     v.w[0] = a[0]; v.w[1] = a[1]; v.w[2] = b[0]; v.w[3] = b[1];
     v.w[4] = c[0]; v.w[5] = c[1]; v.w[6] = d[0]; v.w[7] = d[1];
-#else
-    const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
-    v.w[0] = w00 * wx0; v.w[1] = w00 * wx1; v.w[2] = w01 * wx0; v.w[3] = w01 * wx1;
-    v.w[4] = w10 * wx0; v.w[5] = w10 * wx1; v.w[6] = w11 * wx0; v.w[7] = w11 * wx1;
-#endif
     // byte offset of row (jz, jy, jx): exact in fp32 (< 2^24), one conversion
     const float af = fmaf(jz, (float)(4 * kSrcPlaneRows * kSrcStride),
                           fmaf(jy, (float)(4 * kSrcRowsY * kSrcStride), jx * (float)(4 * kSrcStride)));
@@ -375,43 +366,18 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
 #endif
 }
 
-// Both voxels of a lane (pass 0, pass 1) at once: x / y stay packed over the axes, and what is per-voxel scalar work in
-// hat_voxel -- the z coordinate, its offset and offset - 1, and the row address -- is packed over the two passes
-// (3 + 3 instructions per pair instead of per voxel).  Same arithmetic per element as hat_voxel.
-template <int Q>
-__device__ __forceinline__ void hat_voxel_pair(HatVoxel& v0, HatVoxel& v1, const float* srcT, const GatherHyp& h)
+// pass p of quarter Q, Q a compile-time constant (the one-wave-per-hypothesis kernels)
+template <int Q, bool XDL = false>
+__device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const GatherHyp& h, int p)
 {
-    const f32x2 qq = {(float)Q, (float)Q};
-    const f32x2 ia = Q == 0 ? h.ixy[0] : __builtin_elementwise_fma(qq, h.dqxy, h.ixy[0]);
-    const f32x2 ib = Q == 0 ? h.ixy[1] : __builtin_elementwise_fma(qq, h.dqxy, h.ixy[1]);
-    const f32x2 iz = Q == 0 ? h.izp : __builtin_elementwise_fma(qq, f32x2{h.dqz, h.dqz}, h.izp);
-    const float jxa = __builtin_amdgcn_fmed3f(floorf(ia[0]), 0.0f, 6.0f), jya = __builtin_amdgcn_fmed3f(floorf(ia[1]), 0.0f, 6.0f);
-    const float jxb = __builtin_amdgcn_fmed3f(floorf(ib[0]), 0.0f, 6.0f), jyb = __builtin_amdgcn_fmed3f(floorf(ib[1]), 0.0f, 6.0f);
-    const float jza = __builtin_amdgcn_fmed3f(floorf(iz[0]), 0.0f, 6.0f), jzb = __builtin_amdgcn_fmed3f(floorf(iz[1]), 0.0f, 6.0f);
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 ua = ia - f32x2{jxa, jya}, ub = ib - f32x2{jxb, jyb}, uz = iz - f32x2{jza, jzb};
-    const f32x2 ta = ua - one, tb = ub - one, tz = uz - one;
-    auto weights = [](HatVoxel& v, float ux, float uy, float uzz, float tx, float ty, float tzz) {
-        const float wx0 = clamp01(1.0f - fabsf(ux)), wy0 = clamp01(1.0f - fabsf(uy)), wz0 = clamp01(1.0f - fabsf(uzz));
-        const float wx1 = clamp01(1.0f - fabsf(tx)), wy1 = clamp01(1.0f - fabsf(ty)), wz1 = clamp01(1.0f - fabsf(tzz));
-        const f32x2 wy = {wy0, wy1}, wx = {wx0, wx1};
-        const f32x2 w0y = wz0 * wy, w1y = wz1 * wy;
-        const f32x2 a = w0y[0] * wx, b = w0y[1] * wx, c = w1y[0] * wx, d = w1y[1] * wx;
-        v.w[0] = a[0]; v.w[1] = a[1]; v.w[2] = b[0]; v.w[3] = b[1];
-        v.w[4] = c[0]; v.w[5] = c[1]; v.w[6] = d[0]; v.w[7] = d[1];
-    };
-    weights(v0, ua[0], ua[1], uz[0], ta[0], ta[1], tz[0]);
-    weights(v1, ub[0], ub[1], uz[1], tb[0], tb[1], tz[1]);
-    // byte offsets of the two rows (jz, jy, jx): exact in fp32 (< 2^24)
-    const f32x2 af = __builtin_elementwise_fma(
-        f32x2{jza, jzb}, f32x2{(float)(4 * kSrcPlaneRows * kSrcStride), (float)(4 * kSrcPlaneRows * kSrcStride)},
-        __builtin_elementwise_fma(f32x2{jya, jyb}, f32x2{(float)(4 * kSrcRowsY * kSrcStride), (float)(4 * kSrcRowsY * kSrcStride)},
-                                  f32x2{jxa, jxb} * f32x2{(float)(4 * kSrcStride), (float)(4 * kSrcStride)}));
-    v0.base = reinterpret_cast<const char*>(srcT) + (unsigned)af[0];
-    v1.base = reinterpret_cast<const char*>(srcT) + (unsigned)af[1];
-#ifdef AHV_DIAG_LINEAR_GATHER
-    v0.base = v1.base = reinterpret_cast<const char*>(srcT) + (threadIdx.x & 63) * (4 * kSrcStride);
-#endif
+    hat_voxel_at<XDL>(v, srcT, Q == 0 ? h.ixy[p] : __builtin_elementwise_fma(f32x2{(float)Q, (float)Q}, h.dqxy, h.ixy[p]),
+                      Q == 0 ? h.izp[p] : fmaf((float)Q, h.dqz, h.izp[p]));
+}
+
+// the same with the quarter known only at run time (wave-uniform: ahv_team.h, one quarter per wave)
+__device__ __forceinline__ void hat_voxel_rt(HatVoxel& v, const float* srcT, const GatherHyp& h, int p, float qf)
+{
+    hat_voxel_at<false>(v, srcT, __builtin_elementwise_fma(f32x2{qf, qf}, h.dqxy, h.ixy[p]), fmaf(qf, h.dqz, h.izp[p]));
 }
 
 // Quarter Q of the rotated volume into `buf`.  The two voxels of a lane (passes 0, 1) are blended as ONE stream
@@ -420,10 +386,7 @@ __device__ __forceinline__ void hat_voxel_pair(HatVoxel& v0, HatVoxel& v1, const
 // conflicts, and leaves the rest to the partner wave.  The stream is cut in two so that its head can be issued
 // from inside the PREVIOUS quarter's GEMM (hat_prologue: coordinates, weights and the first kHatDepth row
 // requests, placed ahead of that GEMM's last MFMA chunk), which hides the gather's start-up round trip as well.
-#ifndef AHV_HAT_DEPTH
-#define AHV_HAT_DEPTH 6
-#endif
-constexpr int kHatDepth = AHV_HAT_DEPTH;
+constexpr int kHatDepth = 6;  // depths 4 and 8 measured slower (round 2)
 static_assert(kHatDepth >= 1 && kHatDepth <= 8, "the prologue requests rows of pass 0 only");
 
 struct HatState {
@@ -485,15 +448,19 @@ __device__ __forceinline__ void hat_prologue_mirror(HatState& st, const float* s
 template <int Q, bool XDL = false>
 __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
 {
-#ifdef AHV_HAT_VOXEL_PAIR  // A/B knob of tools/kbench: 24 instructions fewer per hypothesis and SLOWER (0.6911 vs 0.6880 ms
-    // per 50 000 hypotheses, same box): the first six row requests then wait for the set-up of BOTH voxels
-    hat_voxel_pair<Q>(st.vx[0], st.vx[1], srcT, h);
-    HatRequests<0, kHatDepth>::run(st);
-#else
+    // voxel 0, its first row requests, THEN voxel 1: setting both voxels up together (packed over the two passes, 24
+    // instructions fewer per hypothesis) was measured slower -- 0.6911 vs 0.6880 ms per 50 000 hypotheses, round 3 -- the
+    // first six row requests then wait for both set-ups
     hat_voxel<Q, XDL>(st.vx[0], srcT, h, 0);
     HatRequests<0, kHatDepth>::run(st);
     hat_voxel<Q, XDL>(st.vx[1], srcT, h, 1);
-#endif
+}
+
+__device__ __forceinline__ void hat_prologue_rt(HatState& st, const float* srcT, const GatherHyp& h, float qf)
+{
+    hat_voxel_rt(st.vx[0], srcT, h, 0, qf);
+    HatRequests<0, kHatDepth>::run(st);
+    hat_voxel_rt(st.vx[1], srcT, h, 1, qf);
 }
 
 // Where a blended voxel goes.  ROW = floats between the channel planes of the destination image (128: the
@@ -549,13 +516,9 @@ __device__ __forceinline__ void hat_body(HatState& st, float* buf, const GatherD
 {
     f32x2 o[8];
     const HatStoreF32<128> store = {{buf + (MIR ? dst.m0 : dst.o0), buf + (MIR ? dst.m1 : dst.o1)}};
-#if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
-#endif
     HatSteps<0, HatStoreF32<128>, MIR>::run(st, o, store);
-#if AHV_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // the same into a LINEAR image X[c][voxel = a0*64 + b*8 + e] with ROW floats per channel plane (backward kernels)
@@ -634,10 +597,7 @@ __device__ __forceinline__ void g1_mfma(f32x4 (&acc)[2][4], const G1Chunk& ck)
 
 // `hook` runs once, ahead of the MFMAs of chunk kG1HookChunk (the fused scorer passes the next quarter's
 // gather prologue, whose LDS round trip then elapses under the remaining MFMAs of this quarter).
-#ifndef AHV_G1_HOOK
-#define AHV_G1_HOOK 10
-#endif
-constexpr int kG1HookChunk = AHV_G1_HOOK;
+constexpr int kG1HookChunk = 10;  // chunks 8 and 11 measured slower (round 2)
 
 template <int Q, int K>
 struct G1Pipe {
@@ -647,15 +607,7 @@ struct G1Pipe {
     {
         G1Chunk nxt;
         if (K + 1 < 12) g1_load<Q, K + 1>(nxt, T, buf, i0, j, kq);
-        if (K == kG1HookChunk) {
-#if AHV_PRIO == 3
-            __builtin_amdgcn_s_setprio(1);
-#endif
-            hook();
-#if AHV_PRIO == 3
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
+        if (K == kG1HookChunk) hook();
         __builtin_amdgcn_sched_barrier(0);
         g1_mfma<Q, K>(acc, cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -678,17 +630,7 @@ __device__ __forceinline__ void gemm1_quarter_pipe(f32x4 (&acc)[2][4], const flo
     const f32x4* T = reinterpret_cast<const f32x4*>(table) + lane;
     G1Chunk first;
     g1_load<Q, 0>(first, T, buf, i0, j, kq);
-#if AHV_PRIO == 2
-    __builtin_amdgcn_s_setprio(1);
-#elif AHV_PRIO >= 3   // everything but GEMM1 runs at priority 1 (set once before the hypothesis loop)
-    __builtin_amdgcn_s_setprio(0);
-#endif
     G1Pipe<Q, 0>::run(acc, first, T, buf, i0, j, kq, hook);
-#if AHV_PRIO == 2
-    __builtin_amdgcn_s_setprio(0);
-#elif AHV_PRIO >= 3
-    __builtin_amdgcn_s_setprio(1);
-#endif
 }
 
 }  // namespace ahv

@@ -212,10 +212,8 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
     static_assert(MODE == 0 || MODE == 1, "MODE 2 (3-D taps) stays with linear_kernel");
     static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
     constexpr int NS = KC / kStageK;  // stages
-#ifndef AHV_STAGED_DEPTH
-#define AHV_STAGED_DEPTH 2
-#endif
-    constexpr int DEPTH = AHV_STAGED_DEPTH < NS ? AHV_STAGED_DEPTH : NS;  // stages requested ahead of their use
+    constexpr int DEPTH = 2 < NS ? 2 : NS;  // stages requested ahead of their use (3, 4, 8 measured: 319.7 / 323.9 / 323.9 us
+                                            // per forward against 318.5 at 2, round 3)
     // two stage buffers (26 KB each at NT = 2): 2 workgroups per CU once M > 64.  (Three buffers with the next
     // stage's fragments read ahead of the MFMAs were measured: equal at B = 1, 5-14 % slower at B = 2..8.)
     __shared__ __attribute__((aligned(16))) float sx[2][64 * kStageLd];

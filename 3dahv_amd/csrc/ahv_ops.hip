@@ -444,17 +444,17 @@ __global__ __launch_bounds__(256) void score_features_kernel(const float* __rest
 // arg-max over materialised scores (test_co3d.py:145), same packed key as the fused path.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ scores, int B, long N,
-                                                     long n_offset, unsigned long long* __restrict__ best_key)
+                                                     long n_offset, key_t* __restrict__ best_key)
 {
     const int b = blockIdx.y;
     const float* s = scores + (long)b * N;
-    unsigned long long best = 0ull;
+    key_t best = kKeyEmpty;
     for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
-        const unsigned long long k = pack_key(s[n], (unsigned)(n_offset + n));
+        const key_t k = pack_key(s[n], (unsigned)(n_offset + n));
         best = k > best ? k : best;
     }
-    best = wave_max_u64(best);
-    if ((threadIdx.x & 63) == 0 && best != 0ull) atomicMax(best_key + b, best);
+    best = wave_max_key(best);
+    if ((threadIdx.x & 63) == 0 && best != kKeyEmpty) atomicMax(best_key + b, best);
 }
 
 // ---------------------------------------------------------------------------------
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ s
 // set): refinement hypotheses R_fine[b][n] = R[idx_b] * D[n], where idx_b is decoded on the device from
 // the packed key of the coarse stage and D is a fixed set of small rotations.  Graph-capturable.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void compose_rotations_kernel(const unsigned long long* __restrict__ best_key,
+__global__ __launch_bounds__(256) void compose_rotations_kernel(const key_t* __restrict__ best_key,
                                                                 const float* __restrict__ R, long r_batch_stride,
                                                                 long n_offset, long N, const float* __restrict__ D,
                                                                 long N2, int B, float* __restrict__ out)
@@ -471,9 +471,9 @@ __global__ __launch_bounds__(256) void compose_rotations_kernel(const unsigned l
     if (i >= (long)B * N2) return;
     const int b = (int)(i / N2);
     const long n = i - (long)b * N2;
-    const unsigned long long key = best_key[b];
-    long idx = (long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) - n_offset;
-    idx = (key == 0ull || idx < 0 || idx >= N) ? 0 : idx;  // nothing scored / foreign shard: stay in bounds
+    const key_t key = best_key[b];
+    long idx = key_index(key) - n_offset;
+    idx = (key == kKeyEmpty || idx < 0 || idx >= N) ? 0 : idx;  // nothing scored / foreign shard: stay in bounds
     const float* r = R + (long)b * r_batch_stride + idx * 9;
     const float* d = D + n * 9;
     float* o = out + i * 9;
@@ -483,21 +483,23 @@ __global__ __launch_bounds__(256) void compose_rotations_kernel(const unsigned l
         for (int c = 0; c < 3; ++c) o[a * 3 + c] = r[a * 3] * d[c] + r[a * 3 + 1] * d[3 + c] + r[a * 3 + 2] * d[6 + c];
 }
 
-// unpack + gather in one launch: (best score, global index, R_pred = R[idx]) of test_co3d.py:145-146
-__global__ void select_rotation_kernel(const unsigned long long* __restrict__ best_key, const float* __restrict__ R,
-                                       long r_batch_stride, long n_offset, long N, int B,
-                                       float* __restrict__ R_out, float* __restrict__ best_score,
-                                       long* __restrict__ best_idx)
+// unpack + gather in one launch: (best score, global index, R_pred = R[idx]) of test_co3d.py:145-146.
+// reset: the key is handed back EMPTY, ready for the next verify step's atomic max (the step then needs no launch
+// of its own to clear it: stream order puts this kernel between the two scorers).
+__global__ void select_rotation_kernel(key_t* __restrict__ best_key, const float* __restrict__ R, long r_batch_stride,
+                                       long n_offset, long N, int B, float* __restrict__ R_out,
+                                       float* __restrict__ best_score, long* __restrict__ best_idx, bool reset)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const unsigned long long k = best_key[b];
-    const long gidx = (k == 0ull) ? -1l : (long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
-    if (best_score) best_score[b] = (k == 0ull) ? -INFINITY : key_score(k);
+    const key_t k = best_key[b];
+    if (reset) best_key[b] = kKeyEmpty;
+    const long gidx = (k == kKeyEmpty) ? -1l : key_index(k);
+    if (best_score) best_score[b] = (k == kKeyEmpty) ? -INFINITY : key_score(k);
     if (best_idx) best_idx[b] = gidx;
     if (R_out) {
         const long loc = gidx - n_offset;
-        const bool mine = (k != 0ull) && loc >= 0 && loc < N;  // with sharding only the owner rank holds the row
+        const bool mine = (k != kKeyEmpty) && loc >= 0 && loc < N;  // with sharding only the owner rank holds the row
         const float* r = R + (long)b * r_batch_stride + (mine ? loc : 0) * 9;
 #pragma unroll
         for (int e = 0; e < 9; ++e) R_out[b * 9 + e] = mine ? r[e] : 0.0f;
@@ -646,24 +648,24 @@ hipError_t launch_score_features(const float* f_src, const float* f_tgt, int B, 
     return hipGetLastError();
 }
 
-hipError_t launch_compose_rotations(const uint64_t* best_key, const float* R, int64_t r_batch_stride,
+hipError_t launch_compose_rotations(const int64_t* best_key, const float* R, int64_t r_batch_stride,
                                     int64_t n_offset, int64_t N, const float* D, int64_t N2, int B, float* out,
                                     hipStream_t stream)
 {
     const long total = (long)B * N2;
     hipLaunchKernelGGL(compose_rotations_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const unsigned long long*>(best_key), R, (long)r_batch_stride,
-                       (long)n_offset, (long)N, D, (long)N2, B, out);
+                       reinterpret_cast<const key_t*>(best_key), R, (long)r_batch_stride, (long)n_offset, (long)N, D,
+                       (long)N2, B, out);
     return hipGetLastError();
 }
 
-hipError_t launch_select_rotation(const uint64_t* best_key, const float* R, int64_t r_batch_stride,
-                                  int64_t n_offset, int64_t N, int B, float* R_out, float* best_score,
-                                  int64_t* best_idx, hipStream_t stream)
+hipError_t launch_select_rotation(int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                                  int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, bool reset,
+                                  hipStream_t stream)
 {
     hipLaunchKernelGGL(select_rotation_kernel, dim3((B + 63) / 64), dim3(64), 0, stream,
-                       reinterpret_cast<const unsigned long long*>(best_key), R, (long)r_batch_stride,
-                       (long)n_offset, (long)N, B, R_out, best_score, reinterpret_cast<long*>(best_idx));
+                       reinterpret_cast<key_t*>(best_key), R, (long)r_batch_stride, (long)n_offset, (long)N, B, R_out,
+                       best_score, reinterpret_cast<long*>(best_idx), reset);
     return hipGetLastError();
 }
 
@@ -681,14 +683,27 @@ hipError_t launch_so3_grid(int64_t n_total, int64_t offset, int64_t N, float* ou
     return hipGetLastError();
 }
 
-hipError_t launch_argmax(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key,
+hipError_t launch_argmax(const float* scores, int B, int64_t N, int64_t n_offset, int64_t* best_key,
                          int num_cu, hipStream_t stream)
 {
     long bx = (N + 255) / 256;
     const long cap = num_cu * 4 / (B < num_cu ? B : num_cu) + 1;
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, scores, B, (long)N,
-                       (long)n_offset, reinterpret_cast<unsigned long long*>(best_key));
+                       (long)n_offset, reinterpret_cast<key_t*>(best_key));
+    return hipGetLastError();
+}
+
+// best_key[0..B) = EMPTY (below every real key): one tiny launch, graph-capturable
+__global__ void fill_keys_kernel(key_t* __restrict__ k, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) k[b] = kKeyEmpty;
+}
+
+hipError_t launch_fill_keys(int64_t* best_key, int B, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fill_keys_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, reinterpret_cast<key_t*>(best_key), B);
     return hipGetLastError();
 }
 

@@ -10,10 +10,14 @@
 // ~one workgroup per CU; blockIdx.y strides over the batch, (blockIdx.x, wave) strides over hypotheses;
 // one wave owns one hypothesis, no barrier on the hot path.  LDS per workgroup (158 KiB): source image
 // 46 KiB + W1 fragment table 48 KiB + 8 x 8 KiB private quarter images (ahv_dual.h).
-// Two kernels: score_hypotheses_dual_kernel<false> (all fp32, the default) and <true> (GEMM1 as split-f16
-// MFMA products, opt-in through AHV_SCORE_SPLIT_F16; ahv_split.h).
+// Three instances: score_hypotheses_dual_kernel<false, false> (all fp32, the default), <false, true> (the same with the
+// target features forward_3d2d(vol_tgt) built inside the launch: ahv_verify_pair_f32) and <true, false> (GEMM1 as
+// split-f16 MFMA products, opt-in through AHV_SCORE_SPLIT_F16; ahv_split.h).  The remainder of a launch that fills
+// less than a quarter of the wave slots is scored by TEAMS of four waves per hypothesis (ahv_team.h).
 #include "ahv_dual.h"
 #include "ahv_split.h"
+#include "ahv_team.h"
+#include "ahv_launch.h"
 
 namespace ahv {
 
@@ -72,11 +76,7 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
     // <v, tg> / max(|v|, 1e-12) (F.normalize's eps) as <v, tg> * rsq(max(|v|^2, 1e-24)): v_max + v_rsq + v_mul instead of a
     // correctly rounded sqrt and an IEEE division (~20 instructions of scaling and fix-up); v_rsq_f32 is good to 1 ulp,
     // the cosine to ~2e-7 relative, three orders inside the parity bar
-#ifdef AHV_NO_RSQ
-    const float c = d1 / fmaxf(sqrtf(s1), 1e-12f);
-#else
     const float c = d1 * __builtin_amdgcn_rsqf(fmaxf(s1, 1e-24f));
-#endif
     const float tot = wave_sum_dpp(c);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63)) * (1.0f / 64.0f);
 }
@@ -102,19 +102,24 @@ __device__ unsigned long long g_wgclk[1024 * 2];  // s_memtime at loop start / e
 constexpr int kDualThreads = 512;
 
 // SPLIT = true: GEMM1 on the f16 matrix pipe with hi/lo split operands (ahv_split.h; AHV_SCORE_SPLIT_F16).
-template <bool SPLIT>
+// TGT = true: `tgt` is the target VOLUME [B][16][8][8][8] and team 1 of every workgroup builds forward_3d2d of it while
+// the other waves are on their first hypothesis (ahv_verify_pair_f32); else `tgt` = the features [B][32][64].
+// Hypotheses [0, n_main) go to single waves, [n_main, N) to teams of four (n_main = N: no teams).
+template <bool SPLIT, bool TGT>
 __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
-    const float* __restrict__ vol_src, const float* __restrict__ feat_tgt, const float* __restrict__ R,
+    const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
     long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
-    const float* __restrict__ b2, int B, long N, float* __restrict__ scores,
-    unsigned long long* __restrict__ best_key, unsigned long long* __restrict__ clk)
+    const float* __restrict__ b2, int B, long N, long n_main, float* __restrict__ scores,
+    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, unsigned long long* __restrict__ clk)
 {
+    static_assert(!(SPLIT && TGT), "the split-f16 kernel takes ready-made target features");
     // The source image goes FIRST in LDS (the backend lays the arrays out by descending alignment): the gather builds
     // a row's byte offset in fp32 and converts it once, so with the image at LDS address 0 the offset IS the address
     // (it sat at 0x1c000, too far for the 16-bit immediate of ds_read: one v_add_u32 per voxel).
     __shared__ __attribute__((aligned(1024))) float lds_src[kSrcFloats];
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
     __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
+    __shared__ TeamSync lds_team;  // 84 of the 512 bytes the three images leave
 #ifdef AHV_DIAG_CODE_SHIFT  // diagnostic builds only (tools/first_launch.cpp): moves all the code below by 4 bytes per unit,
     // i.e. to another position inside the 64-byte instruction-fetch lines
     asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(AHV_DIAG_CODE_SHIFT));
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const unsigned long long wg_t_entry = __builtin_amdgcn_s_memrealtime();
     unsigned long long wg_t_loop = 0;
 #endif
+    if (!SPLIT && tid < (int)(sizeof(TeamSync) / 4)) reinterpret_cast<unsigned*>(&lds_team)[tid] = 0u;
     int w1_exp = 0;
     if (SPLIT) {
         float m = 0.0f;
@@ -142,6 +148,9 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     }
     DualFrags f0;
     if (!SPLIT) load_dual_frags(f0, W2, b2, lane);
+    const int team = wave >> 2, member = wave & 3;
+    unsigned team_rounds = 0;  // exchanges this wave's team has completed (wave-uniform; the counters of TeamSync only grow)
+    unsigned samples_done = 0;
     const GatherLane glane = gather_lane(lane);
     const GatherDst gdst = gather_dst_swizzled(lane);
     const SplitDst sdst = split_dst(lane);
@@ -174,8 +183,8 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // Target features as the per-lane fragments the score needs, parked in the 16-byte pad of source
         // rows 0..511 (row (2t + m2)*64 + lane): 32 registers less per wave, and the 80-byte row stride
         // makes the eight ds_read_b128 of the epilogue conflict-free.
-        {
-            const float* ft = feat_tgt + (long)b * (32 * 64);
+        if (!TGT) {
+            const float* ft = tgt + (long)b * (32 * 64);
             const int l = tid & 63, t = tid >> 7, m2 = (tid >> 6) & 1;
             f32x4 x;
 #pragma unroll
@@ -183,43 +192,70 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             *reinterpret_cast<f32x4*>(lds_src + tid * kSrcStride + 16) = x;
         }
         __syncthreads();
-
-#ifdef AHV_DUAL_STAGGER
-        // Waves 4-7 (the second wave of each SIMD) start late, so that the two waves of a SIMD sit in
-        // complementary phases (one gathers while the other contracts) instead of in lockstep.
-        if (wave >= 4) {
+        bool tg_ready = !TGT;
+        if constexpr (TGT) {
+            // forward_3d2d(vol_tgt[b]) (test_co3d.py:141, modules/modules.py:112-124) by team 1, one quarter per wave, while
+            // team 0 is on its first hypotheses: each member stages its un-rotated quarter straight from global memory
+            // (R = I needs no gather), contracts it, the members exchange the z partials and member t finishes position
+            // tile t and parks ITS eight rows of the fragment layout above.  Everybody else meets the result at the first
+            // use (tg_wait below); the ~0.2 hypotheses' worth of work lands on the four waves that have one hypothesis
+            // less than their SIMD partners whenever the last round is partial.
+            if (team == 1) {
+                stage_quarter_global(buf, tgt + (long)b * (16 * 512), member, lane);
+                wave_lds_fence();
+                TeamAcc ta;
+                gemm1_quarter_team(ta, lds_w1, buf, lane, member);
+                wave_lds_fence();
+                f32x4 u[2], v[2];
+                team_exchange(u, ta, lds_q + 4 * kQuarterFloats, lds_team, 1, member, team_rounds, lane);
+                ++team_rounds;
+                const float inv = 1.0f / fmaxf(sqrtf(team_head(v, u, f0)), 1e-12f);  // F.normalize(dim=1), eps 1e-12
 #pragma unroll
-            for (int i = 0; i < AHV_DUAL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const f32x4 x = v[m2] * inv;
+                    *reinterpret_cast<f32x4*>(lds_src + ((2 * member + m2) * 64 + lane) * kSrcStride + 16) = x;
+                    if (feat_tgt_out != nullptr && blockIdx.x == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            feat_tgt_out[(long)b * (32 * 64) + (16 * m2 + 4 * (lane >> 4) + r) * 64 + 16 * member + (lane & 15)] = x[r];
+                    }
+                }
+                team_signal(&lds_team.tgt_ready, lane);
+                team_wait(&lds_team.done[1], 4u * team_rounds);  // my image is free again (the teammates have read it)
+            }
         }
-#endif
+        auto tg_wait = [&]() {
+            if (TGT && !tg_ready) {
+                team_wait(&lds_team.tgt_ready, 4u * (samples_done + 1u));
+                tg_ready = true;
+            }
+        };
 #ifdef AHV_STAMPS
         wg_t_loop = __builtin_amdgcn_s_memrealtime();
         const unsigned long long wg_c_loop = __builtin_amdgcn_s_memtime();
 #endif
-        unsigned long long best = 0ull;
+        key_t best = kKeyEmpty;
         const float* Rb = R + (long)b * r_batch_stride;
+        const int residue = xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
         // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): the last, partial round of
         // the persistent grid then spreads over ALL CUs with few waves each (a lone wave on a SIMD runs
         // ~1.6x faster than a pair) instead of filling some CUs completely and leaving the rest idle.
-        long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        long h = (long)wave * gridDim.x + residue;
         // The rotation of the NEXT hypothesis travels as ONE vector load (lane i < 9 fetches element i) and is
         // broadcast with v_readlane at the top of the next iteration.  Not as scalar loads: SMEM shares lgkmcnt
         // with the LDS and returns out of order, so the first LDS wait behind an s_load has to wait for the s_load
         // too -- a first-touch read of R from HBM (~2 us) in front of every hypothesis' first gather step.
         const int rl = lane < 9 ? lane : 8;
-        float Rn = Rb[(h < N ? h : 0) * 9 + rl];
+        float Rn = Rb[(h < n_main ? h : 0) * 9 + rl];
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#if AHV_PRIO >= 3
-        if (!SPLIT) __builtin_amdgcn_s_setprio(1);
-#endif
-        for (; h < N; h += hstep) {
+        for (; h < n_main; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rn), i));
             {
-                const long hn = (h + hstep < N) ? h + hstep : h;
+                const long hn = (h + hstep < n_main) ? h + hstep : h;
                 Rn = Rb[hn * 9 + rl];
             }
             f32x4 acc[2][4];
@@ -273,6 +309,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 gemm1_quarter_pipe<2>(acc, lds_w1, buf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             }
 
+            tg_wait();
             f32x4 v[2][4];
             gemm2_dual(v, acc, f);
             AHV_TS(9)
@@ -284,7 +321,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                     tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
             const float s = hyp_score_rs<SPLIT>(v, tg, lane);
             if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
-            const unsigned long long key = pack_key(s, (unsigned)(n_offset + h));
+            const key_t key = pack_key(s, (unsigned)(n_offset + h));
             best = key > best ? key : best;
             AHV_TS(10)
 #ifdef AHV_STAMPS
@@ -292,13 +329,79 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             tsum[10] += 1;
 #endif
         }
+        if constexpr (!SPLIT) {
+            // The remainder [n_main, N): one hypothesis per TEAM (ahv_team.h).  Team slot g = team * gridDim.x + residue, so
+            // the remainder spreads over all workgroups first and over their second team next.  Every member runs the same
+            // rounds; member 0 emits the score of round r after the arrive point of round r + 1 (or of the flush below),
+            // where the four partial means of round r are known to be in place.
+            const long tstep = 2l * gridDim.x;
+            long ht = n_main + (long)team * gridDim.x + residue;
+            if (ht < N) {
+                long h_prev = -1;
+                for (; ht < N; ht += tstep) {
+                    const float Rv = Rb[ht * 9 + rl];
+                    float Rm[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rv), i));
+                    GatherHyp gh;
+                    gather_hyp(gh, Rm, glane);
+                    HatState st;
+                    hat_prologue_rt(st, srcT, gh, (float)member);
+                    team_wait(&lds_team.done[team], 4u * team_rounds);  // the image is free: last round's partials have been read
+                    hat_body(st, buf, gdst);
+                    wave_lds_fence();
+                    TeamAcc ta;
+                    gemm1_quarter_team(ta, lds_w1, buf, lane, member);
+                    wave_lds_fence();
+                    f32x4 u[2], v[2];
+                    team_exchange(u, ta, lds_q + 4 * team * kQuarterFloats, lds_team, team, member, team_rounds, lane);
+                    if (member == 0 && h_prev >= 0) {  // behind the arrive point of this round: last round's partials are complete
+                        const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
+                        const float sc = ((pp[0] + pp[1]) + (pp[2] + pp[3])) * (1.0f / 64.0f);
+                        if (scores != nullptr && lane == 0) scores[(long)b * N + h_prev] = sc;
+                        const key_t key = pack_key(sc, (unsigned)(n_offset + h_prev));
+                        best = key > best ? key : best;
+                    }
+                    tg_wait();
+                    const float ss = team_head(v, u, f);
+                    float dt = 0.0f;
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(lds_src + ((2 * member + m2) * 64 + lane) * kSrcStride + 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dt = fmaf(v[m2][r], g[r], dt);
+                    }
+                    dt += __shfl_xor(dt, 16, 64);
+                    dt += __shfl_xor(dt, 32, 64);
+                    // the four lane rows hold the same 16 columns: row 0 alone enters the sum over positions
+                    const float c = lane < 16 ? dt * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)) : 0.0f;
+                    const float tot = wave_sum_dpp(c);
+                    if (lane == 63) lds_team.part[team][team_rounds & 1u][member] = tot;
+                    ++team_rounds;
+                    h_prev = ht;
+                }
+                // flush: one more meeting point, then member 0 emits the last round's score
+                team_signal(&lds_team.arrive[team], lane);
+                team_wait(&lds_team.arrive[team], 4u * (team_rounds + 1u));
+                if (member == 0) {
+                    const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
+                    const float sc = ((pp[0] + pp[1]) + (pp[2] + pp[3])) * (1.0f / 64.0f);
+                    if (scores != nullptr && lane == 0) scores[(long)b * N + h_prev] = sc;
+                    const key_t key = pack_key(sc, (unsigned)(n_offset + h_prev));
+                    best = key > best ? key : best;
+                }
+                team_signal(&lds_team.done[team], lane);  // keeps arrive and done in step: one of each per meeting point
+                ++team_rounds;
+            }
+        }
+        ++samples_done;
 #ifdef AHV_STAMPS
         if (lane == 0) {
             const int gw = (blockIdx.x * 8 + wave) & 2047;
             for (int i = 0; i < 11; ++i) g_stamps[gw * 16 + i] = tsum[i];
         }
 #endif
-        if (best_key != nullptr && lane == 0 && best != 0ull) atomicMax(best_key + b, best);
+        if (best_key != nullptr && lane == 0 && best != kKeyEmpty) atomicMax(best_key + b, best);
 #ifdef AHV_STAMPS
         __syncthreads();
         if (tid == 0) {
@@ -324,14 +427,14 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     }
 }
 
-__global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_key, int B,
-                                   float* __restrict__ best_score, long* __restrict__ best_idx)
+__global__ void unpack_best_kernel(const key_t* __restrict__ best_key, int B, float* __restrict__ best_score,
+                                   long* __restrict__ best_idx)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const unsigned long long k = best_key[b];
-    if (best_score) best_score[b] = (k == 0ull) ? -INFINITY : key_score(k);
-    if (best_idx) best_idx[b] = (k == 0ull) ? -1l : (long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    const key_t k = best_key[b];
+    if (best_score) best_score[b] = (k == kKeyEmpty) ? -INFINITY : key_score(k);
+    if (best_idx) best_idx[b] = (k == kKeyEmpty) ? -1l : key_index(k);
 }
 
 }  // namespace ahv
@@ -339,46 +442,60 @@ __global__ void unpack_best_kernel(const unsigned long long* __restrict__ best_k
 // ---- host-side launchers (called by the C ABI in ahv_abi.hip) ----------------------
 namespace ahv {
 
-// Generic launch helper.
-template <typename K, typename... A>
-static hipError_t launch_score_kernel(K kernel, size_t lds, dim3 grid, int threads, hipStream_t stream, A... args)
+// How a launch covers N hypotheses with gx workgroups of 8 waves (per sample).  Hypotheses [0, n_main) go to single
+// waves, round after round of 8 * gx; the remainder goes to teams of four waves (ahv_team.h) when it would fill less
+// than a quarter of the wave slots: a lone last round costs a whole hypothesis' latency (~17 us with one wave per
+// SIMD, ~27 us with two) for a handful of hypotheses, a team round ~5-8 us.
+ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool teams)
 {
-    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, stream, args...);
+    ScorePlan p;
+    int avail = num_cu - spare_cu;
+    if (avail < 1) avail = 1;
+    p.gy = B < avail ? B : avail;
+    if (p.gy < 1) p.gy = 1;
+    int64_t gx = avail / p.gy;
+    // small N: spread over as many CUs as there is work for -- two hypotheses per workgroup when teams can take them
+    // (one per team), else four (one wave per SIMD runs a hypothesis ~1.6x faster than two waves sharing the SIMD)
+    const int64_t want = teams ? (N + 1) / 2 : (N + 3) / 4;
+    if (gx > want) gx = want;
+    if (gx < 1) gx = 1;
+    p.gx = (int)gx;
+    const int64_t slots = 8 * gx, full = N / slots, rem = N - full * slots;
+    p.n_main = (teams && rem > 0 && rem <= 2 * gx) ? full * slots : N;
+    return p;
+}
+
+hipError_t launch_score_hypotheses(const ScoreLaunch& a, hipStream_t stream)
+{
+    static_assert(sizeof(key_t) == sizeof(int64_t), "key width");
+    const bool teams = !a.split_f16 && !a.no_teams;
+    const ScorePlan p = plan_score_launch(a.B, a.N, a.num_cu, a.spare_cu, teams);
+    const dim3 grid(p.gx, p.gy), block(kDualThreads);
+    auto* key = reinterpret_cast<key_t*>(a.best_key);
+    auto* clk = reinterpret_cast<unsigned long long*>(a.clock_stamps);
+    if (a.split_f16) {
+        if (a.tgt_is_volume) return hipErrorInvalidValue;  // the ABI routes this case through forward_3d2d first
+        hipLaunchKernelGGL((score_hypotheses_dual_kernel<true, false>), grid, block, 0, stream, a.vol_src, a.tgt, a.R,
+                           (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
+                           key, a.feat_tgt_out, clk);
+    } else if (a.tgt_is_volume) {
+        hipLaunchKernelGGL((score_hypotheses_dual_kernel<false, true>), grid, block, 0, stream, a.vol_src, a.tgt, a.R,
+                           (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
+                           key, a.feat_tgt_out, clk);
+    } else {
+        hipLaunchKernelGGL((score_hypotheses_dual_kernel<false, false>), grid, block, 0, stream, a.vol_src, a.tgt, a.R,
+                           (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
+                           key, a.feat_tgt_out, clk);
+    }
     return hipGetLastError();
 }
 
-// split_f16: the opt-in kernel (AHV_SCORE_SPLIT_F16); clock_stamps: NULL, or [4 * num_cu] words for the
-// diagnostic entry point (per workgroup: s_memtime / s_memrealtime before and after its hypothesis loop).
-hipError_t launch_score_hypotheses(const float* vol_src, const float* feat_tgt, const float* R,
-                                   int64_t r_batch_stride, int64_t n_offset, const float* W1,
-                                   const float* W2, const float* b2, int B, int64_t N, float* scores,
-                                   uint64_t* best_key, int num_cu, bool split_f16, uint64_t* clock_stamps,
-                                   hipStream_t stream)
-{
-    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "key width");
-    // Persistent grid: ~one workgroup per CU.  y strides over the batch, x over hypotheses.
-    int gy = B < num_cu ? B : num_cu;
-    int gx = num_cu / gy;
-    const int64_t need_w = (N + 7) / 8;  // workgroups that can get at least one hypothesis per wave
-    if (gx > need_w) gx = (int)need_w;
-    if (gx < 1) gx = 1;
-    const dim3 grid(gx, gy);
-    auto* key = reinterpret_cast<unsigned long long*>(best_key);
-    auto* clk = reinterpret_cast<unsigned long long*>(clock_stamps);
-    if (split_f16)
-        return launch_score_kernel(score_hypotheses_dual_kernel<true>, 0, grid, kDualThreads, stream, vol_src, feat_tgt, R,
-                                   (long)r_batch_stride, (long)n_offset, W1, W2, b2, B, (long)N, scores, key, clk);
-    return launch_score_kernel(score_hypotheses_dual_kernel<false>, 0, grid, kDualThreads, stream, vol_src, feat_tgt, R,
-                               (long)r_batch_stride, (long)n_offset, W1, W2, b2, B, (long)N, scores, key, clk);
-}
-
-hipError_t launch_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx,
+hipError_t launch_unpack_best(const int64_t* best_key, int B, float* best_score, int64_t* best_idx,
                               hipStream_t stream)
 {
     const int threads = 64;
     hipLaunchKernelGGL(unpack_best_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, stream,
-                       reinterpret_cast<const unsigned long long*>(best_key), B, best_score,
-                       reinterpret_cast<long*>(best_idx));
+                       reinterpret_cast<const key_t*>(best_key), B, best_score, reinterpret_cast<long*>(best_idx));
     return hipGetLastError();
 }
 

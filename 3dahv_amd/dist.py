@@ -4,14 +4,14 @@ Hypotheses are independent given the per-pair constants (source volume, target
 feature, head weights: 94 KB, replicated on every rank), so N is partitioned
 contiguously: rank r scores [lo_r, hi_r) with ``n_offset = lo_r``.  The data
 path has ONE exchange: an all-reduce(max) of B packed 64-bit keys
-``(ordered_u32(score) << 32) | (0xFFFFFFFF - global_idx)``, i.e. 8*B bytes --
-latency-bound, bandwidth-irrelevant.  Unsigned max on the key = largest score,
+``(ordered_i32(score) << 32) | (0xFFFFFFFF - global_idx)``, i.e. 8*B bytes --
+latency-bound, bandwidth-irrelevant.  Signed max on the key = largest score,
 lowest global index among equal scores (torch.max semantics, test_co3d.py:145),
 independent of how N was split.
 
-torch has no unsigned 64-bit reductions, so keys travel as int64 XOR
-0x8000...0, which maps unsigned order onto signed order (works on ``nccl`` =
-RCCL and on ``gloo``).
+The kernels pack the key in SIGNED int64 order (include/ahv.h, "Packed keys"), which is
+what ``ReduceOp.MAX`` on an int64 tensor computes on ``nccl`` (= RCCL) and ``gloo`` alike:
+the all-reduce takes the key as it is, with no re-encoding launch on either side.
 """
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-_SIGN = -(1 << 63)
+KEY_EMPTY = -(1 << 63)  # AHV_KEY_EMPTY: below every real key ("nothing scored")
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -32,40 +32,39 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def merge_keys(keys: torch.Tensor) -> torch.Tensor:
-    """Unsigned max over dim 0 of packed int64 keys: (G,B) -> (B,)."""
-    return (keys ^ _SIGN).max(dim=0).values ^ _SIGN
+    """Max over dim 0 of packed int64 keys (what the all-reduce computes): (G,B) -> (B,)."""
+    return keys.max(dim=0).values
 
 
 def all_reduce_best(key: torch.Tensor, group=None) -> torch.Tensor:
     """In-place global merge of per-rank packed keys (B,) int64; returns ``key``."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        key.bitwise_xor_(_SIGN)
         dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
-        key.bitwise_xor_(_SIGN)
     return key
 
 
 # ---- host-side key codec (numpy): used by host logic and CPU tests ------------------
 
 def pack_keys_host(scores: np.ndarray, idx: np.ndarray) -> np.ndarray:
-    """Same packing as the device code (csrc/ahv_device.h pack_key); returns int64 bit patterns."""
+    """Same packing as the device code (csrc/ahv_device.h pack_key); returns int64 keys."""
     s = np.asarray(scores, dtype=np.float32) + np.float32(0.0)
     u = s.view(np.uint32).copy()
     u[np.isnan(s)] = np.uint32(0x7FC00000)
     neg = (u & np.uint32(0x80000000)) != 0
-    u = np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+    u = np.where(neg, u ^ np.uint32(0x7FFFFFFF), u).astype(np.uint64)
     k = (u << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.asarray(idx, dtype=np.uint64))
     return k.view(np.int64)
 
 
 def unpack_keys_host(keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    k = np.asarray(keys, dtype=np.int64).view(np.uint64)
+    ks = np.asarray(keys, dtype=np.int64)
+    k = ks.view(np.uint64)
     u = (k >> np.uint64(32)).astype(np.uint32)
-    pos = (u & np.uint32(0x80000000)) != 0
-    bits = np.where(pos, u & np.uint32(0x7FFFFFFF), ~u).astype(np.uint32)
+    neg = (u & np.uint32(0x80000000)) != 0
+    bits = np.where(neg, u ^ np.uint32(0x7FFFFFFF), u).astype(np.uint32)
     score = bits.view(np.float32).copy()
     idx = (np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64)
-    empty = k == 0
+    empty = ks == KEY_EMPTY
     score[empty] = -np.inf
     idx[empty] = -1
     return score, idx

@@ -6,6 +6,7 @@ Same names, argument meaning and error behaviour as the reference callables:
 * ``forward_3d2d(img_feat, W1, W2, b2)``  -- Feature_Aligner.forward_3d2d, modules/modules.py:112-124
 * ``score_features`` / ``argmax``  -- the inline lines test_co3d.py:143 / :145
 * ``score_hypotheses``  -- all of the above fused into one launch (test_co3d.py:137-145)
+* ``verify_pair``  -- the same with ``forward_3d2d(vol_tgt)`` (test_co3d.py:141) inside that launch
 * ``score_hypotheses_autograd`` / ``forward_3d2d_autograd`` / ``score_hypotheses_backward``  -- the same with
   autograd edges for training (infoNCE_loss, modules/model_co3d.py:41-61): HIP forward + HIP backward
 
@@ -197,7 +198,8 @@ def argmax(scores: torch.Tensor, n_offset: int = 0, return_key: bool = False):
 def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
                      W2: torch.Tensor, b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True,
                      best_key: torch.Tensor | None = None, reset_best: bool | None = None,
-                     split_f16: bool | None = None, clock_stamps: torch.Tensor | None = None):
+                     split_f16: bool | None = None, clock_stamps: torch.Tensor | None = None,
+                     no_teams: bool = False, spare_cus: int = 0):
     """Fused hot loop (one launch): returns ``(scores (B,N) or None, best_key (B,) int64)``.
 
     vol_src (B,16,8,8,8); feat_tgt (B,32,64) = forward_3d2d(vol_tgt); R (N,3,3) shared by the
@@ -207,6 +209,9 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
     Decode with ``unpack_best``; ``n_offset`` is the global index of R[0] when N is sharded.
     ``split_f16``: opt-in kernel for this call (None: the enclosing ``split_f16_scorer`` block, else fp32).
     ``clock_stamps`` (int64, 4 * CU count, zeroed): diagnostic launch that also records the shader clock.
+    ``no_teams``: AHV_SCORE_NO_TEAMS -- every hypothesis by one wave, so that a score does not depend (in its last
+    bits) on N or on the hypothesis' position; ``spare_cus``: compute units left without a workgroup of the persistent
+    grid (room for a concurrent small kernel, e.g. the previous step's RCCL all-reduce).
     With autograd recording and an input that requires grad, the returned scores carry the autograd edge of
     ``score_hypotheses_autograd`` (HIP backward) -- like the reference's op sequence, nothing is silently detached.
     """
@@ -215,15 +220,39 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
         return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2, n_offset, best_key, reset_best, split_f16)
     with torch.no_grad():
         return _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best,
-                                        split_f16, clock_stamps)
+                                        split_f16, clock_stamps, no_teams=no_teams, spare_cus=spare_cus)
+
+
+@torch.no_grad()
+def verify_pair(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor,
+                b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True, best_key: torch.Tensor | None = None,
+                reset_best: bool | None = None, split_f16: bool | None = None, want_feat_tgt: bool = False,
+                clock_stamps: torch.Tensor | None = None, no_teams: bool = False, spare_cus: int = 0):
+    """The whole per-pair verify step of test_co3d.py:137-145 behind ONE entry point (``ahv_verify_pair_f32``):
+    ``forward_3d2d(vol_tgt)`` is built inside the scoring launch instead of in a launch of its own.  Arguments as
+    ``score_hypotheses`` with the target VOLUME ``vol_tgt (B,16,8,8,8)`` in place of ``feat_tgt``.  Returns
+    ``(scores (B,N) or None, best_key (B,) int64)`` and, with ``want_feat_tgt``, the target features ``(B,32,64)`` as
+    third element (always materialised for the split-f16 kernel, which runs forward_3d2d as a launch of its own).
+    Inference only (no autograd edge)."""
+    _refuse_grad("verify_pair", vol_src, vol_tgt, W1, W2, b2)
+    if vol_tgt.dim() != 5 or tuple(vol_tgt.shape) != tuple(vol_src.shape):
+        raise RuntimeError("vol_tgt must have vol_src's shape (B,16,8,8,8), got %s" % (tuple(vol_tgt.shape),))
+    split = bool(_SPLIT_F16.get() if split_f16 is None else split_f16)
+    feat = None
+    if want_feat_tgt or split:
+        feat = torch.empty((vol_src.shape[0], 32, 64), dtype=torch.float32, device=vol_src.device)
+    scores, key = _score_hypotheses_nograd(vol_src, vol_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best,
+                                           split, clock_stamps, no_teams=no_teams, spare_cus=spare_cus, tgt_is_volume=True,
+                                           feat_tgt_out=feat)
+    return (scores, key, feat) if want_feat_tgt else (scores, key)
 
 
 def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best, split_f16,
-                             clock_stamps):
+                             clock_stamps, no_teams=False, spare_cus=0, tgt_is_volume=False, feat_tgt_out=None):
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
         raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
     B = vol_src.shape[0]
-    if tuple(feat_tgt.shape) != (B, 32, 64):
+    if not tgt_is_volume and tuple(feat_tgt.shape) != (B, 32, 64):
         raise RuntimeError("feat_tgt must be (B,32,64), got %s" % (tuple(feat_tgt.shape),))
     if R.dim() == 3 and tuple(R.shape[1:]) == (3, 3):
         N, rstride = R.shape[0], 0
@@ -243,17 +272,26 @@ def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_sc
     flags = _lib.AHV_SCORE_RESET_BEST if reset_best else 0
     if _SPLIT_F16.get() if split_f16 is None else split_f16:
         flags |= _lib.AHV_SCORE_SPLIT_F16
+    if no_teams:
+        flags |= _lib.AHV_SCORE_NO_TEAMS
+    if not 0 <= int(spare_cus) <= 255:
+        raise RuntimeError("spare_cus must be in 0..255")
+    flags |= int(spare_cus) << _lib.AHV_SCORE_SPARE_CUS_SHIFT
     lib = _lib.load()
-    args = (vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset, W1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
-            B, N, scores.data_ptr() if scores is not None else None, best_key.data_ptr(), flags)
+    head = (vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset, W1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+            B, N, scores.data_ptr() if scores is not None else None, best_key.data_ptr())
+    if clock_stamps is not None and (clock_stamps.dtype != torch.int64 or clock_stamps.device != dev or
+                                     clock_stamps.numel() < 4 * lib.ahv_device_cu_count()):
+        raise RuntimeError("clock_stamps must be an int64 tensor of 4 * CU-count elements on %s" % dev)
     with torch.cuda.device(dev):
-        if clock_stamps is None:
-            _lib.check(lib.ahv_score_hypotheses_f32(*args, _stream(dev)), "ahv_score_hypotheses_f32")
+        if tgt_is_volume:
+            _lib.check(lib.ahv_verify_pair_f32(*head, feat_tgt_out.data_ptr() if feat_tgt_out is not None else None, flags,
+                                               clock_stamps.data_ptr() if clock_stamps is not None else None,
+                                               _stream(dev)), "ahv_verify_pair_f32")
+        elif clock_stamps is None:
+            _lib.check(lib.ahv_score_hypotheses_f32(*head, flags, _stream(dev)), "ahv_score_hypotheses_f32")
         else:
-            if clock_stamps.dtype != torch.int64 or clock_stamps.device != dev or \
-                    clock_stamps.numel() < 4 * lib.ahv_device_cu_count():
-                raise RuntimeError("clock_stamps must be an int64 tensor of 4 * CU-count elements on %s" % dev)
-            _lib.check(lib.ahv_score_hypotheses_clocked_f32(*args, clock_stamps.data_ptr(), _stream(dev)),
+            _lib.check(lib.ahv_score_hypotheses_clocked_f32(*head, flags, clock_stamps.data_ptr(), _stream(dev)),
                        "ahv_score_hypotheses_clocked_f32")
     return scores, best_key
 
@@ -327,8 +365,9 @@ class _ScoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2, n_offset=0, best_key=None, reset_best=None, split_f16=None):
+        # single waves only: the backward differentiates exactly this forward (teams associate the sums differently)
         scores, key = _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, True, best_key, reset_best,
-                                               split_f16, None)
+                                               split_f16, None, no_teams=True)
         ctx.save_for_backward(vol_src, feat_tgt, R, W1, W2, b2)
         ctx.mark_non_differentiable(key)
         return scores, key
@@ -382,9 +421,19 @@ def _rot_layout(R: torch.Tensor, B: int):
 
 
 @torch.no_grad()
-def select_rotation(best_key: torch.Tensor, R: torch.Tensor, n_offset: int = 0):
+def reset_best(best_key: torch.Tensor) -> torch.Tensor:
+    """``best_key[:] = AHV_KEY_EMPTY`` (one tiny launch): a key tensor ready to be merged into."""
+    if best_key.dtype != torch.int64 or not best_key.is_cuda:
+        raise RuntimeError("best_key must be a GPU int64 tensor")
+    _call(best_key.device, "ahv_reset_best", best_key.data_ptr(), best_key.numel())
+    return best_key
+
+
+@torch.no_grad()
+def select_rotation(best_key: torch.Tensor, R: torch.Tensor, n_offset: int = 0, reset_key: bool = False):
     """(best_score (B,), best_idx (B,) global int64, R_pred (B,3,3)) in ONE launch:
-    ``pred_sim, pred_index = torch.max(...)``; ``proposals[pred_index]`` (test_co3d.py:145-146)."""
+    ``pred_sim, pred_index = torch.max(...)``; ``proposals[pred_index]`` (test_co3d.py:145-146).
+    ``reset_key``: hand ``best_key`` back EMPTY (AHV_SELECT_RESET_KEY), ready for the next step's scorer."""
     B = best_key.numel()
     _need_gpu(R)
     N, rstride = _rot_layout(R, B)
@@ -394,7 +443,7 @@ def select_rotation(best_key: torch.Tensor, R: torch.Tensor, n_offset: int = 0):
     idx = torch.empty((B,), dtype=torch.int64, device=dev)
     R_out = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
     _call(dev, "ahv_select_rotation_f32", best_key.data_ptr(), Rc.data_ptr(), rstride, n_offset, N, B,
-          R_out.data_ptr(), score.data_ptr(), idx.data_ptr())
+          R_out.data_ptr(), score.data_ptr(), idx.data_ptr(), _lib.AHV_SELECT_RESET_KEY if reset_key else 0)
     return score, idx, R_out
 
 

@@ -6,10 +6,10 @@ scores N2 refinements ``R* @ D[n]`` around each sample's stage-1 winner, where `
 small rotations (``rotations.refine_rotations(I, N2, max_angle)``; D[0] = I, so stage 2 can never
 score below stage 1).  Everything between the two stages stays on the device: the winner index is
 decoded from the packed key by ``ahv_compose_rotations_f32``; no host round trip, so the whole step
-(target features, 2 fused scorer launches, compose, select) replays from a graph.
+(2 fused scorer launches -- the first builds the target features in-launch --, compose, 2 selects) replays from a graph.
 
 Multi-rank (one process per GPU): both hypothesis sets are sharded contiguously (``dist.shard_range``);
-each stage ends in the 8*B-byte packed-key all-reduce(max) of ``dist.all_reduce_best`` -- two collectives per
+each stage ends in the 8*B-byte packed-key all-reduce(max) (int64 MAX on the key as the kernel packs it) -- two collectives per
 step; the winner's rotation row needs no exchange (every rank composes the full refinement set of the
 winner).  The verify semantics per stage
 are those of modules/model.py:183-196.  With the ``nccl`` backend (= RCCL) the collectives are enqueued on
@@ -24,19 +24,24 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .dist import all_reduce_best, shard_range
+from .dist import KEY_EMPTY, shard_range
 from .rotations import refine_rotations
 
 
 class CoarseToFine:
-    """``backend`` provides ``forward_3d2d, score_hypotheses, compose_rotations, select_rotation, unpack_best``
-    with the signatures of ``3dahv_amd.ops`` (the default and the only product backend: HIP kernels, no CPU
-    path); CPU tests inject an oracle-backed object to execute the multi-rank control flow under gloo."""
+    """``backend`` provides ``verify_pair, score_hypotheses, compose_rotations, select_rotation`` with the signatures of
+    ``3dahv_amd.ops`` (the default and the only product backend: HIP kernels, no CPU path); CPU tests inject an
+    oracle-backed object to execute the multi-rank control flow under gloo.
+
+    One step = FIVE launches: the coarse stage as one ``verify_pair`` launch (the target features are built inside it and
+    kept for the fine stage), ``compose_rotations``, the fine stage, and one ``select_rotation`` per stage, each of which
+    also hands its key back empty for the next step (no clearing launches).  ``no_teams`` makes every score independent
+    of how the hypothesis sets are split over ranks, bit for bit (``ops.score_hypotheses``)."""
 
     def __init__(self, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, R_coarse: torch.Tensor,
                  D: Optional[torch.Tensor] = None, n_fine: int = 1000, max_angle_deg: float = 10.0,
                  batch: int = 1, use_graph: bool = True, group=None, seed: int = 0, backend=None,
-                 want_scores: bool = False, force_collectives: bool = False):
+                 want_scores: bool = False, force_collectives: bool = False, no_teams: bool = False):
         dev = R_coarse.device
         self.ops = ops if backend is None else backend
         self.W1, self.W2, self.b2 = W1, W2, b2
@@ -48,6 +53,7 @@ class CoarseToFine:
         self.B = batch
         self.group = group
         self.want_scores = want_scores
+        self.no_teams = no_teams
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
         self.rank = dist.get_rank(group) if inited else 0
@@ -57,62 +63,77 @@ class CoarseToFine:
         self.f_lo, self.f_hi = shard_range(self.D.shape[0], self.rank, self.world)
         capturable = (not self.collectives) or (inited and dist.get_backend(group) == "nccl")
         self.use_graph = bool(use_graph and dev.type == "cuda" and capturable)
+        # the two keys live with the object: every step's select hands them back empty
+        self._keys = [torch.full((batch,), KEY_EMPTY, dtype=torch.int64, device=dev) for _ in range(2)]
+        self._R_fine = torch.empty((batch, self.D.shape[0], 3, 3), dtype=torch.float32, device=dev)
         self._graph = None
         self._static = None
 
     def _merge(self, key):
-        if self.collectives:
-            if self.world > 1:
-                all_reduce_best(key, self.group)
-            else:  # forced on a 1-rank group: same call sequence, same captured nodes
-                key.bitwise_xor_(-(1 << 63))
-                dist.all_reduce(key, op=dist.ReduceOp.MAX, group=self.group)
-                key.bitwise_xor_(-(1 << 63))
+        if self.collectives:  # world > 1, or forced on a 1-rank group: same call, same captured node
+            dist.all_reduce(key, op=dist.ReduceOp.MAX, group=self.group)
         return key
+
+    @property
+    def buffers(self):
+        """The static input volumes ``(vol_src, vol_tgt)`` of the captured step (allocated on first use).  A producer that
+        writes its volumes straight into them -- ``forward_2d3d(..., out=c2f.buffers)`` -- and then calls ``c2f()`` with no
+        arguments replays the graph with no staging copy."""
+        if self._static is None:
+            dev = self.R_coarse.device
+            self._static = tuple(torch.zeros((self.B, 16, 8, 8, 8), dtype=torch.float32, device=dev) for _ in range(2))
+        return self._static
 
     # ---- the step, written once; runs eagerly or under capture
     def _step(self, vol_src, vol_tgt):
         o = self.ops
-        f_tgt = o.forward_3d2d(vol_tgt, self.W1, self.W2, self.b2)
+        key1, key2 = self._keys
+        kw = {"no_teams": True} if self.no_teams else {}
         Rc = self.R_coarse[self.c_lo:self.c_hi]
-        s1, key1 = o.score_hypotheses(vol_src, f_tgt, Rc, self.W1, self.W2, self.b2, n_offset=self.c_lo,
-                                      want_scores=self.want_scores)
+        s1, _, f_tgt = o.verify_pair(vol_src, vol_tgt, Rc, self.W1, self.W2, self.b2, n_offset=self.c_lo,
+                                     want_scores=self.want_scores, best_key=key1, reset_best=False, want_feat_tgt=True, **kw)
         self._merge(key1)
         # Every rank holds the whole coarse set AND the whole refinement set D, so after the key all-reduce each
         # rank composes ALL N2 refinements of the winner locally (N2 * B threads) and scores its own slice of them.
         # After the second key all-reduce every rank knows both winning indices and already holds the winning
         # row: R_pred is a local gather -- two collectives per step, not three.
-        R_fine_all = o.compose_rotations(key1, self.R_coarse, self.D)
+        R_fine_all = o.compose_rotations(key1, self.R_coarse, self.D, out=self._R_fine)
         R_fine = R_fine_all if self.world == 1 else R_fine_all[:, self.f_lo:self.f_hi]
-        s2, key2 = o.score_hypotheses(vol_src, f_tgt, R_fine, self.W1, self.W2, self.b2, n_offset=self.f_lo,
-                                      want_scores=self.want_scores)
+        s2, _ = o.score_hypotheses(vol_src, f_tgt, R_fine, self.W1, self.W2, self.b2, n_offset=self.f_lo,
+                                   want_scores=self.want_scores, best_key=key2, reset_best=False, **kw)
         self._merge(key2)
-        score, idx, R_pred = o.select_rotation(key2, R_fine_all, n_offset=0)
-        coarse_score, coarse_idx = o.unpack_best(key1)
+        score, idx, R_pred = o.select_rotation(key2, R_fine_all, n_offset=0, reset_key=True)
+        coarse_score, coarse_idx, _ = o.select_rotation(key1, self.R_coarse, n_offset=0, reset_key=True)
         # this rank's slices of the two score sets and of the refinement set (None unless want_scores)
         self.last = {"coarse_scores": s1, "fine_scores": s2, "R_fine": R_fine if self.want_scores else None}
         return score, idx, R_pred, coarse_score, coarse_idx
 
     @torch.no_grad()
-    def __call__(self, vol_src: torch.Tensor, vol_tgt: torch.Tensor):
+    def __call__(self, vol_src: Optional[torch.Tensor] = None, vol_tgt: Optional[torch.Tensor] = None):
         """vol_src, vol_tgt (B,16,8,8,8) -> (fine score (B,), fine index (B,), R_pred (B,3,3),
         coarse score (B,), coarse index (B,)).  With ``use_graph`` the outputs are static buffers that
-        the next call overwrites."""
+        the next call overwrites; called with no arguments the step runs on ``self.buffers`` as they are."""
+        if (vol_src is None) != (vol_tgt is None):
+            raise RuntimeError("pass both volumes or neither")
         if not self.use_graph:
+            if vol_src is None:
+                vol_src, vol_tgt = self.buffers
             return self._step(vol_src, vol_tgt)
+        static = self.buffers
+        if vol_src is not None and vol_src.data_ptr() != static[0].data_ptr():
+            static[0].copy_(vol_src)
+        if vol_tgt is not None and vol_tgt.data_ptr() != static[1].data_ptr():
+            static[1].copy_(vol_tgt)
         if self._graph is None:
-            self._static = (vol_src.clone(), vol_tgt.clone())
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):  # warm-up outside capture (lazy initialisation inside the launchers / RCCL)
                 for _ in range(2):
-                    self._step(*self._static)
+                    self._step(*static)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._out = self._step(*self._static)
-        self._static[0].copy_(vol_src)
-        self._static[1].copy_(vol_tgt)
+                self._out = self._step(*static)
         self._graph.replay()
         return self._out

@@ -60,21 +60,47 @@ def random_rotations(n: int, dtype=torch.float32, device=None, generator: torch.
     return m.reshape(n, 3, 3).to(dtype)
 
 
+def _sincos_turns(f: np.ndarray):
+    """sin(2 pi f), cos(2 pi f) for f in [0, 1) from +, -, * alone (nearest octant + Taylor series on |x| <= pi/8):
+    correct to ~1e-16 and, unlike libm / SIMD sin and cos, bit-reproducible on every IEEE-754 machine -- the SHA-256 of
+    the grid is stored in a golden fixture and re-derived on another box."""
+    f = np.asarray(f, dtype=np.float64)
+    k = np.floor(f * 8.0 + 0.5)
+    x = (f - k * 0.125) * (2.0 * math.pi)
+    x2 = x * x
+    sn = np.ones_like(x)
+    cs = np.ones_like(x)
+    for m in range(9, 0, -1):  # Horner: sin x = x (1 - x2/(2.3) (1 - x2/(4.5) ...)), cos x = 1 - x2/(1.2) (1 - x2/(3.4) ...)
+        sn = 1.0 - sn * x2 * (1.0 / ((2 * m) * (2 * m + 1)))
+        cs = 1.0 - cs * x2 * (1.0 / ((2 * m - 1) * (2 * m)))
+    sn = sn * x
+    h = math.sqrt(0.5)
+    tab_s = np.array([0.0, h, 1.0, h, 0.0, -h, -1.0, -h])
+    tab_c = np.array([1.0, h, 0.0, -h, -1.0, -h, 0.0, h])
+    ki = k.astype(np.int64) & 7
+    s0, c0 = tab_s[ki], tab_c[ki]
+    return s0 * cs + c0 * sn, c0 * cs - s0 * sn
+
+
 def so3_grid_np(n: int) -> np.ndarray:
     """Deterministic, nearly uniform SO(3) grid of n rotations (super-Fibonacci spiral).
 
     Build-defined (the reference has no grid: test_linemod.py:43 samples randomly).
     Alexa, "Super-Fibonacci Spirals: Fast, Low-Discrepancy Sampling of SO(3)", CVPR 2022.
+    Point i is the quaternion (sqrt(t) sin a, sqrt(t) cos a, sqrt(1-t) sin b, sqrt(1-t) cos b) with t = (i + 1/2)/n,
+    a = 2 pi (i + 1/2)/sqrt(2), b = 2 pi (i + 1/2)/psi; the angles are reduced as turn fractions first (they reach
+    10^6 rad) and sin / cos come from ``_sincos_turns``, so the float32 result is the same bytes on every machine.
     """
-    phi = math.sqrt(2.0)
     psi = 1.533751168755204288118041
     i = np.arange(n, dtype=np.float64)
     s = i + 0.5
     t = s / n
-    d = 2.0 * math.pi * s
+    fa, fb = s * math.sqrt(0.5), s * (1.0 / psi)
+    fa, fb = fa - np.floor(fa), fb - np.floor(fb)
     r, R = np.sqrt(t), np.sqrt(1.0 - t)
-    alpha, beta = d / phi, d / psi
-    q = np.stack([r * np.sin(alpha), r * np.cos(alpha), R * np.sin(beta), R * np.cos(beta)], axis=1)
+    sa, ca = _sincos_turns(fa)
+    sb, cb = _sincos_turns(fb)
+    q = np.stack([r * sa, r * ca, R * sb, R * cb], axis=1)
     return quaternion_to_matrix_np(q).astype(np.float32)
 
 

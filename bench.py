@@ -3,13 +3,14 @@
 
 One "step" = the reference's per-pair hot loop (test_co3d.py:137-146) for ONE synthetic image
 pair with N_hyp = 50 000 hypotheses on each GPU (BASELINE.json configs[1]):
-    forward_3d2d(vol_tgt)                       1 small launch   (test_co3d.py:141)
-    clear the packed key                        1 tiny launch    (outside the kernel's event pair)
-    fused rotate + forward_3d2d + score + max   1 launch         (test_co3d.py:137-145)
-    [N>1: all-reduce(max) of the packed key over RCCL]
-    unpack key, gather R_pred = proposals[idx]                    (test_co3d.py:145-146)
+    forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max   ONE launch, ahv_verify_pair_f32
+                                                                          (test_co3d.py:137-145)
+    [N>1: all-reduce(MAX) of the packed int64 key over RCCL, asynchronous, finalized two steps later]
+    decode the key, gather R_pred = proposals[idx], hand the key back empty   ONE launch   (test_co3d.py:145-146)
 Inputs are resident in HBM before the timed region.  N > 1 shards the hypothesis axis: every
-rank scores its own 50 000 (weak scaling), the only exchange is the 8-byte key all-reduce.
+rank scores its own 50 000 (weak scaling: `value`), the only exchange is the 8-byte key all-reduce.  The same run
+also times a FIXED total split over the ranks (`strong_scaling`: 50 000 hypotheses at B = 1, and BASELINE.json
+configs[3], B = 32 x 50 000).
 
 Launching: `python3 bench.py --gpus N` starts its own N worker processes (one per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE anything touches a GPU and relays rank 0's JSON
@@ -147,6 +148,30 @@ def host_memory_gib() -> float:
     return avail
 
 
+def host_cpu_share():
+    """Threads this process may use: its affinity mask, capped by the cgroup's CPU quota (cpu.max: "<quota> <period>" or
+    "max"; v1: cpu.cfs_quota_us / cpu.cfs_period_us).  BASELINE.md section 4 says os.cpu_count(): on a GPU box whose
+    container owns a slice of the host that over-subscribes the slice 16-fold, so the share is what is used and all three
+    numbers are reported."""
+    import math
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    threads = affinity if quota is None else max(1, min(affinity, int(math.ceil(quota))))
+    return threads, {"os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "cgroup_cpu_quota": quota}
+
+
 def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
     """the reference's op sequence with stock torch CPU operators (oracle/torch_ref.py) on
     the host cores, same inputs as the GPU run, fp32, no_grad, all host threads of this box's CPU share;
@@ -156,7 +181,8 @@ def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
     24 GiB it runs on the first 10 000 hypotheses and says so.  `value` is the faster of the two."""
     import torch
     from oracle import torch_ref
-    cores = int(os.environ.get("AHV_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+    share, share_info = host_cpu_share()
+    cores = int(os.environ.get("AHV_CPU_THREADS", share))
     torch.set_num_threads(cores)
     vs, vt, Rc, w1, w2, bb = [t.cpu() for t in (vol_src, vol_tgt, R, W1, W2, b2)]
     torch_ref.score_hypotheses(vs, vt, Rc[:2000], w1, w2, bb, chunk=1000)  # warm-up (thread pool, oneDNN primitives)
@@ -176,7 +202,7 @@ def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
     t_u, reps_u, scores_u = best_of(n_un, None)
     chunked, unchunked = N_HYP / t_c, n_un / t_u
     res = {"value": max(chunked, unchunked), "unit": "hypotheses/s", "cores": torch.get_num_threads(),
-           "kind": "port", "cpu_model": cpu_model_string(),
+           "kind": "port", "cpu_model": cpu_model_string(), "cpu_share": share_info,
            "chunk_1000": {"value": chunked, "seconds": t_c, "n_hyp": N_HYP, "best_of": reps_c},
            "unchunked": {"value": unchunked, "seconds": t_u, "n_hyp": n_un, "best_of": reps_u,
                          "note": "reference-shaped call: all hypotheses materialised at once"},
@@ -186,6 +212,58 @@ def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
                                                          t_c, n_un, t_u)}
     assert torch.equal(scores[:, :n_un], scores_u) or (scores[:, :n_un] - scores_u).abs().max().item() < 1e-6
     return res, scores
+
+
+class VerifyLoop:
+    """One rank's verify steps on a fixed workload (the reference's per-pair hot loop, test_co3d.py:137-146):
+        step i   = ONE fused launch: forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max into key[i % 4]
+                   [process group: + the asynchronous 8*B-byte all-reduce(MAX) of that key on RCCL's stream]
+        finalize = ONE launch: decode the key, gather R_pred = proposals[idx], hand the key back EMPTY for step i + 4
+    With a process group, step i finalizes step i - lag: the collective of a step has the whole next kernel (lag 1) or two
+    (lag 2) to complete in before the compute stream waits for it."""
+    RING = 4
+
+    def __init__(self, ops, dist, dev, vol_src, vol_tgt, R_local, head, n_offset, use_pg, lag, spare_cus, split):
+        import torch
+        self.ops, self.dist, self.use_pg, self.lag = ops, dist, use_pg, (lag if use_pg else 0)
+        assert 0 <= self.lag < self.RING
+        self.vs, self.vt, self.R, self.head, self.n_offset = vol_src, vol_tgt, R_local, head, n_offset
+        self.spare, self.split = spare_cus, split
+        B = vol_src.shape[0]
+        self.keys = [torch.full((B,), -(1 << 63), dtype=torch.int64, device=dev) for _ in range(self.RING)]
+        self.pending, self.out, self.done = {}, {}, -1
+
+    def finalize(self, i):
+        key = self.keys[i % self.RING]
+        work = self.pending.pop(i, None)
+        if work is not None:
+            work.wait()  # stream-level dependency only, the host does not block
+        # with sharding the owner rank holds the winning row, the others get zeros
+        self.out["best"], self.out["idx"], self.out["R_pred"] = self.ops.select_rotation(key, self.R, n_offset=self.n_offset,
+                                                                                        reset_key=True)
+        self.done = i
+
+    def step(self, i, ev=None, stamps=None):
+        key = self.keys[i % self.RING]  # EMPTY: reset by the select that consumed it
+        if ev is not None:
+            ev[0].record()
+        # `stamps` given: the same kernel also writes every workgroup's s_memtime / s_memrealtime pair (shader clock)
+        self.ops.verify_pair(self.vs, self.vt, self.R, *self.head, n_offset=self.n_offset, want_scores=False, best_key=key,
+                             reset_best=False, split_f16=self.split, clock_stamps=stamps, spare_cus=self.spare)
+        if ev is not None:
+            ev[1].record()
+        if self.use_pg:
+            self.pending[i] = self.dist.all_reduce(key, op=self.dist.ReduceOp.MAX, async_op=True)
+        if i - self.lag >= 0 and i - self.lag > self.done:
+            self.finalize(i - self.lag)
+
+    def run(self, steps, events=None, stamps=None):
+        """`steps` steps, every one finalized on return (the stream is NOT synchronised)."""
+        self.done = -1
+        for i in range(steps):
+            self.step(i, None if events is None else events[i], None if stamps is None else stamps[i])
+        for i in range(max(self.done + 1, 0), steps):
+            self.finalize(i)
 
 
 def worker(args):
@@ -230,45 +308,16 @@ def worker(args):
     ops, adist = ahv.ops, ahv.dist
     lib = ahv._lib.load()  # fails loudly without the HIP library
     split = bool(args.split_f16)
+    # Under a process group the collective of step i is given `lag` kernels to finish in and the scorer leaves `spare`
+    # CUs without a workgroup for it (its persistent grid otherwise holds every CU's LDS): DESIGN.md section 6.
+    lag = int(os.environ.get("AHV_BENCH_FINALIZE_LAG", "2"))
+    spare = int(os.environ.get("AHV_BENCH_SPARE_CUS", "2" if use_pg else "0"))
 
     vol_src, vol_tgt, W1, W2, b2, R = synth_inputs(ahv, dev, rank)
+    head = (W1, W2, b2)
     n_offset = rank * N_HYP
-    ring = 4  # key buffers in flight: step i's tiny all-reduce overlaps step i+1's kernel
-    keys = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ring)]
-    pending = {}
-    out = {}
-
-    def finalize(i):
-        """all-reduce result -> (best score, global idx) -> R_pred = proposals[idx] (test_co3d.py:145-146)."""
-        key = keys[i % ring]
-        work = pending.pop(i, None)
-        if work is not None:
-            work.wait()  # stream-level dependency only, the host does not block
-            key.bitwise_xor_(adist._SIGN)
-        # unpack + gather in one launch; with sharding the owner rank holds the winning row, the others get zeros
-        out["best"], out["idx"], out["R_pred"] = ops.select_rotation(key, R, n_offset=n_offset)
-
+    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, lag, spare if use_pg else 0, split)
     ncu = lib.ahv_device_cu_count()
-
-    def step(i, ev=None, stamps=None):
-        feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
-        key = keys[i % ring]
-        # the key is cleared by a launch of its own AHEAD of the event pair, so that the pair brackets the fused kernel
-        # alone (with AHV_SCORE_RESET_BEST the library's zero-fill launch would sit inside it: +4 us on 700)
-        key.zero_()
-        if ev is not None:
-            ev[0].record()
-        # `stamps` given: the SAME kernel through the clocked entry point (one extra pointer argument; each
-        # workgroup also writes its s_memtime / s_memrealtime pair) -- the shader clock of the timed launches
-        ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset, want_scores=False, best_key=key,
-                             reset_best=False, split_f16=split, clock_stamps=stamps)
-        if ev is not None:
-            ev[1].record()
-        if use_pg:
-            key.bitwise_xor_(adist._SIGN)  # unsigned order -> signed order for ReduceOp.MAX
-            pending[i] = dist.all_reduce(key, op=dist.ReduceOp.MAX, async_op=True)
-        if i > 0:
-            finalize(i - 1)  # finish the previous step while this step's kernel runs
 
     def barrier():
         if use_pg:
@@ -286,9 +335,7 @@ def worker(args):
         settled = False
         while min_ms > 0:
             evs = new_events(batch)
-            for j in range(batch):
-                step(j, evs[j])
-            finalize(batch - 1)
+            loop.run(batch, evs)
             torch.cuda.synchronize()
             done += batch
             last = (last + [a.elapsed_time(b) for a, b in evs])[-3:]
@@ -304,30 +351,44 @@ def worker(args):
         return {"prewarm_ms": (time.perf_counter() - t0) * 1e3, "prewarm_steps": done, "prewarm_settled": settled,
                 "prewarm_last_kernel_ms": [round(x, 4) for x in last]}
 
-    with torch.no_grad():
-        pre = prewarm(args.prewarm_ms)
-        for i in range(args.warmup):
-            step(i)
-        if args.warmup:
-            finalize(args.warmup - 1)
+    def timed(lp, steps, warmup, events=None, stamps=None):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        if warmup:
+            lp.run(warmup)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        events = new_events(args.steps)
-        stamps = torch.zeros(args.steps, 4 * ncu, dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, events[i], stamps[i])
-        finalize(args.steps - 1)
+        lp.run(steps, events, stamps)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if use_pg:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    def global_best(scores, offset):
+        """torch.max over the materialised scores of ALL ranks: (value, global index) per sample."""
+        lv, li = torch.max(scores, dim=1)
+        cand = torch.stack([lv.double(), (li + offset).double()], dim=1)  # (B, 2)
+        if use_pg:
+            allc = [torch.zeros_like(cand) for _ in range(world)]
+            dist.all_gather(allc, cand)
+            cand = torch.stack(allc)  # (world, B, 2)
+            # largest value, lowest index among equals
+            order = torch.argsort(cand[:, :, 1], dim=0)
+            cand = torch.gather(cand, 0, order[:, :, None].expand_as(cand))
+            pick = torch.argmax(cand[:, :, 0], dim=0)
+            cand = cand[pick, torch.arange(cand.shape[1], device=cand.device)]
+        return cand
+
+    with torch.no_grad():
+        pre = prewarm(args.prewarm_ms)
+        events = new_events(args.steps)
+        stamps = torch.zeros(args.steps, 4 * ncu, dtype=torch.int64, device=dev)
+        dt = timed(loop, args.steps, args.warmup, events, stamps)
+        out = dict(loop.out)
         # fused kernel, HIP events on its stream, every timed launch
         kern_list = [a.elapsed_time(b) for a, b in events]
         kern_ms = float(np.mean(kern_list))
@@ -338,17 +399,39 @@ def worker(args):
         clock_ghz = float(np.median((st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]))) * 0.1 if len(st) else None
 
         # correctness of what was timed: the key equals torch.max over the materialised scores (all ranks)
-        feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)
-        scores, key = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, n_offset=n_offset, split_f16=split)
-        lv, li = torch.max(scores, dim=1)
-        cand = torch.stack([lv.double(), (li + n_offset).double()], dim=1)
-        if use_pg:
-            allc = [torch.zeros_like(cand) for _ in range(world)]
-            dist.all_gather(allc, cand)
-            cand = torch.cat(allc)
-        gbest = cand[torch.argmax(cand[:, 0])]
+        scores, key = ops.verify_pair(vol_src, vol_tgt, R, *head, n_offset=n_offset, split_f16=split, spare_cus=loop.spare)
+        gbest = global_best(scores, n_offset)[0]
         assert int(out["idx"].item()) == int(gbest[1].item()), (out["idx"], gbest)
         assert float(out["best"].item()) == float(gbest[0].item())
+
+        # ---- strong scaling, same run: a FIXED total split over the ranks (BASELINE.json metric "at 1/2/4/8"; configs[3])
+        def strong(vs, vt, R_all, steps, warmup):
+            n_total = R_all.shape[0]
+            lo, hi = adist.shard_range(n_total, rank, world)
+            lp = VerifyLoop(ops, dist, dev, vs, vt, R_all[lo:hi].contiguous(), head, lo, use_pg, lag,
+                            spare if use_pg else 0, split)
+            t = timed(lp, steps, warmup)
+            # the merged winner == the winner of the unsharded set scored on this rank alone
+            s_all, _ = ops.verify_pair(vs, vt, R_all, *head, split_f16=split, no_teams=True)
+            v, ix = torch.max(s_all, dim=1)
+            assert torch.equal(lp.out["idx"], ix), (lp.out["idx"], ix)
+            assert (lp.out["best"] - v).abs().max().item() <= 1e-6
+            B = vs.shape[0]
+            return {"n_hyp_total": n_total, "B": B, "n_hyp_per_rank": hi - lo, "steps": steps, "warmup": warmup,
+                    "ms_per_step": t / steps * 1e3, "hypotheses_per_s": B * n_total * steps / t,
+                    "pairs_per_s": B * steps / t}
+
+        R_all = torch.from_numpy(ahv.rotations.haar_rotations_np(N_HYP, seed=1000)).to(dev)
+        g = torch.Generator().manual_seed(5)
+        vs32 = (torch.randn(32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
+        vt32 = (torch.randn(32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
+        strong_scaling = {
+            "note": "a fixed total split over the ranks (value / ms_per_step above are WEAK scaling: 50 000 hypotheses per "
+                    "rank); same step, same collectives, timed between barriers, max over ranks",
+            "n50k_b1": strong(vol_src, vol_tgt, R_all, max(20, min(args.steps, 100)), 5),
+            "configs3_b32_n50k": strong(vs32, vt32, R_all, 5, 2),
+        }
+        feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)  # for the split-f16 side report below
 
     if rank == 0:
         total_hyp = N_HYP * world * args.steps
@@ -364,6 +447,7 @@ def worker(args):
             traffic = tj.get("fused_hbm_bytes_per_launch")
             traffic_src = "%s (rocprofv3 --pmc passes of %s; not measured in this run)" % (
                 TRAFFIC_JSON, tj.get("source", "an earlier bench.py run"))
+        kname = "score_hypotheses_dual_kernel<false, true>"
         res = {
             "metric": "rotation hypotheses scored/sec (B=1)", "value": value, "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -374,28 +458,35 @@ def worker(args):
                        "n_hyp_per_gpu": N_HYP, "n_hyp_total": N_HYP * world,
                        "parallelism": "hypothesis axis sharded x%d, 8-byte key all-reduce(max)" % world,
                        "backend": "single process" if not use_pg else ("rccl" if args.backend == "nccl" else args.backend),
-                       "step": "forward_3d2d(tgt) + key clear + fused score/argmax + select (unpack + gather R_pred)"},
+                       "step": "ONE fused launch (forward_3d2d(tgt) + rotate + forward_3d2d + score + arg-max: "
+                               "ahv_verify_pair_f32)%s + ONE select launch (decode + gather R_pred + key reset)" % (
+                                   " + all-reduce(MAX) of the int64 key, finalized %d step(s) later, %d CU(s) left free "
+                                   "for it" % (loop.lag, loop.spare) if use_pg else "")},
             # what the timed region computed (asserted above against torch.max over the materialised scores of
             # all ranks): lets a forced-process-group run be compared with a single-process run
             "result": {"best_idx": int(out["idx"].item()), "best_score": float(out["best"].item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "score_hypotheses_dual_kernel<false>", "kernel_ms": kern_ms,
+                         "kernel": kname, "kernel_ms": kern_ms,
                          "kernel_ms_min": float(np.min(kern_list)), "kernel_ms_median": float(np.median(kern_list)),
                          "kernel_ms_mean": kern_ms, "kernel_ms_per_step": [round(x, 4) for x in kern_list],
                          "frac_at_median": FLOPS_PER_HYP * N_HYP / (float(np.median(kern_list)) * 1e-3) / 1e12
                                            / PEAK_F32_MFMA_TFLOPS,
                          "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
+                         "algorithmic_flops_note": "50 000 hypotheses x 1 839 104; the in-launch target features (one more "
+                                                   "forward_3d2d per workgroup, ~0.5 %% extra work) are NOT counted",
                          "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP,
                          "shader_clock_ghz": clock_ghz,
                          "shader_clock_source": "s_memtime / s_memrealtime stamps of the TIMED launches (all %d, all "
                                                 "workgroups, median)" % args.steps,
                          "frac_at_delivered_clock": (achieved / (PEAK_F32_MFMA_TFLOPS * clock_ghz / MAX_CLOCK_GHZ)
                                                      if clock_ghz else None)},
+            "strong_scaling": strong_scaling,
         }
         if split:  # opt-in kernel: priced against the f16 matrix peak (16 x the fp32 one)
             res["dtype"] = "f16 hi/lo split products, f32 accumulate"
-            res["roofline"].update(kernel="score_hypotheses_dual_kernel<true>", peak=16 * PEAK_F32_MFMA_TFLOPS,
+            res["roofline"].update(kernel="forward_3d2d_small_kernel + score_hypotheses_dual_kernel<true, false>",
+                                   peak=16 * PEAK_F32_MFMA_TFLOPS,
                                    frac=achieved / (16 * PEAK_F32_MFMA_TFLOPS), frac_at_delivered_clock=None,
                                    traffic=None, traffic_source=None,
                                    note="GEMM1 runs 3 f16 MFMA products per algorithmic MAC; the kernel is bound by "
@@ -405,11 +496,12 @@ def worker(args):
             with torch.no_grad():
                 s4, k4 = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, split_f16=True)
 
+                k0 = loop.keys[0]
+
                 def split_launch(ev=None):
-                    keys[0].zero_()
                     if ev is not None:
                         ev[0].record()
-                    ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=keys[0],
+                    ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, want_scores=False, best_key=k0,
                                          reset_best=False, split_f16=True)
                     if ev is not None:
                         ev[1].record()

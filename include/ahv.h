@@ -46,8 +46,21 @@ extern "C" {
 #define AHV_VOL_ELEMS (AHV_CV * AHV_S * AHV_S * AHV_S) /* 8192 floats = 32 KiB */
 #define AHV_FEAT_ELEMS (AHV_O * AHV_P)                 /* 2048 floats = 8 KiB  */
 
+/*
+ * Packed (score, index) keys.  best_key[b] is a SIGNED 64-bit integer
+ *   key = (ordered_i32(score) << 32) | (0xFFFFFFFF - global_idx)
+ * where ordered_i32 maps the fp32 score onto int32 in score order (bits for s >= 0, bits ^ 0x7FFFFFFF for s < 0;
+ * -0 counts as +0; every NaN as the quiet NaN 0x7FC00000, which orders above +inf because torch.max propagates NaN).
+ * A signed max over keys therefore yields the largest score and, among equal scores, the LOWEST index -- the
+ * (value, index) pair of torch.max (test_co3d.py:145) -- and is exactly what an int64 MAX all-reduce (RCCL / gloo)
+ * or torch.max computes: keys of different launches, chunks or GPUs merge without any re-encoding.
+ * AHV_KEY_EMPTY (INT64_MIN) is below every real key: "nothing scored"; it decodes to score -inf, index -1.
+ * (ABI 1.x packed the same fields in UNSIGNED order with 0 as the empty key; 2.0 = that key ^ 0x8000000000000000.)
+ */
+#define AHV_KEY_EMPTY INT64_MIN
+
 /* flags of ahv_score_hypotheses_f32 */
-#define AHV_SCORE_RESET_BEST 1u /* zero best_key[0..B) on the stream before scoring */
+#define AHV_SCORE_RESET_BEST 1u /* set best_key[0..B) to AHV_KEY_EMPTY on the stream before scoring */
 #define AHV_SCORE_SPLIT_F16 2u  /* opt-in kernel for THIS call: GEMM1 (the 384 -> 32 projection) as three f16 MFMA
                                  * products of hi/lo-split operands with fp32 accumulation (the dropped lo*lo term is
                                  * 2^-22 relative; power-of-two prescales chosen on the device keep every finite fp32
@@ -56,7 +69,26 @@ extern "C" {
                                  * opt-in.  GEMM2, normalisation and score stay fp32.  1.8x faster.  The selector is
                                  * per call: there is no process-wide kernel switch. */
 
-/* ABI version (major<<16 | minor). */
+#define AHV_SCORE_NO_TEAMS 4u   /* every hypothesis by ONE wave.  Default: the remainder of a launch that would fill less than
+                                 * a quarter of the device's wave slots is scored by teams of four waves (a quarter of the
+                                 * volume each): ~4x lower latency for those hypotheses, and sums associated differently, so
+                                 * that a hypothesis' score may differ in the last bit or two (~1e-7) from what a lone wave
+                                 * computes -- i.e. depend, to rounding, on N and on the hypothesis' position in the set.
+                                 * With this flag a score is a function of (volumes, weights, R_n) alone, bit for bit. */
+#define AHV_SCORE_SPARE_CUS_SHIFT 8
+#define AHV_SCORE_SPARE_CUS_MASK 0xFF00u
+#define AHV_SCORE_SPARE_CUS(k) (((unsigned)(k) << AHV_SCORE_SPARE_CUS_SHIFT) & AHV_SCORE_SPARE_CUS_MASK)
+                                /* leave k compute units without a workgroup of the persistent grid (default 0: one
+                                 * workgroup per CU, 159.5 KiB of LDS each, so NOTHING else fits on the device while the
+                                 * scorer runs).  A caller that overlaps a small kernel of another stream with the scorer --
+                                 * the RCCL all-reduce of the previous step's key -- reserves a CU or two for it here. */
+
+/* flags of ahv_select_rotation_f32 */
+#define AHV_SELECT_RESET_KEY 1u /* hand best_key[0..B) back as AHV_KEY_EMPTY after decoding it: the next verify step
+                                 * then needs no launch of its own to clear the key */
+
+/* ABI version (major<<16 | minor).  2.0: signed-order keys (above), flags argument of ahv_select_rotation_f32,
+ * ahv_reset_best, ahv_verify_pair_f32. */
 int ahv_abi_version(void);
 
 /* Thread-local text of the last error returned on this thread ("" if none). */
@@ -88,19 +120,16 @@ int ahv_device_cu_count(void);
  *            added to the index packed into best_key.
  *  W1 [32][384], W2 [32][32], b2 [32]   feature_embedding_2d.{0.weight, 2.weight, 2.bias}
  *  scores    [B][N] or NULL     per-hypothesis mean cosine similarity
- *  best_key  [B] or NULL        packed running maximum, merged with atomic max:
- *            key = (ordered_u32(score) << 32) | (0xFFFFFFFF - global_idx), so
- *            that an unsigned max yields the largest score and, among equal
- *            scores, the LOWEST index (torch.max semantics); NaN scores order
- *            above +inf (torch.max propagates NaN).  Decode with ahv_unpack_best.
+ *  best_key  [B] or NULL        packed running maximum (see "Packed keys" above), merged
+ *            with a signed atomic max.  Decode with ahv_unpack_best / ahv_select_rotation_f32.
  *            Requires n_offset + N <= 2^32.
- *  flags     bit-or of AHV_SCORE_RESET_BEST (else: merge into the existing keys, e.g. chunked N) and
- *            AHV_SCORE_SPLIT_F16 (else: the all-fp32 kernel)
+ *  flags     bit-or of AHV_SCORE_RESET_BEST (else: merge into the existing keys, e.g. chunked N),
+ *            AHV_SCORE_SPLIT_F16 (else: the all-fp32 kernel), AHV_SCORE_NO_TEAMS, AHV_SCORE_SPARE_CUS(k)
  */
 int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
                              int64_t r_batch_stride, int64_t n_offset, const float* W1,
                              const float* W2, const float* b2, int B, int64_t N, float* scores,
-                             uint64_t* best_key, unsigned flags, void* stream);
+                             int64_t* best_key, unsigned flags, void* stream);
 
 /*
  * Diagnostics (measurement only; not part of the reference's interface): the same launch as
@@ -114,14 +143,37 @@ int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const 
 int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt, const float* R,
                                      int64_t r_batch_stride, int64_t n_offset, const float* W1,
                                      const float* W2, const float* b2, int B, int64_t N, float* scores,
-                                     uint64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream);
+                                     int64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream);
+
+/*
+ * One-launch verify step: everything the reference does per image pair between the encoder and the arg-max,
+ *   forward_3d2d(img_feat_tgt)                          test_co3d.py:141   (modules/modules.py:112-124)
+ *   rotate_volume + forward_3d2d + score + running max  test_co3d.py:137-145
+ * behind one entry point and, for the fp32 kernel, in ONE launch: the target features are built inside the scoring
+ * kernel (four waves of every workgroup share the target volume by quarter while the others start on their first
+ * hypotheses) instead of in a launch of their own.  Arguments as ahv_score_hypotheses_f32 except
+ *  vol_tgt       [B][16][8][8][8]  target volumes (the second output of forward_2d3d) in place of feat_tgt
+ *  feat_tgt_out  [B][32][64] or NULL: if given, forward_3d2d(vol_tgt) as the launch computed it (validation_step's
+ *                gt_sim reuses it, modules/model.py:137-143).  REQUIRED with AHV_SCORE_SPLIT_F16, whose kernel
+ *                takes ready-made features: that case runs forward_3d2d into it and then the scorer (two launches).
+ *  clock_stamps  NULL, or as in ahv_score_hypotheses_clocked_f32 (diagnostics)
+ * With N = 0 and feat_tgt_out given only the target features are produced.  The in-launch features are summed in
+ * another order than ahv_forward_3d2d_f32's (both fp32, both within 1e-6 of the reference).
+ */
+int ahv_verify_pair_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,
+                        int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
+                        float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags, uint64_t* clock_stamps,
+                        void* stream);
 
 /*
  * Decode packed keys: best_score[b], best_idx[b] (int64, global hypothesis index).
  * Replaces the (value, index) pair of torch.max (test_co3d.py:145).  Either output may be NULL.
- * A key of 0 (nothing scored: N = 0) decodes to best_score = -inf and best_idx = -1.
+ * AHV_KEY_EMPTY (nothing scored: N = 0) decodes to best_score = -inf and best_idx = -1.
  */
-int ahv_unpack_best(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream);
+int ahv_unpack_best(const int64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream);
+
+/* best_key[0..B) = AHV_KEY_EMPTY on the stream (what AHV_SCORE_RESET_BEST does in front of a scoring launch). */
+int ahv_reset_best(int64_t* best_key, int B, void* stream);
 
 /*
  * Op-level drop-in for utils.rotate_volume (utils.py:113-131): F.affine_grid +
@@ -163,7 +215,7 @@ int ahv_score_features_f32(const float* f_src, const float* f_tgt, int B, int64_
  * Arg-max over materialised scores (test_co3d.py:145): merges scores[b][0..N)
  * into best_key[b] with the same packing as the fused scorer.
  */
-int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key,
+int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, int64_t* best_key,
                    unsigned flags, void* stream);
 
 /*
@@ -172,9 +224,11 @@ int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, uint
  * `pred_sim, pred_index = torch.max(...)`; `proposals[pred_index]` of test_co3d.py:145-146.
  * With N sharded across GPUs only the rank whose slice [n_offset, n_offset+N) holds the
  * winner writes the row; the others write zeros (sum over ranks = R_pred).  Any output may be NULL.
+ * flags: AHV_SELECT_RESET_KEY (best_key is then written: EMPTY for the next step) or 0 (best_key is only read).
  */
-int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
-                            int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, void* stream);
+int ahv_select_rotation_f32(int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+                            int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, unsigned flags,
+                            void* stream);
 
 /*
  * Coarse-to-fine refinement set, composed on the device (no host round trip, graph-capturable):
@@ -182,7 +236,7 @@ int ahv_select_rotation_f32(const uint64_t* best_key, const float* R, int64_t r_
  * and D [N2][3][3] is a fixed set of small rotations.  Not in the reference (it scores one flat
  * set, test_objaverse.py:17); BASELINE.json configs[4].  out [B][N2][3][3].
  */
-int ahv_compose_rotations_f32(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
+int ahv_compose_rotations_f32(const int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
                               int64_t N, const float* D, int64_t N2, int B, float* out, void* stream);
 
 /*

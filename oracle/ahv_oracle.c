@@ -275,24 +275,27 @@ void ahv_oracle_geodesic_deg_f32(const float* R_pred, const float* R_gt, int64_t
 #include <string.h>
 
 #define AHV_TWIN_RESET_BEST 1u
+#define AHV_TWIN_SELECT_RESET_KEY 1u
+#define AHV_TWIN_KEY_EMPTY INT64_MIN
 
-/* ahv_device.h pack_key: key = ordered_u32(score) << 32 | (0xFFFFFFFF - idx); NaN ranks above +inf; -0 == +0 */
-static uint64_t twin_pack_key(float s, uint32_t idx)
+/* include/ahv.h "Packed keys": key = ordered_i32(score) << 32 | (0xFFFFFFFF - idx), SIGNED order; NaN ranks above
+ * +inf; -0 == +0; INT64_MIN = nothing scored */
+static int64_t twin_pack_key(float s, uint32_t idx)
 {
     s += 0.0f;
     uint32_t u;
     memcpy(&u, &s, 4);
     if (s != s) u = 0x7FC00000u;
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - idx);
+    u = (u & 0x80000000u) ? (u ^ 0x7FFFFFFFu) : u;
+    return (int64_t)(((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - idx));
 }
 
-static void twin_merge(uint64_t* best_key, int B, int64_t N, int64_t n_offset, const float* scores, unsigned flags)
+static void twin_merge(int64_t* best_key, int B, int64_t N, int64_t n_offset, const float* scores, unsigned flags)
 {
     for (int b = 0; b < B; ++b) {
-        uint64_t k = (flags & AHV_TWIN_RESET_BEST) ? 0 : best_key[b];
+        int64_t k = (flags & AHV_TWIN_RESET_BEST) ? AHV_TWIN_KEY_EMPTY : best_key[b];
         for (int64_t n = 0; n < N; ++n) {
-            const uint64_t c = twin_pack_key(scores[(int64_t)b * N + n], (uint32_t)(n_offset + n));
+            const int64_t c = twin_pack_key(scores[(int64_t)b * N + n], (uint32_t)(n_offset + n));
             if (c > k) k = c;
         }
         best_key[b] = k;
@@ -331,7 +334,7 @@ int ahv_score_features_f32_cpu(const float* f_src, const float* f_tgt, int B, in
     return 0;
 }
 
-int ahv_argmax_f32_cpu(const float* scores, int B, int64_t N, int64_t n_offset, uint64_t* best_key, unsigned flags,
+int ahv_argmax_f32_cpu(const float* scores, int B, int64_t N, int64_t n_offset, int64_t* best_key, unsigned flags,
                        void* stream)
 {
     (void)stream;
@@ -343,14 +346,14 @@ int ahv_argmax_f32_cpu(const float* scores, int B, int64_t N, int64_t n_offset, 
 /* feat_tgt [B][32][64] is GIVEN here (forward_3d2d of the target volume), as in the product's entry point */
 int ahv_score_hypotheses_f32_cpu(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
                                  int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
-                                 float* scores, uint64_t* best_key, unsigned flags, void* stream)
+                                 float* scores, int64_t* best_key, unsigned flags, void* stream)
 {
     (void)stream;
     if (B < 0 || N < 0 || (!scores && !best_key)) return -1;
     if (r_batch_stride != 0 && r_batch_stride < N * 9) return -1;
     if (n_offset < 0 || n_offset + N > 4294967296ll) return -1;
     if (best_key && (flags & AHV_TWIN_RESET_BEST))
-        for (int b = 0; b < B; ++b) best_key[b] = 0;
+        for (int b = 0; b < B; ++b) best_key[b] = AHV_TWIN_KEY_EMPTY;
     if (B == 0 || N == 0) return 0;
     if (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2) return -1;
     const int64_t VOL = AHV_CV * AHV_S * AHV_S * AHV_S, FEAT = AHV_O * AHV_P, CH = 256;
@@ -372,40 +375,69 @@ int ahv_score_hypotheses_f32_cpu(const float* vol_src, const float* feat_tgt, co
     return 0;
 }
 
-/* ahv_device.h key_score / key_index; a key of 0 (nothing scored) decodes to -inf, -1 */
-int ahv_unpack_best_cpu(const uint64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
+/* the whole verify step behind one entry point (include/ahv.h ahv_verify_pair_f32): forward_3d2d of the target volume
+ * (test_co3d.py:141), then the fused loop; feat_tgt_out optional; clock_stamps ignored */
+int ahv_verify_pair_f32_cpu(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,
+                            int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
+                            float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags, uint64_t* clock_stamps,
+                            void* stream)
+{
+    (void)clock_stamps;
+    if (B < 0 || N < 0) return -1;
+    if (B > 0 && (!vol_tgt || !W1 || !W2 || !b2)) return -1;
+    float* ft = feat_tgt_out ? feat_tgt_out : (float*)calloc((size_t)(B > 0 ? B : 1) * AHV_O * AHV_P, sizeof(float));
+    if (!ft) return -1;
+    if (B > 0) ahv_oracle_forward_3d2d_f32(vol_tgt, W1, W2, b2, B, ft);
+    const int rc = ahv_score_hypotheses_f32_cpu(vol_src, ft, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key,
+                                                flags & 3u, stream);
+    if (!feat_tgt_out) free(ft);
+    return rc;
+}
+
+/* ahv_device.h key_score / key_index; the empty key (nothing scored) decodes to -inf, -1 */
+int ahv_unpack_best_cpu(const int64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)
 {
     (void)stream;
     if (!best_key || B < 0) return -1;
     for (int b = 0; b < B; ++b) {
-        const uint64_t k = best_key[b];
-        uint32_t u = (uint32_t)(k >> 32);
+        const int64_t k = best_key[b];
+        uint32_t u = (uint32_t)((uint64_t)k >> 32);
         float s;
-        if (k == 0) {
+        if (k == AHV_TWIN_KEY_EMPTY) {
             s = -INFINITY;
         } else {
-            u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+            u = (u & 0x80000000u) ? (u ^ 0x7FFFFFFFu) : u;
             memcpy(&s, &u, 4);
         }
         if (best_score) best_score[b] = s;
-        if (best_idx) best_idx[b] = k == 0 ? -1 : (int64_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu));
+        if (best_idx) best_idx[b] = k == AHV_TWIN_KEY_EMPTY ? -1 : (int64_t)(0xFFFFFFFFu - (uint32_t)((uint64_t)k & 0xFFFFFFFFu));
     }
     return 0;
 }
 
-int ahv_select_rotation_f32_cpu(const uint64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
-                                int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, void* stream)
+int ahv_reset_best_cpu(int64_t* best_key, int B, void* stream)
 {
+    (void)stream;
+    if (B < 0 || (B > 0 && !best_key)) return -1;
+    for (int b = 0; b < B; ++b) best_key[b] = AHV_TWIN_KEY_EMPTY;
+    return 0;
+}
+
+int ahv_select_rotation_f32_cpu(int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset, int64_t N,
+                                int B, float* R_out, float* best_score, int64_t* best_idx, unsigned flags, void* stream)
+{
+    if (flags & ~AHV_TWIN_SELECT_RESET_KEY) return -1;
     if (ahv_unpack_best_cpu(best_key, B, best_score, NULL, stream)) return -1;
     for (int b = 0; b < B; ++b) {
-        const uint64_t k = best_key[b];
-        const int64_t idx = k == 0 ? -1 : (int64_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu));
+        const int64_t k = best_key[b];
+        const int64_t idx = k == AHV_TWIN_KEY_EMPTY ? -1 : (int64_t)(0xFFFFFFFFu - (uint32_t)((uint64_t)k & 0xFFFFFFFFu));
         if (best_idx) best_idx[b] = idx;
         if (R_out) {
             const int64_t local = idx - n_offset;
             for (int i = 0; i < 9; ++i)
                 R_out[b * 9 + i] = (idx >= 0 && local >= 0 && local < N) ? R[b * r_batch_stride + local * 9 + i] : 0.0f;
         }
+        if (flags & AHV_TWIN_SELECT_RESET_KEY) best_key[b] = AHV_TWIN_KEY_EMPTY;
     }
     return 0;
 }

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib, ahv):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.ahv_abi_version() == (1 << 16)
+    assert lib.ahv_abi_version() == (2 << 16)
     assert isinstance(lib.ahv_last_error(), bytes)
 
 

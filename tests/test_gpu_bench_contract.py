@@ -41,6 +41,18 @@ def test_bench_json_line():
     assert abs(r["kernel_ms_mean"] - r["kernel_ms"]) < 1e-12
     assert "TIMED launches" in r["shader_clock_source"]
     assert out.stdout.strip() == lines[0]                                  # stdout = the one JSON line, nothing else
+    # one step = ONE fused launch + ONE select launch: what is not the scorer stays small (21 us in round 3)
+    assert r["kernel"].startswith("score_hypotheses_dual_kernel<false, true>")
+    assert d["ms_per_step"] - r["kernel_ms"] < 0.015, (d["ms_per_step"], r["kernel_ms"])
+    # the strong-scaling record of the same run: a fixed total split over the ranks (one rank here: everything)
+    ss = d["strong_scaling"]
+    a, b = ss["n50k_b1"], ss["configs3_b32_n50k"]
+    assert a["n_hyp_total"] == 50000 and a["n_hyp_per_rank"] == 50000 and a["B"] == 1
+    assert b["n_hyp_total"] == 50000 and b["B"] == 32 and b["steps"] == 5
+    assert abs(a["hypotheses_per_s"] - 50000 / (a["ms_per_step"] * 1e-3)) / a["hypotheses_per_s"] < 1e-6
+    assert abs(b["hypotheses_per_s"] - 32 * 50000 / (b["ms_per_step"] * 1e-3)) / b["hypotheses_per_s"] < 1e-6
+    assert 0.5 * d["value"] < a["hypotheses_per_s"] < 1.2 * d["value"]          # the same workload at one rank
+    assert b["hypotheses_per_s"] > 0.9 * a["hypotheses_per_s"]                   # batching never costs throughput
 
 
 def test_bench_rccl_branch_on_one_gpu():
@@ -48,18 +60,25 @@ def test_bench_rccl_branch_on_one_gpu():
     collective of the world > 1 path -- the async key all-reduce ring, the barriers, the all-reduce of the time,
     the all-gather check -- so the first multi-GPU run is not the first run of that code.  Same arg-max and score
     as the single-process run."""
-    base = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "200", "--warmup", "20", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    single = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
-    assert single.returncode == 0, single.stderr[-2000:]
-    forced = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=REPO,
-                            env=dict(env, AHV_BENCH_FORCE_PG="1"))
-    assert forced.returncode == 0, forced.stderr[-3000:]
-    a, b = json.loads(single.stdout.strip()), json.loads(forced.stdout.strip())
+
+    def run(extra):
+        out = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=REPO, env=dict(env, **extra))
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads(out.stdout.strip())
+
+    a, b = run({}), run({"AHV_BENCH_FORCE_PG": "1"})
     assert a["config"]["backend"] == "single process" and b["config"]["backend"] == "rccl"
     assert b["n_gpus"] == 1 and a["result"] == b["result"]
-    # the collectives ride beside the kernel (async all-reduce on RCCL's stream): the step may not get much slower
-    assert b["ms_per_step"] < 1.5 * a["ms_per_step"] + 0.2
+    assert "finalized 2 step(s) later" in b["config"]["step"]
+    # The collective is hidden: the int64 key goes into the all-reduce as the kernel packed it (no re-encoding launches) and
+    # is consumed two steps later, so the step with the process group costs what the step without it costs (round 3: +4.6 %).
+    # Two processes seconds apart differ by the clock they are granted (<= 1 %): one repeat before judging.
+    ta, tb = a["ms_per_step"], b["ms_per_step"]
+    if tb > 1.02 * ta:
+        ta, tb = min(ta, run({})["ms_per_step"]), min(tb, run({"AHV_BENCH_FORCE_PG": "1"})["ms_per_step"])
+    assert tb <= 1.02 * ta, (ta, tb)
 
 
 def test_bench_launches_its_own_ranks():

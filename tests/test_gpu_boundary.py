@@ -130,7 +130,8 @@ def test_plain_ops_never_drop_a_gradient(ahv, dev):
         ahv.ops.score_features(torch.zeros(1, 2, 32, 64, device=dev, requires_grad=True), torch.zeros(1, 32, 64, device=dev))
     with pytest.raises(RuntimeError, match="GPU only"):
         ahv.ops.unpack_best(torch.zeros(1, dtype=torch.int64))
-    _, key2 = ahv.ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False)   # nothing differentiable requested
+    # nothing differentiable requested: the plain launch (single waves like the autograd path: same bits)
+    _, key2 = ahv.ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False, no_teams=True)
     assert torch.equal(key2, key)
 
 

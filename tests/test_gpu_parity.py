@@ -270,18 +270,20 @@ def test_fused_tie_break_lowest_index(ops, G, dev, ahv):
 
 
 def test_fused_sharded_offsets_merge(ops, G, dev, ahv):
-    """N split into shards with n_offset (what each rank does); max over packed keys = global arg-max."""
+    """N split into shards with n_offset (what each rank does); max over packed keys = global arg-max.
+    AHV_SCORE_NO_TEAMS: scores that do not depend on N bit for bit (the default lets teams of four waves score the
+    remainder of a launch, equal to rounding: tests/test_gpu_verify.py)."""
     R = to_dev(ahv.rotations.haar_rotations_np(10000, 11), dev)
     ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
-    s_full, k_full = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
+    s_full, k_full = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], no_teams=True)
     keys, parts = [], []
     for r in range(4):
         lo, hi = r * 2500, (r + 1) * 2500
-        s, k = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo)
+        s, k = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo, no_teams=True)
         keys.append(k)
         parts.append(s)
     assert torch.equal(torch.cat(parts, dim=1), s_full)  # per-hypothesis results do not depend on the shard
-    merged = ahv.dist.merge_keys(torch.stack(keys))  # unsigned max over ranks
+    merged = ahv.dist.merge_keys(torch.stack(keys))  # int64 max over ranks: what the all-reduce computes
     assert torch.equal(merged, k_full)
     assert ops.unpack_best(merged)[1].item() == ops.unpack_best(k_full)[1].item()
     # chunked accumulation into one key tensor (flags = 0: merge into the caller's keys)
@@ -289,8 +291,11 @@ def test_fused_sharded_offsets_merge(ops, G, dev, ahv):
     for r in range(4):
         lo, hi = r * 2500, (r + 1) * 2500
         _, key = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo,
-                                      want_scores=False, best_key=key)
+                                      want_scores=False, best_key=key, no_teams=True)
     assert torch.equal(key, k_full)
+    # the default (teams may take a shard's remainder): same winner, scores equal to rounding
+    s_t, k_t = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
+    assert (s_t - s_full).abs().max().item() <= 1e-6 and torch.equal(ops.unpack_best(k_t)[1], ops.unpack_best(k_full)[1])
 
 
 def test_configs3_full_size(ops, dev, ahv, oracle):
@@ -307,13 +312,13 @@ def test_configs3_full_size(ops, dev, ahv, oracle):
     W = [to_dev(g[k], dev) for k in ("W1", "W2", "b2")]
     vsd, vtd, R = to_dev(vs, dev), to_dev(vt, dev), to_dev(Rn, dev)
     ft = ops.forward_3d2d(vtd, *W)
-    s_full, k_full = ops.score_hypotheses(vsd, ft, R, *W)
+    s_full, k_full = ops.score_hypotheses(vsd, ft, R, *W, no_teams=True)
     assert s_full.shape == (B, N)
     keys = []
     for r in range(G8):
         lo, hi = ahv.dist.shard_range(N, r, G8)
         assert hi - lo == N // G8
-        s, k = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo)
+        s, k = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, no_teams=True)
         assert torch.equal(s, s_full[:, lo:hi])            # per-hypothesis results do not depend on the shard
         keys.append(k)
         if r == 3:
@@ -328,8 +333,12 @@ def test_configs3_full_size(ops, dev, ahv, oracle):
     key = None
     for r in range(G8):
         lo, hi = ahv.dist.shard_range(N, r, G8)
-        _, key = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, want_scores=False, best_key=key)
+        _, key = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, want_scores=False, best_key=key, no_teams=True)
     assert torch.equal(key, k_full)
+    # what bench.py's strong-scaling record runs: the one-launch step per shard, teams allowed -- same winners
+    keys_t = [ops.verify_pair(vsd, vtd, R[lo:hi], *W, n_offset=lo, want_scores=False)[1]
+              for lo, hi in (ahv.dist.shard_range(N, r, G8) for r in range(G8))]
+    assert torch.equal(ops.unpack_best(ahv.dist.merge_keys(torch.stack(keys_t)))[1], ri)
 
 
 def test_fused_properties_full_size(ops, G, dev, ahv):
@@ -344,8 +353,10 @@ def test_fused_properties_full_size(ops, G, dev, ahv):
         assert idx.item() == ri.item() and val.item() == rv.item()        # key == torch.max of the scores
         assert torch.all(s.abs() <= 1.0 + 1e-5)                           # mean cosine similarity
         perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
-        s_p, _ = ops.score_hypotheses(G["vol_src"], ft, R[perm].contiguous(), G["W1"], G["W2"], G["b2"])
-        assert torch.equal(s_p[0], s[0, perm])                            # order independence, bit for bit
+        s_1, _ = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], no_teams=True)
+        s_p, _ = ops.score_hypotheses(G["vol_src"], ft, R[perm].contiguous(), G["W1"], G["W2"], G["b2"], no_teams=True)
+        assert torch.equal(s_p[0], s_1[0, perm])                          # order independence, bit for bit (single waves)
+        assert (s - s_1).abs().max().item() <= 1e-6                       # teams for the remainder: equal to rounding
         s_again, k_again = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
         assert torch.equal(s_again, s) and torch.equal(k_again, k)        # deterministic
     # identity hypothesis == un-rotated source features scored against the target

@@ -146,7 +146,7 @@ def test_split_selector_is_per_call_and_per_context(ops, ahv, dev):
     assert not hasattr(lib, "ahv_set_option")
     key = torch.zeros(1, dtype=torch.int64, device=dev)
     rc = lib.ahv_score_hypotheses_f32(vs.data_ptr(), ft.data_ptr(), R.data_ptr(), 0, 0, W1.data_ptr(), W2.data_ptr(),
-                                      b2.data_ptr(), 1, 128, None, key.data_ptr(), 4, None)
+                                      b2.data_ptr(), 1, 128, None, key.data_ptr(), 8, None)
     assert rc == -1 and b"unknown flags" in lib.ahv_last_error()
 
 

@@ -63,11 +63,12 @@ def test_key_codec_matches_torch_max(ahv):
     assert idx[0] == 5 and score[0] == s[5]
     # ordering across sign, zero and NaN
     vals = np.array([-np.inf, -2.0, -0.0, 0.0, 1e-30, 3.0, np.inf, np.nan], dtype=np.float32)
-    k = d.pack_keys_host(vals, np.zeros(8)).view(np.uint64)
-    assert k[2] == k[3] and all(k[i] < k[i + 1] for i in (0, 1, 3, 4, 5, 6))
+    k = d.pack_keys_host(vals, np.zeros(8))   # int64, signed order (include/ahv.h "Packed keys")
+    assert k.dtype == np.int64 and k[2] == k[3] and all(k[i] < k[i + 1] for i in (0, 1, 3, 4, 5, 6))
+    assert np.all(k > d.KEY_EMPTY) and d.KEY_EMPTY == np.iinfo(np.int64).min
     sc, ix = d.unpack_keys_host(d.pack_keys_host(vals, np.arange(8)))
     assert np.array_equal(sc[[0, 1, 4, 5, 6]], vals[[0, 1, 4, 5, 6]]) and np.isnan(sc[7]) and list(ix) == list(range(8))
-    sc, ix = d.unpack_keys_host(np.zeros(2, dtype=np.int64))
+    sc, ix = d.unpack_keys_host(np.full(2, d.KEY_EMPTY, dtype=np.int64))
     assert list(ix) == [-1, -1] and np.all(np.isneginf(sc))
 
 

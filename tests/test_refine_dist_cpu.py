@@ -23,26 +23,35 @@ class OracleBackend:
     def __init__(self, ahv, oracle):
         self.ahv, self.oracle = ahv, oracle
 
-    def forward_3d2d(self, vol_tgt, W1, W2, b2):
-        return vol_tgt  # the oracle's scorer takes the target VOLUME (it applies forward_3d2d itself)
-
-    def score_hypotheses(self, vol_src, vol_tgt, R, W1, W2, b2, n_offset=0, want_scores=True):
+    def score_hypotheses(self, vol_src, vol_tgt, R, W1, W2, b2, n_offset=0, want_scores=True, best_key=None,
+                         reset_best=None):
         s, _, _ = self.oracle.score_hypotheses(vol_src.numpy(), vol_tgt.numpy(), R.numpy(), W1.numpy(), W2.numpy(),
                                                b2.numpy())
         best, idx = self.oracle.argmax(s)
         key = torch.from_numpy(self.ahv.dist.pack_keys_host(best, idx + n_offset))
+        if best_key is not None:  # merge into the caller's key (handed over empty), as the product does
+            assert reset_best is False
+            best_key.copy_(torch.maximum(best_key, key))
+            key = best_key
         return (torch.from_numpy(s) if want_scores else None), key
+
+    def verify_pair(self, vol_src, vol_tgt, R, W1, W2, b2, want_feat_tgt=False, **kw):
+        # the oracle's scorer takes the target VOLUME (it applies forward_3d2d itself): "features" = the volume
+        s, key = self.score_hypotheses(vol_src, vol_tgt, R, W1, W2, b2, **kw)
+        return (s, key, vol_tgt) if want_feat_tgt else (s, key)
 
     def unpack_best(self, key):
         b, i = self.ahv.dist.unpack_keys_host(key.numpy())
         return torch.from_numpy(b), torch.from_numpy(i)
 
-    def compose_rotations(self, key, R, D, n_offset=0):
+    def compose_rotations(self, key, R, D, n_offset=0, out=None):
         _, idx = self.unpack_best(key)
         return torch.matmul(R[idx - n_offset][:, None], D[None]).contiguous()
 
-    def select_rotation(self, key, R, n_offset=0):
+    def select_rotation(self, key, R, n_offset=0, reset_key=False):
         score, idx = self.unpack_best(key)
+        if reset_key:
+            key.fill_(self.ahv.dist.KEY_EMPTY)
         B, N = key.numel(), R.shape[-3]
         out = torch.zeros(B, 3, 3)
         for b in range(B):

@@ -78,8 +78,28 @@ if not only or "5" in only:
         c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, max_angle_deg=10.0, batch=1, use_graph=use_graph)
         ms = timeit(lambda: c2f(vs, vt), 200, warm=5)
         out = c2f(vs, vt)
+        # the producer writes straight into the step's static inputs: no staging copies in front of the replay
+        c2f.buffers[0].copy_(vs)
+        c2f.buffers[1].copy_(vt)
+        ms_in_place = timeit(lambda: c2f(), 200, warm=5)
         print(json.dumps({"config": "5 coarse10k+fine1k", "graph": use_graph, "us_per_step": ms * 1e3,
-                          "hyp_per_s": 11_000 / ms * 1e3, "fine_score": out[0].item(), "coarse_score": out[3].item()}))
+                          "us_per_step_inputs_in_place": ms_in_place * 1e3, "launches_per_step": 5,
+                          "hyp_per_s": 11_000 / ms_in_place * 1e3, "fine_score": out[0].item(), "coarse_score": out[3].item()}))
+
+if not only or "shard" in only:
+    # what one rank of a strong-scaling run does per step (B = 1): the one-launch verify + select on its shard of 50 000
+    vs, vt = vol[0, :1], vol[1, :1]
+    key = torch.full((1,), -(1 << 63), dtype=torch.int64, device=dev)
+    for N in (1000, 6250, 10_000, 12_500, 25_000, 50_000):
+        R = torch.from_numpy(ahv.rotations.haar_rotations_np(N, 9)).to(dev)
+        row = {"config": "shard B=1", "N": N}
+        for name, kw in (("teams", {}), ("single_waves", {"no_teams": True})):
+            def step():
+                ops.verify_pair(vs, vt, R, W1, W2, b2, want_scores=False, best_key=key, reset_best=False, **kw)
+                ops.select_rotation(key, R, reset_key=True)
+            row["us_per_step_" + name] = timeit(step, 200, warm=20) * 1e3
+        row["hyp_per_s"] = N / row["us_per_step_teams"] * 1e6
+        print(json.dumps(row))
 
 if not only or "enc" in only:
     # once-per-pair encoder (forward_2d3d), stock PyTorch-ROCm operators: eager vs one hipGraph replay

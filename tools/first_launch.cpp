@@ -40,7 +40,7 @@ int main(int argc, char** argv)
         for (int e = 0; e < 9; ++e) R[n * 9 + e] = (float)m[e];
     }
     float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dsc;
-    uint64_t* dkey;
+    int64_t* dkey;
     CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
     CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
     CK(hipMalloc(&dsc, N * 4)); CK(hipMalloc(&dkey, 8));
@@ -54,7 +54,9 @@ int main(int argc, char** argv)
     int cu = 0;
     CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0));
     auto launch = [&](bool split, long off) {
-        return ahv::launch_score_hypotheses(dvol, dft, dR + off * 9, 0, 0, dW1, dW2, db2, 1, N / 2, dsc, dkey, cu, split, nullptr, 0);
+        // no_teams: this tool compares the two kernels hypothesis by hypothesis, independent of N
+        ahv::ScoreLaunch a = {dvol, dft, false, dR + off * 9, 0, 0, dW1, dW2, db2, 1, N / 2, dsc, dkey, nullptr, cu, 0, split, true, nullptr};
+        return ahv::launch_score_hypotheses(a, 0);
     };
     const int L = (int)strlen(seq);
     std::vector<std::vector<float>> res(L, std::vector<float>(N / 2));

@@ -118,6 +118,68 @@ def gen_encoder_full(Feature_Aligner):
         n_param, v_src.std().item(), v_src.abs().max().item(), grabbed["tok0_src"].std().item()))
 
 
+def seeded_pair(Feature_Aligner):
+    """The aligner and the B = 3 volume pairs every score fixture shares (seed 0; the first pair is G1's)."""
+    torch.manual_seed(0)
+    fa = Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).eval()
+    with torch.no_grad():
+        layer4 = torch.randn(2, 3, 768, 8, 8)  # [src|tgt][B=3]
+        vol_src3, vol_tgt3 = fa.forward_2d3d(layer4[0], layer4[1], random_mask=False, mask_ratio=0)
+    return fa, vol_src3, vol_tgt3
+
+
+def chunked_scores(rotate_volume, fa, vol_src, vol_tgt, R_np, chunk):
+    """(B, N) scores of the reference hot loop, hypotheses in chunks (chunking does not change per-hypothesis results)."""
+    sims = []
+    for n0 in range(0, R_np.shape[0], chunk):
+        _, _, _, s, _, _ = ref_hot_loop(rotate_volume, fa, vol_src, vol_tgt, torch.from_numpy(R_np[n0:n0 + chunk]))
+        sims.append(s)
+    return torch.cat(sims, dim=1)
+
+
+def gen_grid_digest(rotate_volume, fa, vol_src, vol_tgt):
+    """G8 `score_n200k_grid_digest` (BASELINE.json configs[2]): the reference hot loop (test_linemod.py:43-63 shape,
+    test_co3d.py:135-146 code) over the 200 000-point super-Fibonacci SO(3) grid of rotations.so3_grid_np -- the dense
+    set where near-ties live.  Stored: best index / score, top-16 (index, score), every 389th score, the top-2 margin,
+    the number of scores within 1e-6 of the best, SHA-256 of the grid's bytes.  Volumes and head weights are G1's."""
+    n = 200000
+    R = rot.so3_grid_np(n)
+    sim = chunked_scores(rotate_volume, fa, vol_src, vol_tgt, R, 5000)
+    best, idx = torch.max(sim, dim=1)
+    topv, topi = torch.topk(sim[0], 16)
+    near = (sim[0] >= best[0] - 1e-6).nonzero().flatten()
+    np.savez(os.path.join(OUT, "score_n200k_grid_digest.npz"), n=np.int64(n),
+             R_sha256=np.array(hashlib.sha256(R.tobytes()).hexdigest()),
+             top16_idx=topi.numpy().astype(np.int64), top16_score=topv.numpy(),
+             every389_score=sim[0, ::389].numpy(), best=best.numpy(), best_idx=idx.numpy(),
+             top2_margin=(topv[0] - topv[1]).numpy(), tie_set_1e6=near.numpy().astype(np.int64))
+    print("G8 200k grid best", best.item(), idx.item(), "margin", (topv[0] - topv[1]).item(), "within 1e-6:", near.tolist())
+
+
+def gen_batched32(rotate_volume, Feature_Aligner, fa):
+    """G9 `batched32_digest` (BASELINE.json configs[3] shape, modules/model.py:184-196): B = 32 volume pairs from the
+    reference's forward_2d3d on randn(32,768,8,8) (rounded to fp16-representable values and stored as fp16: exact, half
+    the bytes), ONE shared hypothesis set R(4096) (Haar, seed 9) -> per-sample best index / score, top-2 margin and
+    every 61st score."""
+    torch.manual_seed(90)
+    with torch.no_grad():
+        layer4 = torch.randn(2, 32, 768, 8, 8)
+        vs, vt = fa.forward_2d3d(layer4[0], layer4[1], random_mask=False, mask_ratio=0)
+    vs, vt = vs.half().float(), vt.half().float()
+    R = rot.haar_rotations_np(4096, seed=9)
+    rows = []
+    for b in range(32):  # per sample: the reference materialises 130 KB per (sample, hypothesis)
+        rows.append(chunked_scores(rotate_volume, fa, vs[b:b + 1], vt[b:b + 1], R, 1024))
+    sim = torch.cat(rows, dim=0)
+    best, idx = torch.max(sim, dim=1)
+    top2 = torch.topk(sim, 2, dim=1).values
+    np.savez(os.path.join(OUT, "batched32_digest.npz"), vol_src=vs.half().numpy(), vol_tgt=vt.half().numpy(),
+             seed=np.int64(9), n=np.int64(4096), R_sha256=np.array(hashlib.sha256(R.tobytes()).hexdigest()),
+             best=best.numpy(), best_idx=idx.numpy().astype(np.int64), top2_margin=(top2[:, 0] - top2[:, 1]).numpy(),
+             every61_score=sim[:, ::61].numpy())
+    print("G9 B=32 best idx", idx.tolist()[:8], "... min margin", (top2[:, 0] - top2[:, 1]).min().item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -128,13 +190,13 @@ def main():
         return
 
     # ---- full-size aligner with seeded random weights; volumes via the reference's forward_2d3d
-    torch.manual_seed(0)
-    fa = Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).eval()
+    fa, vol_src3, vol_tgt3 = seeded_pair(Feature_Aligner)
     W1, W2, b2 = head_weights(fa)
-    with torch.no_grad():
-        layer4 = torch.randn(2, 3, 768, 8, 8)  # [src|tgt][B=3]
-        vol_src3, vol_tgt3 = fa.forward_2d3d(layer4[0], layer4[1], random_mask=False, mask_ratio=0)
     vol_src, vol_tgt = vol_src3[:1], vol_tgt3[:1]
+    if "--only-g8-g9" in sys.argv:  # round 4 additions alone (the other fixtures regenerate bit-identically anyway)
+        gen_grid_digest(rotate_volume, fa, vol_src, vol_tgt)
+        gen_batched32(rotate_volume, Feature_Aligner, fa)
+        return
     print("volume stats: std %.3f max %.3f" % (vol_src.std().item(), vol_src.abs().max().item()))
 
     # ---- G1: N=128 (BASELINE.json config 1)
@@ -229,6 +291,8 @@ def main():
     err = torch.arccos(simm) * 180.0 / np.pi
     np.savez(os.path.join(OUT, "metric.npz"), R_pred=Rp, R_gt=Rg, err_deg=err.numpy())
 
+    gen_grid_digest(rotate_volume, fa, vol_src, vol_tgt)
+    gen_batched32(rotate_volume, Feature_Aligner, fa)
     gen_encoder_full(Feature_Aligner)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -2,7 +2,9 @@
 // Includes the kernel source directly so that diagnostic builds (-DAHV_STAMPS) can read the
 // in-kernel cycle stamps.  Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DAHV_STAMPS] \
 //                                   -I3dahv_amd/csrc tools/kbench.cpp -o tools/kbench
-// Run (on the GPU box):  tools/kbench [N] [iters]
+// Run (on the GPU box):  tools/kbench [N] [iters] [variant] [spare_cus] [no_teams]
+//   variant 3 = fp32 kernel (target features given), 4 = split-f16, 5 = fp32 with the target features built in the
+//   launch (ahv_verify_pair_f32); without [variant]: 3, 4 and 5 in turn.
 #include "../3dahv_amd/csrc/ahv_score.hip"
 
 #include <algorithm>
@@ -19,7 +21,8 @@ int main(int argc, char** argv)
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
     std::mt19937 rng(0);
     std::normal_distribution<float> nd(0.f, 1.f);
-    std::vector<float> vol(8192), ft(2048), R(N * 9), W1(32 * 384), W2(1024), b2(32);
+    std::vector<float> vol(8192), ft(2048), R(N * 9), W1(32 * 384), W2(1024), b2(32), vtgt(8192);
+    for (auto& x : vtgt) x = 1.15f * nd(rng);
     for (auto& x : vol) x = 1.15f * nd(rng);
     for (auto& x : ft) x = nd(rng) / 5.6f;
     for (auto& x : W1) x = nd(rng) * 0.03f;
@@ -34,11 +37,14 @@ int main(int argc, char** argv)
                              t * (i * k - j * r), t * (j * k + i * r), 1 - t * (i * i + j * j)};
         for (int e = 0; e < 9; ++e) R[n * 9 + e] = (float)m[e];
     }
-    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dsc;
-    uint64_t* dkey;
+    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dsc, *dvt;
+    int64_t* dkey;
+    const int spare = argc > 4 ? atoi(argv[4]) : 0;
+    const bool no_teams = argc > 5 && atoi(argv[5]) != 0;
     CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
     CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
-    CK(hipMalloc(&dsc, N * 4)); CK(hipMalloc(&dkey, 8));
+    CK(hipMalloc(&dsc, N * 4)); CK(hipMalloc(&dkey, 8)); CK(hipMalloc(&dvt, vtgt.size() * 4));
+    CK(hipMemcpy(dvt, vtgt.data(), vtgt.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dvol, vol.data(), vol.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dft, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice));
@@ -51,13 +57,22 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ref(N);
-    for (int variant = (argc > 3 ? atoi(argv[3]) : 3); variant < (argc > 3 ? atoi(argv[3]) + 1 : 5); ++variant) {
-        // 3 = the product's fp32 kernel, 4 = its opt-in split-f16 sibling (0-2, the retired round-1 formulations,
-        // left the tree in round 3; the numbering is kept so that old logs stay comparable)
+    {   // the target features of variant 3 / 4 = what variant 5 computes in the launch (so that the three can be compared)
+        ahv::ScoreLaunch a = {dvol, dvt, true, dR, 0, 0, dW1, dW2, db2, 1, 0, nullptr, nullptr, dft, cu, 0, false, false, nullptr};
+        CK(ahv::launch_score_hypotheses(a, 0));
+        CK(hipDeviceSynchronize());
+        const ahv::ScorePlan p = ahv::plan_score_launch(1, N, cu, spare, !no_teams);
+        printf("N %ld: grid %d x %d, %ld hypotheses by single waves, %ld by teams (spare CUs %d)\n", N, p.gx, p.gy,
+               (long)p.n_main, (long)(N - p.n_main), spare);
+    }
+    for (int variant = (argc > 3 ? atoi(argv[3]) : 3); variant < (argc > 3 ? atoi(argv[3]) + 1 : 6); ++variant) {
+        // 3 = the product's fp32 kernel, 4 = its opt-in split-f16 sibling, 5 = fp32 + in-launch target features (0-2,
+        // the retired round-1 formulations, left the tree in round 3; the numbering is kept so that old logs stay comparable)
         if (variant < 3) { printf("variants 0-2 are retired\n"); return 1; }
         auto launch = [&]() {
-            return ahv::launch_score_hypotheses(dvol, dft, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, cu, variant == 4,
-                                                nullptr, 0);
+            ahv::ScoreLaunch a = {dvol, variant == 5 ? dvt : dft, variant == 5, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, nullptr,
+                                  cu, spare, variant == 4, no_teams, nullptr};
+            return ahv::launch_score_hypotheses(a, 0);
         };
         for (int rep = 0; rep < 3; ++rep) {
             for (int w = 0; w < 3; ++w)
