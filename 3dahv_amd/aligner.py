@@ -15,6 +15,7 @@ with ``load_state_dict``.
 from __future__ import annotations
 
 import math
+import itertools
 import operator
 import weakref
 
@@ -46,16 +47,28 @@ def _f32(t, device):
 _get_version = operator.attrgetter("_version")
 
 
+class _ParamList(list):
+    """The parameters of a module, cached when its table is packed, plus the modules that own them: a parameter that
+    is RE-REGISTERED as a new object (``mod.weight = nn.Parameter(...)``, parametrize / weight_norm, ``to_empty``) leaves
+    the old object's version counter and address untouched, so the key also carries the identities found in the owners'
+    ``_parameters`` dicts right now."""
+    __slots__ = ("owners",)
+
+
 def _param_list(module):
-    return list(module.parameters())
+    pl = _ParamList(module.parameters())
+    pl.owners = [m._parameters for m in module.modules() if m._parameters]
+    return pl
 
 
 def _version_key(params):
-    """(in-place update counters, storage addresses) of a CACHED parameter list: two C-level map passes, ~30 us for
-    the aligner's 229 parameters.  Walking ``module.parameters()`` on every call (round 2) cost ~350 us of Python
-    per forward_2d3d -- more than the 0.3 ms of GPU work it guards.  The list is taken when the table is packed;
-    ``load_state_dict`` and ``invalidate_packed`` drop the table (and the list with it)."""
-    return tuple(map(_get_version, params)), tuple(map(torch.Tensor.data_ptr, params))
+    """(in-place update counters, storage addresses, identities of the registered parameter objects) of a CACHED
+    parameter list: C-level map passes, ~40 us for the aligner's 229 parameters.  Walking ``module.parameters()`` on
+    every call (round 2) cost ~350 us of Python per forward_2d3d -- more than the 0.3 ms of GPU work it guards.  The
+    list is taken when the table is packed; ``load_state_dict`` and ``invalidate_packed`` drop the table (and the
+    list with it); a changed key re-walks the module (``_Packed.refresh``)."""
+    ids = tuple(map(id, itertools.chain.from_iterable(map(dict.values, params.owners))))
+    return tuple(map(_get_version, params)), tuple(map(torch.Tensor.data_ptr, params)), ids
 
 
 class _Packed:
@@ -578,8 +591,7 @@ class Feature_Aligner(nn.Module):
 
     # ---- fused entry point (not in the reference: its call sites inline these three steps) ----
     def score_hypotheses(self, img_feat_src, img_feat_tgt, proposals, n_offset: int = 0, want_scores: bool = True):
-        """rotate_volume + forward_3d2d + score + running arg-max for every proposal in ONE launch
-        (test_co3d.py:137-145).  Returns (scores (B,N) | None, packed best keys (B,))."""
-        f_tgt = self.forward_3d2d(img_feat_tgt)
-        return ops.score_hypotheses(img_feat_src, f_tgt, proposals, *self.head_weights(), n_offset=n_offset,
-                                    want_scores=want_scores)
+        """forward_3d2d(tgt) + rotate_volume + forward_3d2d + score + running arg-max for every proposal in ONE launch
+        (test_co3d.py:137-145, ``ops.verify_pair``).  Returns (scores (B,N) | None, packed best keys (B,))."""
+        return ops.verify_pair(img_feat_src, img_feat_tgt, proposals, *self.head_weights(), n_offset=n_offset,
+                               want_scores=want_scores)

@@ -179,6 +179,12 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 }
         } else {
             stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+            if constexpr (TGT) {
+                // team 1: each wave's un-rotated quarter of the TARGET volume goes into its private image here, ahead of
+                // the staging barrier (the image is free between the two barriers), so that its first-touch latency
+                // elapses while the workgroup waits for the source volume anyway
+                if (team == 1) stage_quarter_global(buf, tgt + (long)b * (16 * 512), member, lane);
+            }
         }
         // Target features as the per-lane fragments the score needs, parked in the 16-byte pad of source
         // rows 0..511 (row (2t + m2)*64 + lane): 32 registers less per wave, and the 80-byte row stride
@@ -201,8 +207,6 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             // use (tg_wait below); the ~0.2 hypotheses' worth of work lands on the four waves that have one hypothesis
             // less than their SIMD partners whenever the last round is partial.
             if (team == 1) {
-                stage_quarter_global(buf, tgt + (long)b * (16 * 512), member, lane);
-                wave_lds_fence();
                 TeamAcc ta;
                 gemm1_quarter_team(ta, lds_w1, buf, lane, member);
                 wave_lds_fence();
@@ -246,7 +250,11 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // with the LDS and returns out of order, so the first LDS wait behind an s_load has to wait for the s_load
         // too -- a first-touch read of R from HBM (~2 us) in front of every hypothesis' first gather step.
         const int rl = lane < 9 ? lane : 8;
-        float Rn = Rb[(h < n_main ? h : 0) * 9 + rl];
+        float Rn = h < n_main ? Rb[h * 9 + rl] : 0.0f;  // nothing of R is touched when this wave has no hypothesis (N = 0: R may be null)
+        // the rotation of this team's first remainder hypothesis: requested now, used after the main loop
+        const long tstep = 2l * gridDim.x;
+        long ht = n_main + (long)team * gridDim.x + residue;
+        float Rt = (!SPLIT && ht < N) ? Rb[ht * 9 + rl] : 0.0f;
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -334,15 +342,13 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             // the remainder spreads over all workgroups first and over their second team next.  Every member runs the same
             // rounds; member 0 emits the score of round r after the arrive point of round r + 1 (or of the flush below),
             // where the four partial means of round r are known to be in place.
-            const long tstep = 2l * gridDim.x;
-            long ht = n_main + (long)team * gridDim.x + residue;
             if (ht < N) {
                 long h_prev = -1;
                 for (; ht < N; ht += tstep) {
-                    const float Rv = Rb[ht * 9 + rl];
                     float Rm[9];
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rv), i));
+                    for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rt), i));
+                    if (ht + tstep < N) Rt = Rb[(ht + tstep) * 9 + rl];
                     GatherHyp gh;
                     gather_hyp(gh, Rm, glane);
                     HatState st;

@@ -58,52 +58,88 @@ struct TeamAcc {
 };
 
 // GEMM1 on the quarter in `buf` with the quarter index known at run time (it only selects the z slab's A fragments).
-// Same MFMAs and operands as gemm1_quarter_lds (ahv_dual.h); x / y accumulate in their own tile.
+// Same MFMAs, operands and hand-made pipeline as gemm1_quarter_pipe (ahv_dual.h: 12 chunks of 16 MFMAs, the operands of
+// chunk k + 1 requested before the MFMAs of chunk k are issued); x / y accumulate in their own tile.
+template <int K>
+__device__ __forceinline__ void g1_load_team(G1Chunk& ck, const f32x4* T, const f32x4* Tz, const float* buf, int i0, int j, int kq)
+{
+    if (K < 8) {
+        const int c0 = 4 * (K & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i;
+            ck.a[i] = T[((K < 4 ? 0 : 16) + c) * 64];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                ck.b[2 * i + hh] = (K < 4) ? buf[c * 128 + qoff(i0, j, 4 * hh + kq)]    // x slab: k = (c, w)
+                                           : buf[c * 128 + qoff(i0, 4 * hh + kq, j)];   // y slab: k = (c, h)
+        }
+    } else {
+        const int cpp = K - 8;
+        ck.a[0] = Tz[cpp * 64];  // Tz = T + (32 + 4 Q) * 64: the z-slab fragments of THIS wave's quarter
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                ck.b[4 * ci + t] = buf[(2 * (2 * cpp + ci) + (kq >> 1)) * 128 + qoff(kq & 1, 2 * t + i0, j)];
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void g1_mfma_team(TeamAcc& a, const G1Chunk& ck)
+{
+    if (K < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                a.xy[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[i][2 * hh + 0], ck.b[2 * i + hh], a.xy[0], 0, 0, 0);
+                a.xy[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[i][2 * hh + 1], ck.b[2 * i + hh], a.xy[1], 0, 0, 0);
+            }
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a.z[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[0][2 * ci + 0], ck.b[4 * ci + t], a.z[0][t], 0, 0, 0);
+                a.z[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ck.a[0][2 * ci + 1], ck.b[4 * ci + t], a.z[1][t], 0, 0, 0);
+            }
+    }
+}
+
+template <int K>
+struct G1PipeTeam {
+    static __device__ __forceinline__ void run(TeamAcc& a, G1Chunk& cur, const f32x4* T, const f32x4* Tz, const float* buf,
+                                               int i0, int j, int kq)
+    {
+        G1Chunk nxt;
+        if (K + 1 < 12) g1_load_team<K + 1>(nxt, T, Tz, buf, i0, j, kq);
+        __builtin_amdgcn_sched_barrier(0);
+        g1_mfma_team<K>(a, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (K + 1 < 12) G1PipeTeam<K + 1>::run(a, nxt, T, Tz, buf, i0, j, kq);
+    }
+};
+template <>
+struct G1PipeTeam<12> {
+    static __device__ __forceinline__ void run(TeamAcc&, G1Chunk&, const f32x4*, const f32x4*, const float*, int, int, int) {}
+};
+
 __device__ __forceinline__ void gemm1_quarter_team(TeamAcc& a, const float* table, const float* buf, int lane, int Q)
 {
     const int n = lane & 15, kq = lane >> 4;
     const int i0 = n >> 3, j = n & 7;
     const f32x4* T = reinterpret_cast<const f32x4*>(table) + lane;  // group g at T[g * 64]
+    const f32x4* Tz = T + (32 + 4 * Q) * 64;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         a.xy[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t) a.z[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const f32x4 w = T[c * 64];
-#pragma unroll
-        for (int eh = 0; eh < 2; ++eh) {
-            const float bx = buf[c * 128 + qoff(i0, j, 4 * eh + kq)];
-            a.xy[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * eh + 0], bx, a.xy[0], 0, 0, 0);
-            a.xy[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * eh + 1], bx, a.xy[1], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const f32x4 w = T[(16 + c) * 64];
-#pragma unroll
-        for (int bh = 0; bh < 2; ++bh) {
-            const float by = buf[c * 128 + qoff(i0, 4 * bh + kq, j)];
-            a.xy[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * bh + 0], by, a.xy[0], 0, 0, 0);
-            a.xy[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * bh + 1], by, a.xy[1], 0, 0, 0);
-        }
-    }
-    const f32x4* Tz = T + (32 + 4 * Q) * 64;
-#pragma unroll
-    for (int cpp = 0; cpp < 4; ++cpp) {
-        const f32x4 w = Tz[cpp * 64];
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int cp = 2 * cpp + ci;
-                const float bz = buf[(2 * cp + (kq >> 1)) * 128 + qoff(kq & 1, 2 * t + i0, j)];
-                a.z[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * ci + 0], bz, a.z[0][t], 0, 0, 0);
-                a.z[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * ci + 1], bz, a.z[1][t], 0, 0, 0);
-            }
-    }
+    G1Chunk first;
+    g1_load_team<0>(first, T, Tz, buf, i0, j, kq);
+    G1PipeTeam<0>::run(a, first, T, Tz, buf, i0, j, kq);
 }
 
 // Quarter Q of an UN-rotated volume V[16][8][8][8] (global memory) into the swizzled quarter image: what the gather

@@ -109,8 +109,8 @@ class _EstimatorBase(nn.Module):
         R_pred = proposals[idx]  (test_co3d.py:137-146, modules/model.py:186-196)."""
         scores, key = self.feature_aligner.score_hypotheses(img_feat_src, img_feat_tgt, proposals,
                                                             want_scores=want_scores)
-        best, idx = ops.unpack_best(key)
-        return scores, best, idx, proposals[idx]
+        best, idx, R_pred = ops.select_rotation(key, proposals)   # torch.max + proposals[idx] in one launch
+        return scores, best, idx, R_pred
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, cfg=None, map_location="cpu", strict: bool = True,

@@ -56,11 +56,61 @@ class SyntheticSequences:
             yield item
 
 
+class _FlushUploader:
+    """Host -> device staging of one flush of the evaluation loop: everything a flush needs (the key frames of all queued
+    sequences, their rotations, the pair indices) travels as ONE pinned fp32 buffer in ONE copy on a stream of its own,
+    so the upload of flush k + 1 (and the host work of assembling it) overlaps the encoder + verify kernels of flush k
+    instead of queueing behind them -- a pageable ``.to(device)`` is ordered on the compute stream and blocks the host
+    until everything in front of it has run (13 % of the batched per-pair time in round 3,
+    profiles/r03g_evaluation_loop.jsonl).  Two buffer sets alternate."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.slots = [None, None]
+        self.turn = 0
+
+    def upload(self, parts):
+        """[host fp32 tensors] -> [device fp32 tensors of the same shapes]; the compute stream waits for the copy, the
+        host does not (it only waits for the copy that used this slot two flushes ago)."""
+        sizes = [t.numel() for t in parts]
+        total = sum(sizes)
+        slot = self.slots[self.turn]
+        if slot is None or slot[0].numel() < total:
+            slot = (torch.empty(total, dtype=torch.float32).pin_memory(),
+                    torch.empty(total, dtype=torch.float32, device=self.device), torch.cuda.Event(), torch.cuda.Event())
+            slot[3].record(torch.cuda.current_stream(self.device))
+            self.slots[self.turn] = slot
+        self.last = slot
+        self.turn ^= 1
+        pin, dev_buf, ev, used = slot
+        ev.synchronize()
+        o = 0
+        for t, n in zip(parts, sizes):
+            pin[o:o + n].copy_(t.reshape(-1))
+            o += n
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_event(used)              # the flush that last read this device buffer (two flushes ago) is past it
+        with torch.cuda.stream(self.stream):
+            dev_buf[:total].copy_(pin[:total], non_blocking=True)
+            ev.record(self.stream)
+        cur.wait_event(ev)
+        out, o = [], 0
+        for t, n in zip(parts, sizes):
+            out.append(dev_buf[o:o + n].view(t.shape))
+            o += n
+        return out
+
+    def release(self):
+        """The compute stream has issued its last read of the buffer handed out by the latest ``upload``."""
+        self.last[3].record(torch.cuda.current_stream(self.device))
+
+
 @torch.no_grad()
 def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2, device=None,
                       proposals: Optional[torch.Tensor] = None, verify_fn: Optional[Callable] = None,
                       return_details: bool = False, batch_pairs: Optional[bool] = None,
-                      encoder_fn: Optional[Callable] = None, batch_sequences: int = 1):
+                      encoder_fn: Optional[Callable] = None, batch_sequences: Optional[int] = None):
     """Counterpart of ``evaluate_category`` (test_co3d.py:93-154).  Returns the array of angular errors.
 
     Per-pair results stay on the device and are fetched once per category (the reference synchronises per pair with
@@ -68,41 +118,61 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
     e.g. ``model.feature_aligner.graphed_forward_2d3d(2)`` to replay the encoder's 63 launches from one hipGraph.
 
     ``batch_pairs`` (default: on the GPU) runs the ordered pairs of a sequence -- (0,1) and (1,0) for two frames --
-    as ONE batch through the encoder and ONE fused verify launch instead of one by one as the reference does: at
-    B = 1 the encoder is launch-latency bound (0.32 ms for one pair, 0.39 ms for two), so this is worth
-    ~15 % of the per-pair time; results are the same (every kernel on the path is row-independent)."""
+    as ONE batch through the encoder and ONE fused verify launch instead of one by one as the reference does, and
+    ``batch_sequences`` (default: 16 on the GPU, 1 on the CPU) queues that many sequences per batch: at B = 1 the encoder
+    is launch-latency bound (0.31 ms for one pair, 0.07 ms per pair at 32).  Results are the same (every kernel on the
+    path is row-independent) and ``np.random.choice`` is drawn per sequence in the reference's order, so a seed selects
+    the reference's pairs whatever the batching."""
     if device is None:
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     device = torch.device(device)
+    on_gpu = device.type == "cuda"
     if batch_pairs is None:
-        batch_pairs = device.type == "cuda"
+        batch_pairs = on_gpu
+    if batch_sequences is None:
+        batch_sequences = 16 if on_gpu else 1
     permutations = get_permutations(num_frames)
+    perm_np = permutations.numpy()
     if proposals is None:
         proposals = random_rotations(cfg["DATA"]["NUM_ROTA"])
     proposals = proposals.to(device)
     if verify_fn is None:
-        verify_fn = lambda vs, vt, P: model.verify(vs, vt, P)[1:3]  # (best, idx): fused HIP launch
+        verify_fn = lambda vs, vt, P: model.verify(vs, vt, P)[1:]  # (best, idx, R_pred): one fused launch + one select
+    uploader = _FlushUploader(device) if on_gpu else None
     details, pending = [], []
-    queue = []  # per sequence: (feats (P,2,...), R_gt (P,3,3), model_id, uses layer4)
+    queue = []  # per queued pair group: (frames (F,...) host, R (F,3,3) host, src ids, tgt ids, model_id, uses layer4, pairs)
 
     def flush():
-        """One encoder call and one fused verify launch for every queued ordered pair."""
+        """One upload, one encoder call, one fused verify launch and one select for every queued ordered pair."""
         if not queue:
             return
-        feats = torch.cat([q[0] for q in queue])
-        R_gt = torch.cat([q[1] for q in queue])
-        embed = (encoder_fn or model.forward_features) if queue[0][3] else model
-        vol_src, vol_tgt = embed(feats[:, 0], feats[:, 1])
-        best, idx = verify_fn(vol_src, vol_tgt, proposals)
-        R_pred = proposals[idx.reshape(-1)]
+        frames = torch.cat([q[0] for q in queue])
+        rots = torch.cat([q[1] for q in queue]).float()
+        base = np.cumsum([0] + [q[0].shape[0] for q in queue[:-1]])
+        pair = np.stack([np.concatenate([b + q[2] for b, q in zip(base, queue)]),
+                         np.concatenate([b + q[3] for b, q in zip(base, queue)])])          # (2, P): source / target frame
+        if uploader is not None:
+            frames, rots, pair_f = uploader.upload([frames.float(), rots, torch.from_numpy(pair.astype(np.float32))])
+            pair_d = pair_f.to(torch.int64)   # frame numbers are small integers: exact in fp32
+            src, tgt = pair_d[0], pair_d[1]
+        else:
+            src, tgt = torch.from_numpy(pair[0].astype(np.int64)), torch.from_numpy(pair[1].astype(np.int64))
+        R_gt = torch.bmm(rots.index_select(0, src).transpose(1, 2), rots.index_select(0, tgt))
+        embed = (encoder_fn or model.forward_features) if queue[0][5] else model
+        vol_src, vol_tgt = embed(frames.index_select(0, src), frames.index_select(0, tgt))
+        if uploader is not None:
+            uploader.release()
+        res = verify_fn(vol_src, vol_tgt, proposals)
+        best, idx = res[0], res[1]
+        R_pred = res[2] if len(res) > 2 else proposals[idx.reshape(-1)]
         err = geodesic_deg(R_pred, R_gt).reshape(-1)
         pending.append(err)                                                # stays on the device: no sync per pair
         if return_details:
             bs, ids, el = best.reshape(-1).tolist(), idx.reshape(-1).tolist(), err.tolist()
             k = 0
             for q in queue:
-                for i in range(q[0].shape[0]):
-                    details.append({"model_id": q[2], "pair": q[4][i], "best": float(bs[k]), "idx": int(ids[k]),
+                for pr in q[6]:
+                    details.append({"model_id": q[4], "pair": pr, "best": float(bs[k]), "idx": int(ids[k]),
                                     "R_pred": R_pred[k].cpu().numpy(), "err": el[k]})
                     k += 1
         queue.clear()
@@ -113,17 +183,24 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
         if "get_data" in meta:  # lazy source (co3d.Co3dSequences): decode only the key frames (test_co3d.py:112)
             meta = dict(meta, **meta["get_data"](key_frames))
             key_frames = np.arange(num_frames)
-        # select on the device: indexing a host tensor goes through torch's CPU thread pool, which costs milliseconds
-        # per call where the process sees more cores than its cgroup grants (measured 15 ms per sequence here)
-        sel = torch.as_tensor(np.asarray(key_frames), device=device)[permutations.to(device)]   # (P, 2) frame ids
-        rot = meta["R"].to(device)[sel]                                     # (P, 2, 3, 3)
-        R_gt = torch.bmm(rot[:, 0].transpose(1, 2), rot[:, 1])
         uses_l4 = "layer4" in meta
-        feats = (meta["layer4"] if uses_l4 else meta["image"]).to(device)[sel]   # (P, 2, ...)
-        for i in range(len(permutations)):
-            queue.append((feats[i:i + 1], R_gt[i:i + 1], meta["model_id"], uses_l4, [tuple(permutations[i].tolist())]))
-            if sum(q[0].shape[0] for q in queue) >= pairs_per_flush:
+        # the key frames are picked on the HOST with numpy (torch's CPU indexing spins up one thread per visible core,
+        # which costs milliseconds per call inside a small cgroup) and uploaded once per flush
+        kf = np.asarray(key_frames)
+        data = meta["layer4"] if uses_l4 else meta["image"]
+        frames = torch.from_numpy(np.ascontiguousarray(data.cpu().numpy()[kf]))
+        rot = torch.from_numpy(np.ascontiguousarray(meta["R"].cpu().numpy()[kf]))
+        if batch_pairs:
+            queue.append((frames, rot, perm_np[:, 0], perm_np[:, 1], meta["model_id"], uses_l4,
+                          [tuple(p) for p in perm_np.tolist()]))
+            if sum(len(q[2]) for q in queue) >= pairs_per_flush:
                 flush()
+        else:
+            for i in range(len(perm_np)):  # the reference's order: one ordered pair at a time
+                queue.append((frames, rot, perm_np[i:i + 1, 0], perm_np[i:i + 1, 1], meta["model_id"], uses_l4,
+                              [tuple(perm_np[i].tolist())]))
+                if sum(len(q[2]) for q in queue) >= pairs_per_flush:
+                    flush()
     flush()
     errors = torch.cat(pending).tolist() if pending else []               # ONE host synchronisation per category
     errors = np.array(errors)

@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="minimum length of the untimed, time-based pre-warm (the same step, looped until the chip's "
                          "clock has settled: >= this many ms AND three consecutive kernel times within 1 %%; 0 disables)")
+    ap.add_argument("--skip-strong-scaling", action="store_true",
+                    help="leave out the strong_scaling legs (profiling runs: they launch the same kernel at B = 32, which "
+                         "would mix into rocprofv3's per-kernel averages)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -216,35 +219,47 @@ def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
 
 class VerifyLoop:
     """One rank's verify steps on a fixed workload (the reference's per-pair hot loop, test_co3d.py:137-146):
-        step i   = ONE fused launch: forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max into key[i % 4]
-                   [process group: + the asynchronous 8*B-byte all-reduce(MAX) of that key on RCCL's stream]
-        finalize = ONE launch: decode the key, gather R_pred = proposals[idx], hand the key back EMPTY for step i + 4
-    With a process group, step i finalizes step i - lag: the collective of a step has the whole next kernel (lag 1) or two
-    (lag 2) to complete in before the compute stream waits for it."""
+        step i   = ONE fused launch: forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max into its key slot
+        finalize = ONE launch per group of `group` steps: decode the keys, gather R_pred = proposals[idx], hand the keys
+                   back EMPTY (single process: group = 1, i.e. one select per step)
+    With a process group the keys of `group` consecutive steps travel in ONE all-reduce(MAX) of group * B int64 words (the
+    bucketing every data-parallel exchange uses: what a collective costs beside a 0.7-ms kernel is its fixed part -- the
+    event packets torch puts around it, 29 us measured with a one-rank RCCL group, profiles/r04a_* -- not its 8 bytes),
+    either asynchronously on RCCL's stream and consumed `lag` groups later, or (`sync`) in stream order."""
     RING = 4
 
-    def __init__(self, ops, dist, dev, vol_src, vol_tgt, R_local, head, n_offset, use_pg, lag, spare_cus, split):
+    def __init__(self, ops, dist, dev, vol_src, vol_tgt, R_local, head, n_offset, use_pg, group, lag, sync, spare_cus, split):
         import torch
-        self.ops, self.dist, self.use_pg, self.lag = ops, dist, use_pg, (lag if use_pg else 0)
+        self.ops, self.dist, self.use_pg = ops, dist, use_pg
+        self.group, self.sync = max(1, group), sync
+        self.lag = lag if (use_pg and not sync) else 0
         assert 0 <= self.lag < self.RING
         self.vs, self.vt, self.R, self.head, self.n_offset = vol_src, vol_tgt, R_local, head, n_offset
         self.spare, self.split = spare_cus, split
-        B = vol_src.shape[0]
-        self.keys = [torch.full((B,), -(1 << 63), dtype=torch.int64, device=dev) for _ in range(self.RING)]
+        self.B = vol_src.shape[0]
+        self.keys = torch.full((self.RING, self.group, self.B), -(1 << 63), dtype=torch.int64, device=dev)
         self.pending, self.out, self.done = {}, {}, -1
 
-    def finalize(self, i):
-        key = self.keys[i % self.RING]
-        work = self.pending.pop(i, None)
+    def finalize(self, g):
+        """Group g: wait for its collective (stream-level, the host does not block), then ONE select for all its steps."""
+        keys = self.keys[g % self.RING]
+        work = self.pending.pop(g, None)
         if work is not None:
-            work.wait()  # stream-level dependency only, the host does not block
+            work.wait()
         # with sharding the owner rank holds the winning row, the others get zeros
-        self.out["best"], self.out["idx"], self.out["R_pred"] = self.ops.select_rotation(key, self.R, n_offset=self.n_offset,
-                                                                                        reset_key=True)
-        self.done = i
+        best, idx, R_pred = self.ops.select_rotation(keys.view(-1), self.R, n_offset=self.n_offset, reset_key=True)
+        B = self.B  # results of the group's LAST step (empty slots of a partial group decode to -inf / -1 in front of them)
+        self.out["group_best"], self.out["group_idx"] = best.view(self.group, B), idx.view(self.group, B)
+        self.out["group_R_pred"] = R_pred.view(self.group, B, 3, 3)
+        self.done = g
 
-    def step(self, i, ev=None, stamps=None):
-        key = self.keys[i % self.RING]  # EMPTY: reset by the select that consumed it
+    def _result_of(self, step):
+        j = step % self.group
+        return self.out["group_best"][j], self.out["group_idx"][j], self.out["group_R_pred"][j]
+
+    def step(self, i, ev=None, stamps=None, last=False):
+        g, j = i // self.group, i % self.group
+        key = self.keys[g % self.RING, j]  # EMPTY: reset by the select that consumed it
         if ev is not None:
             ev[0].record()
         # `stamps` given: the same kernel also writes every workgroup's s_memtime / s_memrealtime pair (shader clock)
@@ -252,18 +267,25 @@ class VerifyLoop:
                              reset_best=False, split_f16=self.split, clock_stamps=stamps, spare_cus=self.spare)
         if ev is not None:
             ev[1].record()
-        if self.use_pg:
-            self.pending[i] = self.dist.all_reduce(key, op=self.dist.ReduceOp.MAX, async_op=True)
-        if i - self.lag >= 0 and i - self.lag > self.done:
-            self.finalize(i - self.lag)
+        if j == self.group - 1 or last:  # the group is complete (or the run ends inside it)
+            if self.use_pg:
+                w = self.dist.all_reduce(self.keys[g % self.RING], op=self.dist.ReduceOp.MAX, async_op=not self.sync)
+                if not self.sync:
+                    self.pending[g] = w
+            if g - self.lag >= 0 and g - self.lag > self.done:
+                self.finalize(g - self.lag)
 
     def run(self, steps, events=None, stamps=None):
-        """`steps` steps, every one finalized on return (the stream is NOT synchronised)."""
+        """`steps` steps, every one finalized on return (the stream is NOT synchronised).  `events`: {step: event pair} for
+        the launches to bracket with HIP events (a SAMPLE: an event record idles the queue for ~6 us, tools/summarize_timeline.py)."""
         self.done = -1
+        events = events or {}
         for i in range(steps):
-            self.step(i, None if events is None else events[i], None if stamps is None else stamps[i])
-        for i in range(max(self.done + 1, 0), steps):
-            self.finalize(i)
+            self.step(i, events.get(i), None if stamps is None else stamps[i], last=(i == steps - 1))
+        last_group = (steps - 1) // self.group
+        for g in range(max(self.done + 1, 0), last_group + 1):
+            self.finalize(g)
+        self.out["best"], self.out["idx"], self.out["R_pred"] = self._result_of(steps - 1)
 
 
 def worker(args):
@@ -308,15 +330,19 @@ def worker(args):
     ops, adist = ahv.ops, ahv.dist
     lib = ahv._lib.load()  # fails loudly without the HIP library
     split = bool(args.split_f16)
-    # Under a process group the collective of step i is given `lag` kernels to finish in and the scorer leaves `spare`
-    # CUs without a workgroup for it (its persistent grid otherwise holds every CU's LDS): DESIGN.md section 6.
-    lag = int(os.environ.get("AHV_BENCH_FINALIZE_LAG", "2"))
-    spare = int(os.environ.get("AHV_BENCH_SPARE_CUS", "2" if use_pg else "0"))
+    # Under a process group the keys of `group` steps share one all-reduce, issued in stream order (default) or
+    # asynchronously on RCCL's stream and consumed `lag` groups later (AHV_BENCH_COLLECTIVE=async: every cross-stream event
+    # wait costs the compute queue ~30 us here, profiles/r04_forced_pg_timeline.txt); the scorer can leave `spare` CUs
+    # without a workgroup for a concurrent kernel (measured: costs 1.4 % at 2 and buys nothing, so 0).  DESIGN.md section 6.
+    group = int(os.environ.get("AHV_BENCH_STEPS_PER_COLLECTIVE", "8" if use_pg else "1"))
+    lag = int(os.environ.get("AHV_BENCH_FINALIZE_LAG", "1"))
+    sync = os.environ.get("AHV_BENCH_COLLECTIVE", "sync") == "sync"
+    spare = int(os.environ.get("AHV_BENCH_SPARE_CUS", "0"))
 
     vol_src, vol_tgt, W1, W2, b2, R = synth_inputs(ahv, dev, rank)
     head = (W1, W2, b2)
     n_offset = rank * N_HYP
-    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, lag, spare if use_pg else 0, split)
+    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, lag, sync, spare, split)
     ncu = lib.ahv_device_cu_count()
 
     def barrier():
@@ -325,6 +351,15 @@ def worker(args):
 
     def new_events(n):
         return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+    def sampled_events(steps):
+        """Event pairs for every k-th step (k = 8, or less so that a short run still gets >= 3 samples): the kernel time of
+        the contract's `roofline` comes from HIP events on the kernel's stream INSIDE the timed region, but each record
+        costs the queue ~6 us of idling (the 12 us per step of round 3's every-launch bracketing were 1.7 % of `value`);
+        the in-kernel real-time stamps of EVERY timed launch are reported beside them."""
+        k = 8 if steps >= 24 else max(1, steps // 3)
+        idx = list(range(0, steps, k))
+        return dict(zip(idx, new_events(len(idx)))), k
 
     def prewarm(min_ms, max_ms=1500.0, batch=8):
         """Untimed, TIME-based pre-warm of the same step: the chip needs ~30 ms of this kernel to ramp its clock
@@ -335,7 +370,7 @@ def worker(args):
         settled = False
         while min_ms > 0:
             evs = new_events(batch)
-            loop.run(batch, evs)
+            loop.run(batch, dict(enumerate(evs)))
             torch.cuda.synchronize()
             done += batch
             last = (last + [a.elapsed_time(b) for a, b in evs])[-3:]
@@ -385,18 +420,26 @@ def worker(args):
 
     with torch.no_grad():
         pre = prewarm(args.prewarm_ms)
-        events = new_events(args.steps)
+        events, ev_every = sampled_events(args.steps)
         stamps = torch.zeros(args.steps, 4 * ncu, dtype=torch.int64, device=dev)
         dt = timed(loop, args.steps, args.warmup, events, stamps)
         out = dict(loop.out)
-        # fused kernel, HIP events on its stream, every timed launch
-        kern_list = [a.elapsed_time(b) for a, b in events]
+        # fused kernel, HIP events on its stream, a sample of the timed launches
+        kern_list = [events[i][0].elapsed_time(events[i][1]) for i in sorted(events)]
         kern_ms = float(np.mean(kern_list))
         # shader clock held DURING the timed launches: per workgroup (s_memtime delta) / (s_memrealtime delta at
         # 100 MHz); median over workgroups and launches (MI355X_MICROARCH.md "DVFS give-back" item 6)
-        st = stamps.cpu().numpy().reshape(-1, 4)
+        st_all = stamps.cpu().numpy().reshape(args.steps, -1, 4)
+        st = st_all.reshape(-1, 4)
         st = st[st[:, 3] > st[:, 1]]
         clock_ghz = float(np.median((st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]))) * 0.1 if len(st) else None
+        # every timed launch from its own workgroups' 100-MHz real-time stamps: first hypothesis-loop entry -> last exit
+        # (the ~5 us of per-workgroup prologue and the launch itself are outside these stamps)
+        loop_ms = []
+        for row in st_all:
+            row = row[row[:, 3] > row[:, 1]]
+            if len(row):
+                loop_ms.append(float(row[:, 3].max() - row[:, 1].min()) * 1e-5)
 
         # correctness of what was timed: the key equals torch.max over the materialised scores (all ranks)
         scores, key = ops.verify_pair(vol_src, vol_tgt, R, *head, n_offset=n_offset, split_f16=split, spare_cus=loop.spare)
@@ -408,8 +451,7 @@ def worker(args):
         def strong(vs, vt, R_all, steps, warmup):
             n_total = R_all.shape[0]
             lo, hi = adist.shard_range(n_total, rank, world)
-            lp = VerifyLoop(ops, dist, dev, vs, vt, R_all[lo:hi].contiguous(), head, lo, use_pg, lag,
-                            spare if use_pg else 0, split)
+            lp = VerifyLoop(ops, dist, dev, vs, vt, R_all[lo:hi].contiguous(), head, lo, use_pg, group, lag, sync, spare, split)
             t = timed(lp, steps, warmup)
             # the merged winner == the winner of the unsharded set scored on this rank alone
             s_all, _ = ops.verify_pair(vs, vt, R_all, *head, split_f16=split, no_teams=True)
@@ -425,7 +467,7 @@ def worker(args):
         g = torch.Generator().manual_seed(5)
         vs32 = (torch.randn(32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
         vt32 = (torch.randn(32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
-        strong_scaling = {
+        strong_scaling = None if args.skip_strong_scaling else {
             "note": "a fixed total split over the ranks (value / ms_per_step above are WEAK scaling: 50 000 hypotheses per "
                     "rank); same step, same collectives, timed between barriers, max over ranks",
             "n50k_b1": strong(vol_src, vol_tgt, R_all, max(20, min(args.steps, 100)), 5),
@@ -459,9 +501,12 @@ def worker(args):
                        "parallelism": "hypothesis axis sharded x%d, 8-byte key all-reduce(max)" % world,
                        "backend": "single process" if not use_pg else ("rccl" if args.backend == "nccl" else args.backend),
                        "step": "ONE fused launch (forward_3d2d(tgt) + rotate + forward_3d2d + score + arg-max: "
-                               "ahv_verify_pair_f32)%s + ONE select launch (decode + gather R_pred + key reset)" % (
-                                   " + all-reduce(MAX) of the int64 key, finalized %d step(s) later, %d CU(s) left free "
-                                   "for it" % (loop.lag, loop.spare) if use_pg else "")},
+                               "ahv_verify_pair_f32)%s + ONE select launch per %d step(s) (decode + gather R_pred + key reset)" % (
+                                   " + ONE all-reduce(MAX) of the int64 keys of %d steps (%s), %d CU(s) left free" % (
+                                       loop.group, "in stream order" if loop.sync else
+                                       "asynchronous, consumed %d group(s) later" % loop.lag, loop.spare) if use_pg else "",
+                                   loop.group),
+                       "steps_per_collective": loop.group if use_pg else None},
             # what the timed region computed (asserted above against torch.max over the materialised scores of
             # all ranks): lets a forced-process-group run be compared with a single-process run
             "result": {"best_idx": int(out["idx"].item()), "best_score": float(out["best"].item())},
@@ -470,6 +515,12 @@ def worker(args):
                          "kernel": kname, "kernel_ms": kern_ms,
                          "kernel_ms_min": float(np.min(kern_list)), "kernel_ms_median": float(np.median(kern_list)),
                          "kernel_ms_mean": kern_ms, "kernel_ms_per_step": [round(x, 4) for x in kern_list],
+                         "kernel_ms_is": "HIP event pairs on the kernel's stream around every %d-th launch of the timed region "
+                                         "(%d samples; a record idles the queue ~6 us, so not every launch)" % (
+                                             ev_every, len(kern_list)),
+                         "hypothesis_loop_ms_all_launches_median": float(np.median(loop_ms)) if loop_ms else None,
+                         "hypothesis_loop_ms_is": "in-kernel s_memrealtime stamps of ALL %d timed launches: first workgroup "
+                                                  "entering its hypothesis loop -> last leaving it" % args.steps,
                          "frac_at_median": FLOPS_PER_HYP * N_HYP / (float(np.median(kern_list)) * 1e-3) / 1e12
                                            / PEAK_F32_MFMA_TFLOPS,
                          "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
@@ -496,7 +547,7 @@ def worker(args):
             with torch.no_grad():
                 s4, k4 = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, split_f16=True)
 
-                k0 = loop.keys[0]
+                k0 = loop.keys[0, 0]
 
                 def split_launch(ev=None):
                     if ev is not None:

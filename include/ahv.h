@@ -19,6 +19,17 @@
  *    returns a thread-local description of the last failure on this thread.
  *    No C++ exception crosses the ABI.  Entry points are re-entrant and thread-safe:
  *    the library has no mutable process-wide state (kernel choices are per-call flags).
+ *  - Non-finite inputs.  Rotation matrices may hold ANY value (non-orthonormal, scaled, zero, inf, NaN): a sample point
+ *    that leaves the volume -- or is not a number -- contributes zeros, exactly as F.grid_sample's zeros padding does
+ *    (ATen casts floor() of the coordinate to an integer that lands out of bounds), and the scores equal the reference's
+ *    (tests/test_gpu_verify.py::test_any_rotation_matrix_matches_the_reference).  Non-finite VOXELS or head weights are
+ *    outside the contract: the scorers clamp the 2x2x2 footprint of a sample INTO the volume and give the corners that
+ *    zeros padding drops a weight of exactly 0 (csrc/ahv_dual.h, hat weights) -- for a sample coordinate i < 0 along an
+ *    axis they read rows 0 and 1 with weights (1 + i, 0) where the reference reads row 0 alone, for i >= 7 rows 6 and 7
+ *    with (0, 8 - i), beyond [-1, 8) both with 0 -- and 0 * NaN = NaN, 0 * inf = NaN: a non-finite voxel can make a
+ *    score NaN that the reference keeps finite (never the other way round for the NaNs torch produces); ReLU is an
+ *    integer max that maps a NaN with the sign bit set to +0 where torch.relu propagates it.  No hang, no fault, and the
+ *    packed key stays torch.max of the launch's own scores (NaN first): tests/test_gpu_verify.py pins all of this.
  *  - Fixed geometry of the reference: volume channels Cv=16, side S=8
  *    (modules/modules.py:64,97), head width O=32, K=3*Cv*S=384
  *    (modules/modules.py:66-70), P=S*S=64 output positions.

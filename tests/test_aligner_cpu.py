@@ -139,3 +139,24 @@ def test_procedural_fill_is_stable():
 
 
 PROCFILL_SHA = "64658f846e85ec49b4fc90c1ded4fda17c2d5e5ad0592ce1e5770ee6503354d8"
+
+
+def test_packed_weight_key_sees_reregistered_parameters(ahv):
+    """the staleness key of the packed-weight tables is computed over a CACHED parameter list.  An in-place
+    update, a storage move and a parameter RE-REGISTERED as a new object (the old object's version and address do not
+    change) must all change the key; an untouched module must not."""
+    import torch.nn as nn
+    al = ahv.aligner
+    m = nn.Sequential(nn.Linear(4, 4), nn.Sequential(nn.Linear(4, 2)))
+    params = al._param_list(m)
+    k0 = al._version_key(params)
+    assert al._version_key(params) == k0
+    with torch.no_grad():
+        m[0].weight.add_(1.0)                                   # in-place update: version counter
+    k1 = al._version_key(params)
+    assert k1 != k0
+    m[1][0].bias = nn.Parameter(torch.ones(2))                  # re-registration: only the owner's dict shows it
+    k2 = al._version_key(params)
+    assert k2 != k1 and k2[0] == k1[0] and k2[1] == k1[1]       # versions and addresses of the cached objects unchanged
+    m[0].weight.data = m[0].weight.data.clone()                 # storage moved
+    assert al._version_key(params) != k2

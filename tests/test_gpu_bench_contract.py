@@ -36,14 +36,13 @@ def test_bench_json_line():
     assert "ms" not in d["config"] and d["config"]["backend"] == "single process"
     # the time-based pre-warm ran (>= 60 ms of the same step) and is disclosed; the per-step list is complete
     assert d["prewarm_ms"] >= 60.0 and d["prewarm_steps"] >= 8
-    assert len(r["kernel_ms_per_step"]) == 5
+    assert len(r["kernel_ms_per_step"]) == 5 and "every 1-th launch" in r["kernel_ms_is"]   # 5 steps: all bracketed
+    assert 0.5 * r["kernel_ms"] < r["hypothesis_loop_ms_all_launches_median"] <= r["kernel_ms"]
     assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= max(r["kernel_ms_per_step"]) + 1e-6
     assert abs(r["kernel_ms_mean"] - r["kernel_ms"]) < 1e-12
     assert "TIMED launches" in r["shader_clock_source"]
     assert out.stdout.strip() == lines[0]                                  # stdout = the one JSON line, nothing else
-    # one step = ONE fused launch + ONE select launch: what is not the scorer stays small (21 us in round 3)
-    assert r["kernel"].startswith("score_hypotheses_dual_kernel<false, true>")
-    assert d["ms_per_step"] - r["kernel_ms"] < 0.015, (d["ms_per_step"], r["kernel_ms"])
+    assert r["kernel"].startswith("score_hypotheses_dual_kernel<false, true>")   # the one-launch verify step
     # the strong-scaling record of the same run: a fixed total split over the ranks (one rank here: everything)
     ss = d["strong_scaling"]
     a, b = ss["n50k_b1"], ss["configs3_b32_n50k"]
@@ -71,10 +70,13 @@ def test_bench_rccl_branch_on_one_gpu():
     a, b = run({}), run({"AHV_BENCH_FORCE_PG": "1"})
     assert a["config"]["backend"] == "single process" and b["config"]["backend"] == "rccl"
     assert b["n_gpus"] == 1 and a["result"] == b["result"]
-    assert "finalized 2 step(s) later" in b["config"]["step"]
-    # The collective is hidden: the int64 key goes into the all-reduce as the kernel packed it (no re-encoding launches) and
-    # is consumed two steps later, so the step with the process group costs what the step without it costs (round 3: +4.6 %).
-    # Two processes seconds apart differ by the clock they are granted (<= 1 %): one repeat before judging.
+    assert b["config"]["steps_per_collective"] == 8 and a["config"]["steps_per_collective"] is None
+    # one step = ONE fused launch + ONE select launch: what is not the scorer stays small (21 us in round 3)
+    assert a["ms_per_step"] - a["roofline"]["kernel_ms"] < 0.010, (a["ms_per_step"], a["roofline"]["kernel_ms"])
+    # The collective is cheap: the int64 keys go into the all-reduce as the kernel packed them (no re-encoding launches),
+    # eight steps' keys per collective, consumed one group later -- so the step with the process group costs what the step
+    # without it costs (round 3: +4.6 %).  Two processes seconds apart differ by the clock they are granted (<= 1 %):
+    # one repeat before judging.
     ta, tb = a["ms_per_step"], b["ms_per_step"]
     if tb > 1.02 * ta:
         ta, tb = min(ta, run({})["ms_per_step"]), min(tb, run({"AHV_BENCH_FORCE_PG": "1"})["ms_per_step"])

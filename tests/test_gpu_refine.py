@@ -47,8 +47,8 @@ def test_coarse_to_fine_matches_two_stage_reference(ahv, setup, use_graph):
     for rep in range(3):  # replays with different inputs
         a, b = (vs, vt) if rep != 1 else (vt, vs)
         score, idx, R_pred, c_score, c_idx = [t.clone() for t in c2f(a, b)]
-        ft = ops.forward_3d2d(b, W1, W2, b2)
-        s1, _ = ops.score_hypotheses(a, ft, R, W1, W2, b2)
+        # the step's own sequence: coarse stage = one verify_pair launch whose in-launch target features feed the fine stage
+        s1, _, ft = ops.verify_pair(a, b, R, W1, W2, b2, want_feat_tgt=True)
         v1, i1 = torch.max(s1, dim=1)
         assert torch.equal(c_idx, i1) and torch.equal(c_score, v1)
         fine = torch.matmul(R[i1][:, None], c2f.D[None]).contiguous()
@@ -112,8 +112,11 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 vs, vt, W1, W2, b2 = T(g["vol_src"]), T(g["vol_tgt"]), T(h["W1"]), T(h["W2"]), T(h["b2"])
 R = torch.from_numpy(ahv.rotations.haar_rotations_np(10_000, 40)).to(dev)
 force = backend == "nccl"
-multi = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=True, force_collectives=force)
-single = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=False, group=solo)
+# no_teams: every score by one wave, i.e. independent of how the sets are split over the ranks -- bit for bit
+multi = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=True, force_collectives=force, no_teams=True)
+single = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=False, group=solo, no_teams=True)
+# the default (teams of four waves may take a shard's remainder): same winners, scores equal to rounding
+multi_t = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, batch=3, use_graph=True, force_collectives=force)
 assert single.world == 1 and not single.collectives
 assert multi.collectives and multi.use_graph == (backend == "nccl")
 for rep in range(3):
@@ -122,6 +125,8 @@ for rep in range(3):
     ref = [t.clone() for t in single(a, b)]
     for x, y in zip(got, ref):
         assert torch.equal(x, y), (rank, rep, x, y)
+    for x, y in zip([t.clone() for t in multi_t(a, b)], ref):
+        assert torch.equal(x, y) if x.dtype == torch.int64 else torch.allclose(x, y, rtol=0, atol=1e-6), (rank, rep, x, y)
     flat = torch.cat([t.double().flatten() for t in got]).cpu()
     both = [torch.zeros_like(flat) for _ in range(world)]
     if backend == "gloo":

@@ -275,10 +275,11 @@ if not only or "pairs" in only:
     mp_ = ahv.estimator.EstimatorCo3d(cfgp).to(dev).eval()
     P = ops.random_rotations(50000, seed=1, device=dev)
     graphed = mp_.feature_aligner.graphed_forward_2d3d(2)
-    for name, kw in (("one by one (reference order)", dict(batch_pairs=False)), ("ordered pairs batched", dict(batch_pairs=True)),
-                     ("batched + encoder replayed from a hipGraph", dict(batch_pairs=True, encoder_fn=graphed)),
+    for name, kw in (("one by one (reference order)", dict(batch_pairs=False, batch_sequences=1)),
+                     ("ordered pairs batched", dict(batch_pairs=True, batch_sequences=1)),
+                     ("batched + encoder replayed from a hipGraph", dict(batch_pairs=True, batch_sequences=1, encoder_fn=graphed)),
                      ("4 sequences (8 pairs) per batch", dict(batch_pairs=True, batch_sequences=4)),
-                     ("16 sequences (32 pairs) per batch", dict(batch_pairs=True, batch_sequences=16))):
+                     ("16 sequences (32 pairs) per batch = the default", dict())):
         seqs = list(ahv.harness.SyntheticSequences(40, 2, seed=1))     # materialised: data generation is not timed
         np.random.seed(0)
         ahv.harness.evaluate_category(cfgp, mp_, seqs[:4], device=dev, proposals=P, **kw)

@@ -42,7 +42,9 @@ def get_parser():
     ap.add_argument("--out-dir", default=None, help="where co3d_result.txt goes; default models/<RUN_NAME>")
     ap.add_argument("--device", default=None, help="default: cuda (the verify step has no CPU path)")
     ap.add_argument("--backbone", choices=["midas", "patchify"], default="midas")
-    ap.add_argument("--batch-sequences", type=int, default=1, help="sequences per encoder / verify launch")
+    ap.add_argument("--batch-sequences", type=int, default=None,
+                    help="sequences per encoder / verify launch (default: 16 on the GPU, 1 on the CPU; results do not "
+                         "depend on it, np.random.choice is drawn per sequence in the reference's order)")
     ap.add_argument("--trusted-ckpt", action="store_true", help="allow full unpickling of the checkpoint")
     ap.add_argument("--allow-partial-ckpt", action="store_true", help="load the aligner non-strictly")
     return ap

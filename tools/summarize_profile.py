@@ -4,7 +4,7 @@ Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> [kernel-sub
 import collections, csv, glob, json, os, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
-kern = sys.argv[3] if len(sys.argv) > 3 else "score_hypotheses"
+kern = sys.argv[3] if len(sys.argv) > 3 else "score_hypotheses_dual_kernel<false, true>"  # the one-launch verify step
 suffix = sys.argv[4] if len(sys.argv) > 4 else ""
 out = {}
 for d in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"]:
@@ -48,7 +48,7 @@ if trace:
         steady = {"launches_dropped_before_plateau": k, "calls": len(rest), "median_ns": rest[len(rest) // 2],
                   "mean_ns": sum(rest) / len(rest), "min_ns": rest[0], "max_ns": rest[-1],
                   "first_launches_ns": [round(d) for d in durs[:8]]}
-summary = {"kernel": kname, "command": "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline (tools/profile_bench.sh)",
+summary = {"kernel": kname, "command": "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip-strong-scaling (tools/profile_bench.sh)",
            "kernel_trace": {"calls": calls, "average_ns": avg_ns, "steady_state": steady}, "counters": out}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     f, w = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
