@@ -313,6 +313,12 @@ __device__ __forceinline__ void hat_axis(float i, float& jf, float& w0, float& w
 // between the MFMAs as 80 % of all scores wrong.
 // A kernel that issues XDL MFMAs therefore keeps every scalar it broadcasts over a register pair in the LOW half: low_half(x)
 // hides x from hipcc, which then has to hold it in a register of its own and broadcasts it with op_sel_hi:[..0..].
+#ifdef AHV_DIAG_FP32_LOW_HALF  // tools/kbench A/B only: what the same protection would cost the kernels that issue fp32
+constexpr bool kFp32LowHalf = true;   // MFMAs alone (they are not exposed: fp32 MFMAs never overlap VALU work)
+#else
+constexpr bool kFp32LowHalf = false;
+#endif
+
 __device__ __forceinline__ float low_half(float x)
 {
 #ifndef AHV_DIAG_NO_LOW_HALF  // tools/first_launch_sweep.sh builds the unprotected kernel once, to show the hazard itself
@@ -367,7 +373,7 @@ __device__ __forceinline__ void hat_voxel_at(HatVoxel& v, const float* srcT, f32
 }
 
 // pass p of quarter Q, Q a compile-time constant (the one-wave-per-hypothesis kernels)
-template <int Q, bool XDL = false>
+template <int Q, bool XDL = kFp32LowHalf>
 __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const GatherHyp& h, int p)
 {
     hat_voxel_at<XDL>(v, srcT, Q == 0 ? h.ixy[p] : __builtin_elementwise_fma(f32x2{(float)Q, (float)Q}, h.dqxy, h.ixy[p]),
@@ -377,7 +383,7 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
 // the same with the quarter known only at run time (wave-uniform: ahv_team.h, one quarter per wave)
 __device__ __forceinline__ void hat_voxel_rt(HatVoxel& v, const float* srcT, const GatherHyp& h, int p, float qf)
 {
-    hat_voxel_at<false>(v, srcT, __builtin_elementwise_fma(f32x2{qf, qf}, h.dqxy, h.ixy[p]), fmaf(qf, h.dqz, h.izp[p]));
+    hat_voxel_at<kFp32LowHalf>(v, srcT, __builtin_elementwise_fma(f32x2{qf, qf}, h.dqxy, h.ixy[p]), fmaf(qf, h.dqz, h.izp[p]));
 }
 
 // Quarter Q of the rotated volume into `buf`.  The two voxels of a lane (passes 0, 1) are blended as ONE stream
@@ -445,7 +451,7 @@ __device__ __forceinline__ void hat_prologue_mirror(HatState& st, const float* s
     HatRequests<0, kHatDepth, true>::run(st);
 }
 
-template <int Q, bool XDL = false>
+template <int Q, bool XDL = kFp32LowHalf>
 __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
 {
     // voxel 0, its first row requests, THEN voxel 1: setting both voxels up together (packed over the two passes, 24
@@ -467,7 +473,7 @@ __device__ __forceinline__ void hat_prologue_rt(HatState& st, const float* srcT,
 // forward's swizzled quarter image).  The split-f16 kernel has a store of its own (HatStoreSplit, ahv_split.h).
 template <int ROW>
 struct HatStoreF32 {
-    static constexpr bool kXdlKernel = false;  // fp32 MFMAs only (see low_half)
+    static constexpr bool kXdlKernel = kFp32LowHalf;  // fp32 MFMAs only: no protection needed (see low_half)
     float* d[2];  // the lane's voxel of pass 0 / pass 1 in channel plane 0
     __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
     {

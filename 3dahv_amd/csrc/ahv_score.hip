@@ -21,6 +21,13 @@
 
 namespace ahv {
 
+// a value the compiler cannot see through: keeps address arithmetic where it is written (not hoisted out of a loop)
+__device__ __forceinline__ int opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ float swap_add32(float a, float b)
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -165,10 +172,14 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
+        // The thread / lane numbers of this block go through an empty asm, so that the per-thread global and LDS addresses of
+        // the staging code are built HERE, once per sample: hoisted out of the sample loop they live across the hypothesis
+        // loop, i.e. in scratch (2-4 MB of spill stores per launch showed up as WRITE_SIZE, profiles/r04c_pmc_summary.json).
+        const int tid_s = opaque(tid), lane_s = opaque(lane);
         DualFrags f = f0;
         if (SPLIT) {
-            load_dual_frags(f, W2, b2, lane);  // re-read per sample: keeping an unscaled copy costs 16 registers the gather needs
-            const int v_exp = stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid);
+            load_dual_frags(f, W2, b2, lane_s);  // re-read per sample: keeping an unscaled copy costs 16 registers the gather needs
+            const int v_exp = stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid_s);
             const float unscale = ldexpf(1.0f, -(w1_exp + v_exp));  // exact; relu commutes with it
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -178,12 +189,12 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                     f.a2[m][r][1] *= unscale;
                 }
         } else {
-            stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid, kDualThreads);
+            stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid_s, kDualThreads);
             if constexpr (TGT) {
                 // team 1: each wave's un-rotated quarter of the TARGET volume goes into its private image here, ahead of
                 // the staging barrier (the image is free between the two barriers), so that its first-touch latency
                 // elapses while the workgroup waits for the source volume anyway
-                if (team == 1) stage_quarter_global(buf, tgt + (long)b * (16 * 512), member, lane);
+                if (team == 1) stage_quarter_global(buf, tgt + (long)b * (16 * 512), member, lane_s);
             }
         }
         // Target features as the per-lane fragments the score needs, parked in the 16-byte pad of source
@@ -191,11 +202,11 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // makes the eight ds_read_b128 of the epilogue conflict-free.
         if (!TGT) {
             const float* ft = tgt + (long)b * (32 * 64);
-            const int l = tid & 63, t = tid >> 7, m2 = (tid >> 6) & 1;
+            const int l = tid_s & 63, t = tid_s >> 7, m2 = (tid_s >> 6) & 1;
             f32x4 x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = ft[(16 * m2 + 4 * (l >> 4) + r) * 64 + 16 * t + (l & 15)];
-            *reinterpret_cast<f32x4*>(lds_src + tid * kSrcStride + 16) = x;
+            *reinterpret_cast<f32x4*>(lds_src + tid_s * kSrcStride + 16) = x;
         }
         __syncthreads();
         bool tg_ready = !TGT;
@@ -219,9 +230,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                     const f32x4 x = v[m2] * inv;
                     *reinterpret_cast<f32x4*>(lds_src + ((2 * member + m2) * 64 + lane) * kSrcStride + 16) = x;
                     if (feat_tgt_out != nullptr && blockIdx.x == 0) {
+                        const int ol = opaque(lane);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            feat_tgt_out[(long)b * (32 * 64) + (16 * m2 + 4 * (lane >> 4) + r) * 64 + 16 * member + (lane & 15)] = x[r];
+                            feat_tgt_out[(long)b * (32 * 64) + (16 * m2 + 4 * (ol >> 4) + r) * 64 + 16 * member + (ol & 15)] = x[r];
                     }
                 }
                 team_signal(&lds_team.tgt_ready, lane);
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2)
                     tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
-            const float s = hyp_score_rs<SPLIT>(v, tg, lane);
+            const float s = hyp_score_rs<SPLIT || kFp32LowHalf>(v, tg, lane);
             if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
             const key_t key = pack_key(s, (unsigned)(n_offset + h));
             best = key > best ? key : best;

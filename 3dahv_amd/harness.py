@@ -71,9 +71,10 @@ class _FlushUploader:
         self.turn = 0
 
     def upload(self, parts):
-        """[host fp32 tensors] -> [device fp32 tensors of the same shapes]; the compute stream waits for the copy, the
-        host does not (it only waits for the copy that used this slot two flushes ago)."""
-        sizes = [t.numel() for t in parts]
+        """[host fp32 numpy arrays] -> [device fp32 tensors of the same shapes]; the compute stream waits for the copy, the
+        host does not (it only waits for the copy that used this slot two flushes ago).  The host side is numpy on purpose:
+        torch's CPU operators wake one thread per VISIBLE core (256 here, inside a 16-CPU cgroup) and cost milliseconds."""
+        sizes = [int(t.size) for t in parts]
         total = sum(sizes)
         slot = self.slots[self.turn]
         if slot is None or slot[0].numel() < total:
@@ -85,9 +86,10 @@ class _FlushUploader:
         self.turn ^= 1
         pin, dev_buf, ev, used = slot
         ev.synchronize()
+        host = pin.numpy()
         o = 0
         for t, n in zip(parts, sizes):
-            pin[o:o + n].copy_(t.reshape(-1))
+            host[o:o + n] = t.reshape(-1)
             o += n
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_event(used)              # the flush that last read this device buffer (two flushes ago) is past it
@@ -146,16 +148,17 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
         """One upload, one encoder call, one fused verify launch and one select for every queued ordered pair."""
         if not queue:
             return
-        frames = torch.cat([q[0] for q in queue])
-        rots = torch.cat([q[1] for q in queue]).float()
+        frames = np.concatenate([q[0] for q in queue]).astype(np.float32, copy=False)
+        rots = np.concatenate([q[1] for q in queue]).astype(np.float32, copy=False)
         base = np.cumsum([0] + [q[0].shape[0] for q in queue[:-1]])
         pair = np.stack([np.concatenate([b + q[2] for b, q in zip(base, queue)]),
                          np.concatenate([b + q[3] for b, q in zip(base, queue)])])          # (2, P): source / target frame
         if uploader is not None:
-            frames, rots, pair_f = uploader.upload([frames.float(), rots, torch.from_numpy(pair.astype(np.float32))])
+            frames, rots, pair_f = uploader.upload([frames, rots, pair.astype(np.float32)])
             pair_d = pair_f.to(torch.int64)   # frame numbers are small integers: exact in fp32
             src, tgt = pair_d[0], pair_d[1]
         else:
+            frames, rots = torch.from_numpy(frames), torch.from_numpy(rots)
             src, tgt = torch.from_numpy(pair[0].astype(np.int64)), torch.from_numpy(pair[1].astype(np.int64))
         R_gt = torch.bmm(rots.index_select(0, src).transpose(1, 2), rots.index_select(0, tgt))
         embed = (encoder_fn or model.forward_features) if queue[0][5] else model
@@ -188,8 +191,8 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
         # which costs milliseconds per call inside a small cgroup) and uploaded once per flush
         kf = np.asarray(key_frames)
         data = meta["layer4"] if uses_l4 else meta["image"]
-        frames = torch.from_numpy(np.ascontiguousarray(data.cpu().numpy()[kf]))
-        rot = torch.from_numpy(np.ascontiguousarray(meta["R"].cpu().numpy()[kf]))
+        frames = data.cpu().numpy()[kf]
+        rot = meta["R"].cpu().numpy()[kf]
         if batch_pairs:
             queue.append((frames, rot, perm_np[:, 0], perm_np[:, 1], meta["model_id"], uses_l4,
                           [tuple(p) for p in perm_np.tolist()]))

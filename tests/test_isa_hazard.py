@@ -68,11 +68,17 @@ def test_xdl_kernel_has_no_cross_half_packed_f32(tmp_path):
     assert len(fp32) == 2 and not any(XDL.search(b) for b in fp32)
 
 
-def test_hot_loops_have_no_scratch_traffic(tmp_path):
-    """A register spilled ACROSS the hypothesis loop (stored before it, reloaded after it) is harmless; scratch traffic
-    INSIDE the loop is not.  The hypothesis loop of each scorer instance is the innermost loop that contains MFMAs and
-    more than 2 000 instructions: no scratch_ / buffer_..offen access may sit inside it."""
+def test_scorers_use_no_scratch_memory(tmp_path):
+    """No spilled vector register and no private segment in any scorer instance (round 3's split-f16 kernel carried 7
+    spilled registers, the first one-launch verify kernel 4: per-thread staging addresses hoisted out of the sample loop
+    and parked in scratch across the hypothesis loop -- megabytes of spill stores per launch in WRITE_SIZE), and in
+    particular no scratch access inside a hypothesis loop (the innermost loop with MFMAs and > 2 000 instructions)."""
     asm = _isa(os.path.join(CSRC, "ahv_score.hip"), tmp_path)
+    meta = re.findall(r"\.name:\s+(\S*score_hypotheses_dual_kernel\S*)\s+\.private_segment_fixed_size:\s+(\d+).*?"
+                      r"\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", asm, flags=re.S)
+    assert len(meta) == 3, meta
+    for name, private, vgprs, spills in meta:
+        assert int(private) == 0 and int(spills) == 0 and int(vgprs) <= 256, (name, private, vgprs, spills)
     fns = {n: b for n, b in _functions(asm).items() if "score_hypotheses_dual_kernel" in n}
     assert len(fns) == 3
     for name, body in fns.items():

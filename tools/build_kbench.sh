@@ -8,5 +8,7 @@ timeout 900 hipcc $F -DAHV_STAMPS tools/kbench.cpp -o tools/kbench_stamps
 # conflict-free bound of the gather (wrong results; timing and stamps only)
 timeout 900 hipcc $F -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_lin
 timeout 900 hipcc $F -DAHV_STAMPS -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_stamps_lin
-timeout 900 hipcc $F -DAHV_PK_WEIGHTS tools/kbench.cpp -o tools/kbench_pkw
+# what low_half() (the packed-fp32 op_sel protection of the XDL kernel) would cost the fp32 kernels
+timeout 900 hipcc $F -DAHV_DIAG_FP32_LOW_HALF tools/kbench.cpp -o tools/kbench_lowhalf
+timeout 900 hipcc $F -DAHV_DIAG_FP32_LOW_HALF tools/kbench_bwd.cpp -o tools/kbench_bwd_lowhalf
 timeout 900 hipcc $F tools/kbench_bwd.cpp -o tools/kbench_bwd
