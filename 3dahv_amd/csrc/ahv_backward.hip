@@ -19,6 +19,7 @@
 #include <cstdint>
 
 #include "ahv_device.h"
+#define AHV_FP32_LOW_HALF  // these kernels leave registers free on their SIMDs: see low_half (ahv_dual.h)
 #include "ahv_dual.h"
 
 namespace ahv {

@@ -313,8 +313,14 @@ __device__ __forceinline__ void hat_axis(float i, float& jf, float& w0, float& w
 // between the MFMAs as 80 % of all scores wrong.
 // A kernel that issues XDL MFMAs therefore keeps every scalar it broadcasts over a register pair in the LOW half: low_half(x)
 // hides x from hipcc, which then has to hold it in a register of its own and broadcasts it with op_sel_hi:[..0..].
-#ifdef AHV_DIAG_FP32_LOW_HALF  // tools/kbench A/B only: what the same protection would cost the kernels that issue fp32
-constexpr bool kFp32LowHalf = true;   // MFMAs alone (they are not exposed: fp32 MFMAs never overlap VALU work)
+// Kernels that issue fp32 MFMAs alone are not exposed by THEMSELVES (an fp32 MFMA never overlaps VALU work), only to an XDL
+// wave of another kernel sharing their SIMD.  The scorers rule that out by occupancy -- two waves of 249-256 registers take
+// all 512 of a SIMD, no granule is left for anybody (tests/test_isa_hazard.py checks the allocation) -- and keep hipcc's
+// op_sel forms; the backward kernels (ahv_backward.hip defines AHV_FP32_LOW_HALF) leave 50-60 registers per lane free and
+// take the protection: measured cost 0.2-0.7 % there, 0.27 % on the fp32 scorer (tools/kbench_lowhalf, kbench_bwd_lowhalf:
+// 0.6809 -> 0.6828 ms per 50 000 hypotheses, 2.576 -> 2.588 ms per backward; profiles/r04d_low_half_ab.txt).
+#if defined(AHV_FP32_LOW_HALF) || defined(AHV_DIAG_FP32_LOW_HALF)
+constexpr bool kFp32LowHalf = true;
 #else
 constexpr bool kFp32LowHalf = false;
 #endif

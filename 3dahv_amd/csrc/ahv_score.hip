@@ -461,9 +461,16 @@ __global__ void unpack_best_kernel(const key_t* __restrict__ best_key, int B, fl
 namespace ahv {
 
 // How a launch covers N hypotheses with gx workgroups of 8 waves (per sample).  Hypotheses [0, n_main) go to single
-// waves, round after round of 8 * gx; the remainder goes to teams of four waves (ahv_team.h) when it would fill less
-// than a quarter of the wave slots: a lone last round costs a whole hypothesis' latency (~17 us with one wave per
-// SIMD, ~27 us with two) for a handful of hypotheses, a team round ~5-8 us.
+// waves, round after round of 8 * gx; the remainder may go to teams of four waves (ahv_team.h).  Measured (tools/kbench,
+// profiles/r04d_team_tail.txt; kernel time in us, teams / single waves): a remainder left to single waves is cheap -- the
+// oldest wave of a SIMD issues first, so the wave that owns one hypothesis more runs AHEAD of its partner and the extra
+// hypothesis costs the CU 1/24 of its time, not a lone last round -- while a team round at the end is latency the CU can
+// only hide behind waves that are still in their main rounds, i.e. once the waves of a workgroup have drifted apart:
+//     N = 2 154 (1 round + 106)  53.6 / 56.8      N = 12 500 (6 rounds + 212)  181.5 / 185.7
+//     N = 6 250 (3 rounds + 106) 103.8 / 103.5    N = 25 000 (12 rounds + 424) 349.9 / 353.7
+//     N = 6 400 (3 rounds + 256) 112.4 / 104.3
+// Hence: teams take a remainder of at most two per workgroup behind at least four full rounds, and launches that are
+// all remainder (N <= 2 gx: a team's ~10 us against the ~17 us a lone wave needs for a whole hypothesis).
 ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool teams)
 {
     ScorePlan p;
@@ -479,7 +486,7 @@ ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool tea
     if (gx < 1) gx = 1;
     p.gx = (int)gx;
     const int64_t slots = 8 * gx, full = N / slots, rem = N - full * slots;
-    p.n_main = (teams && rem > 0 && rem <= 2 * gx) ? full * slots : N;
+    p.n_main = (teams && rem > 0 && rem <= 2 * gx && (full == 0 || full >= 4)) ? full * slots : N;
     return p;
 }
 

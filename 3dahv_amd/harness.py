@@ -58,29 +58,35 @@ class SyntheticSequences:
 
 class _FlushUploader:
     """Host -> device staging of one flush of the evaluation loop: everything a flush needs (the key frames of all queued
-    sequences, their rotations, the pair indices) travels as ONE pinned fp32 buffer in ONE copy on a stream of its own,
-    so the upload of flush k + 1 (and the host work of assembling it) overlaps the encoder + verify kernels of flush k
-    instead of queueing behind them -- a pageable ``.to(device)`` is ordered on the compute stream and blocks the host
-    until everything in front of it has run (13 % of the batched per-pair time in round 3,
-    profiles/r03g_evaluation_loop.jsonl).  Two buffer sets alternate."""
+    sequences, their rotations, the pair indices) travels as ONE pinned fp32 buffer in ONE non-blocking copy, so the host
+    never waits for the GPU -- a pageable ``.to(device)`` is ordered on the compute stream and blocks the host until
+    everything in front of it has run (13 % of the batched per-pair time in round 3, profiles/r03g_evaluation_loop.jsonl).
+    Large flushes go through a copy stream of their own and overlap the previous flush's kernels; small ones (a pair or
+    two) stay on the compute stream: a cross-stream event wait costs that queue ~30 us on this stack
+    (profiles/r04_forced_pg_timeline.txt), more than their 20-us copy.  Two buffer sets alternate; one uploader per
+    device lives for the process (pinned allocations cost milliseconds)."""
+    SIDE_STREAM_BYTES = 2 << 20
 
     def __init__(self, device):
         self.device = device
         self.stream = torch.cuda.Stream(device)
         self.slots = [None, None]
         self.turn = 0
+        self.last = None
 
     def upload(self, parts):
-        """[host fp32 numpy arrays] -> [device fp32 tensors of the same shapes]; the compute stream waits for the copy, the
-        host does not (it only waits for the copy that used this slot two flushes ago).  The host side is numpy on purpose:
-        torch's CPU operators wake one thread per VISIBLE core (256 here, inside a 16-CPU cgroup) and cost milliseconds."""
-        sizes = [int(t.size) for t in parts]
+        """[[host fp32 arrays to be laid end to end], ...] -> [device fp32 tensor per part, flat]; the compute stream
+        waits for the copy, the host does not (it only waits for the copy that used this slot two flushes ago).  The
+        host side is numpy on purpose: torch's CPU operators wake one thread per VISIBLE core (256 here, inside a 16-CPU
+        cgroup) and cost milliseconds."""
+        sizes = [sum(int(a.size) for a in part) for part in parts]
         total = sum(sizes)
         slot = self.slots[self.turn]
+        cur = torch.cuda.current_stream(self.device)
         if slot is None or slot[0].numel() < total:
             slot = (torch.empty(total, dtype=torch.float32).pin_memory(),
                     torch.empty(total, dtype=torch.float32, device=self.device), torch.cuda.Event(), torch.cuda.Event())
-            slot[3].record(torch.cuda.current_stream(self.device))
+            slot[3].record(cur)
             self.slots[self.turn] = slot
         self.last = slot
         self.turn ^= 1
@@ -88,24 +94,38 @@ class _FlushUploader:
         ev.synchronize()
         host = pin.numpy()
         o = 0
-        for t, n in zip(parts, sizes):
-            host[o:o + n] = t.reshape(-1)
-            o += n
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_event(used)              # the flush that last read this device buffer (two flushes ago) is past it
-        with torch.cuda.stream(self.stream):
-            dev_buf[:total].copy_(pin[:total], non_blocking=True)
-            ev.record(self.stream)
-        cur.wait_event(ev)
+        for part in parts:
+            for a in part:
+                host[o:o + a.size] = a.reshape(-1)
+                o += a.size
+        if total * 4 >= self.SIDE_STREAM_BYTES:
+            self.stream.wait_event(used)          # the flush that last read this device buffer (two flushes ago) is past it
+            with torch.cuda.stream(self.stream):
+                dev_buf[:total].copy_(pin[:total], non_blocking=True)
+                ev.record(self.stream)
+            cur.wait_event(ev)
+        else:
+            dev_buf[:total].copy_(pin[:total], non_blocking=True)   # stream-ordered: no event packets
+            ev.record(cur)
         out, o = [], 0
-        for t, n in zip(parts, sizes):
-            out.append(dev_buf[o:o + n].view(t.shape))
+        for n in sizes:
+            out.append(dev_buf[o:o + n])
             o += n
         return out
 
     def release(self):
         """The compute stream has issued its last read of the buffer handed out by the latest ``upload``."""
         self.last[3].record(torch.cuda.current_stream(self.device))
+
+
+_UPLOADERS = {}
+
+
+def _uploader(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _UPLOADERS:
+        _UPLOADERS[key] = _FlushUploader(device)
+    return _UPLOADERS[key]
 
 
 @torch.no_grad()
@@ -140,7 +160,7 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
     proposals = proposals.to(device)
     if verify_fn is None:
         verify_fn = lambda vs, vt, P: model.verify(vs, vt, P)[1:]  # (best, idx, R_pred): one fused launch + one select
-    uploader = _FlushUploader(device) if on_gpu else None
+    uploader = _uploader(device) if on_gpu else None
     details, pending = [], []
     queue = []  # per queued pair group: (frames (F,...) host, R (F,3,3) host, src ids, tgt ids, model_id, uses layer4, pairs)
 
@@ -148,17 +168,19 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
         """One upload, one encoder call, one fused verify launch and one select for every queued ordered pair."""
         if not queue:
             return
-        frames = np.concatenate([q[0] for q in queue]).astype(np.float32, copy=False)
-        rots = np.concatenate([q[1] for q in queue]).astype(np.float32, copy=False)
+        n_frames = sum(q[0].shape[0] for q in queue)
+        frame_shape = queue[0][0].shape[1:]
         base = np.cumsum([0] + [q[0].shape[0] for q in queue[:-1]])
         pair = np.stack([np.concatenate([b + q[2] for b, q in zip(base, queue)]),
                          np.concatenate([b + q[3] for b, q in zip(base, queue)])])          # (2, P): source / target frame
         if uploader is not None:
-            frames, rots, pair_f = uploader.upload([frames, rots, pair.astype(np.float32)])
-            pair_d = pair_f.to(torch.int64)   # frame numbers are small integers: exact in fp32
+            frames, rots, pair_f = uploader.upload([[q[0] for q in queue], [q[1] for q in queue], [pair.astype(np.float32)]])
+            frames, rots = frames.view((n_frames,) + frame_shape), rots.view(n_frames, 3, 3)
+            pair_d = pair_f.view(2, -1).to(torch.int64)   # frame numbers are small integers: exact in fp32
             src, tgt = pair_d[0], pair_d[1]
         else:
-            frames, rots = torch.from_numpy(frames), torch.from_numpy(rots)
+            frames = torch.from_numpy(np.concatenate([q[0] for q in queue]))
+            rots = torch.from_numpy(np.concatenate([q[1] for q in queue]))
             src, tgt = torch.from_numpy(pair[0].astype(np.int64)), torch.from_numpy(pair[1].astype(np.int64))
         R_gt = torch.bmm(rots.index_select(0, src).transpose(1, 2), rots.index_select(0, tgt))
         embed = (encoder_fn or model.forward_features) if queue[0][5] else model
@@ -191,8 +213,8 @@ def evaluate_category(cfg, model, sequences: Iterable[dict], num_frames: int = 2
         # which costs milliseconds per call inside a small cgroup) and uploaded once per flush
         kf = np.asarray(key_frames)
         data = meta["layer4"] if uses_l4 else meta["image"]
-        frames = data.cpu().numpy()[kf]
-        rot = meta["R"].cpu().numpy()[kf]
+        frames = data.cpu().numpy()[kf].astype(np.float32, copy=False)
+        rot = meta["R"].cpu().numpy()[kf].astype(np.float32, copy=False)
         if batch_pairs:
             queue.append((frames, rot, perm_np[:, 0], perm_np[:, 1], meta["model_id"], uses_l4,
                           [tuple(p) for p in perm_np.tolist()]))

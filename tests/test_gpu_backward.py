@@ -130,6 +130,27 @@ def test_backward_matches_fp64_autograd(ops, ahv, dev, B, N, per_sample):
     assert all(v < GRAD_RTOL for v in errs.values()), (errs, n_amb)
 
 
+def test_backward_at_integer_sample_coordinates(ops, ahv, dev):
+    """identity and the 24 cube rotations put EVERY sample coordinate exactly on an integer -- where the forward's
+    point-mirror gather (quarters 3 and 2 reuse the set-up of 0 and 1, csrc/ahv_dual.h hat_mirror) picks the neighbouring
+    base row with weights (0, 1) instead of (1, 0), while the dW1 / dV kernels evaluate all four quarters directly.  Same
+    samples, so the five gradients must still be those of the fp64 reference; the 45-degree, scaled, non-orthonormal and
+    zero matrices of the G3 fixture ride along (R is never assumed to be a rotation)."""
+    g3 = load_golden("edge_rotations")
+    vs, ft, _, W1, W2, b2, _ = make_case(ahv, dev, 2, 1, False, 77)
+    R = torch.from_numpy(np.ascontiguousarray(g3["R"])).to(dev)
+    gs = torch.from_numpy(np.random.RandomState(78).standard_normal((2, R.shape[0])).astype(np.float32)).to(dev)
+    got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    errs, n_amb, combo = kink_aware_errors(got, vs, ft, R, W1, W2, b2, gs)
+    assert all(v < GRAD_RTOL for v in errs), (errs, n_amb, combo)
+    # and the forward at the same rotations, fused against the reference-generated scores of the fixture's own volume
+    g1 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    s, _ = ops.verify_pair(t(g1["vol_src"]), t(g1["vol_tgt"]), R, W1, W2, b2, no_teams=True)
+    ref = g3["scores"]
+    assert float(np.max(np.abs(s.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1e-2))) < 1e-4
+
+
 @pytest.mark.parametrize("seed", [1101, 1102, 1103, 1106])
 def test_backward_large_case_any_seed(ops, ahv, dev, seed):
     """B = 2 x N = 1100 on seeds whose plain fp64 comparison trips over a ReLU kink: the kink-aware reference must

@@ -132,16 +132,17 @@ def test_verify_pair_split_kernel_and_graph_replay(ops, G, g128):
 
 # ------------------------------------------------------------------------------------------- team tails
 
-@pytest.mark.parametrize("n", [7, 130, 2048 + 37, 2 * 2048 + 300, 6250])
+@pytest.mark.parametrize("n", [7, 130, 512, 2048 + 37, 4 * 2048 + 300, 5 * 2048 + 512, 12500])
 def test_team_tail_against_single_waves(ops, ahv, G, dev, n):
     """AHV_SCORE_NO_TEAMS = every hypothesis by one wave.  Team scores agree to rounding (sums associated differently),
-    the arg-max is the same, and single-wave scores do not depend on N or on the hypothesis' position: bit for bit."""
-    R = to_dev(ahv.rotations.haar_rotations_np(6250, seed=41)[:n], dev)
+    the arg-max is the same, and single-wave scores do not depend on N or on the hypothesis' position: bit for bit.
+    (All-team launches: n <= 512; team tails: a remainder of at most 512 behind >= 4 full rounds of 2 048.)"""
+    R = to_dev(ahv.rotations.haar_rotations_np(12500, seed=41)[:n], dev)
     s_t, k_t, _ = two_launch(ops, G, R)
     s_1, k_1, _ = two_launch(ops, G, R, no_teams=True)
     assert (s_t - s_1).abs().max().item() <= ORDER_ATOL
     assert torch.equal(ops.unpack_best(k_t)[1], ops.unpack_best(k_1)[1])
-    big = to_dev(ahv.rotations.haar_rotations_np(6250, seed=41), dev)
+    big = to_dev(ahv.rotations.haar_rotations_np(12500, seed=41), dev)
     s_big, _, _ = two_launch(ops, G, big, no_teams=True)
     assert torch.equal(s_big[:, :n], s_1)
     # a reversed set: every hypothesis changes its wave, workgroup and (with teams) possibly its mode
@@ -152,11 +153,13 @@ def test_team_tail_against_single_waves(ops, ahv, G, dev, n):
 
 
 def test_team_tail_against_the_oracle(ops, oracle, ahv, G, g128, dev):
-    """The remainder of a 6 250-hypothesis shard (106 hypotheses scored by teams) against the CPU oracle."""
-    Rn = ahv.rotations.haar_rotations_np(6250, seed=43)
+    """The remainder of a 12 500-hypothesis shard (six full rounds, then 212 hypotheses scored by teams) against the oracle."""
+    Rn = ahv.rotations.haar_rotations_np(12500, seed=43)
     s, key, _ = two_launch(ops, G, to_dev(Rn, dev))
-    ref, _, _ = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], Rn[6144:], g128["W1"], g128["W2"], g128["b2"])
-    assert relerr(s[:, 6144:].cpu().numpy(), ref) <= SCORE_RTOL
+    s1, _, _ = two_launch(ops, G, to_dev(Rn, dev), no_teams=True)
+    assert not torch.equal(s[:, 12288:], s1[:, 12288:]), "the remainder was expected to go through the team path"
+    ref, _, _ = oracle.score_hypotheses(g128["vol_src"], g128["vol_tgt"], Rn[12288:], g128["W1"], g128["W2"], g128["b2"])
+    assert relerr(s[:, 12288:].cpu().numpy(), ref) <= SCORE_RTOL
     v, i = torch.max(s, dim=1)
     bv, bi = ops.unpack_best(key)
     assert bv.item() == v.item() and bi.item() == i.item()
