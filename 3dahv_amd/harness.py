@@ -84,8 +84,9 @@ class _FlushUploader:
         slot = self.slots[self.turn]
         cur = torch.cuda.current_stream(self.device)
         if slot is None or slot[0].numel() < total:
-            slot = (torch.empty(total, dtype=torch.float32).pin_memory(),
-                    torch.empty(total, dtype=torch.float32, device=self.device), torch.cuda.Event(), torch.cuda.Event())
+            cap = 1 << max(20, int(total - 1).bit_length())   # >= 4 MB, powers of two: pinned allocations cost milliseconds
+            slot = (torch.empty(cap, dtype=torch.float32).pin_memory(),
+                    torch.empty(cap, dtype=torch.float32, device=self.device), torch.cuda.Event(), torch.cuda.Event())
             slot[3].record(cur)
             self.slots[self.turn] = slot
         self.last = slot

@@ -71,16 +71,19 @@ def test_bench_rccl_branch_on_one_gpu():
     assert a["config"]["backend"] == "single process" and b["config"]["backend"] == "rccl"
     assert b["n_gpus"] == 1 and a["result"] == b["result"]
     assert b["config"]["steps_per_collective"] == 8 and a["config"]["steps_per_collective"] is None
-    # one step = ONE fused launch + ONE select launch: what is not the scorer stays small (21 us in round 3)
-    assert a["ms_per_step"] - a["roofline"]["kernel_ms"] < 0.010, (a["ms_per_step"], a["roofline"]["kernel_ms"])
     # The collective is cheap: the int64 keys go into the all-reduce as the kernel packed them (no re-encoding launches),
     # eight steps' keys per collective, consumed one group later -- so the step with the process group costs what the step
     # without it costs (round 3: +4.6 %).  Two processes seconds apart differ by the clock they are granted (<= 1 %):
     # one repeat before judging.
     ta, tb = a["ms_per_step"], b["ms_per_step"]
-    if tb > 1.02 * ta:
-        ta, tb = min(ta, run({})["ms_per_step"]), min(tb, run({"AHV_BENCH_FORCE_PG": "1"})["ms_per_step"])
+    gap = a["ms_per_step"] - a["roofline"]["kernel_ms"]
+    if tb > 1.02 * ta or gap > 0.010:
+        a2 = run({})
+        ta, tb = min(ta, a2["ms_per_step"]), min(tb, run({"AHV_BENCH_FORCE_PG": "1"})["ms_per_step"])
+        gap = min(gap, a2["ms_per_step"] - a2["roofline"]["kernel_ms"])
     assert tb <= 1.02 * ta, (ta, tb)
+    # one step = ONE fused launch + ONE select launch: what is not the scorer stays small (21 us in round 3)
+    assert gap < 0.010, (a["ms_per_step"], a["roofline"]["kernel_ms"], gap)
 
 
 def test_bench_launches_its_own_ranks():

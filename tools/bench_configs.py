@@ -282,7 +282,7 @@ if not only or "pairs" in only:
                      ("16 sequences (32 pairs) per batch = the default", dict())):
         seqs = list(ahv.harness.SyntheticSequences(40, 2, seed=1))     # materialised: data generation is not timed
         np.random.seed(0)
-        ahv.harness.evaluate_category(cfgp, mp_, seqs[:4], device=dev, proposals=P, **kw)
+        ahv.harness.evaluate_category(cfgp, mp_, seqs[:32], device=dev, proposals=P, **kw)   # warm-up at the timed batch shape
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e = ahv.harness.evaluate_category(cfgp, mp_, seqs, device=dev, proposals=P, **kw)
@@ -293,7 +293,7 @@ if not only or "pairs" in only:
     with ops.split_f16_scorer():  # opt-in split-f16 scorer (per-call flag)
         seqs = list(ahv.harness.SyntheticSequences(40, 2, seed=1))
         np.random.seed(0)
-        ahv.harness.evaluate_category(cfgp, mp_, seqs[:4], device=dev, proposals=P, batch_sequences=16)
+        ahv.harness.evaluate_category(cfgp, mp_, seqs[:32], device=dev, proposals=P, batch_sequences=16)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e = ahv.harness.evaluate_category(cfgp, mp_, seqs, device=dev, proposals=P, batch_sequences=16)
