@@ -20,7 +20,6 @@ AHV_SCORE_NO_TEAMS = 4
 AHV_SCORE_SPARE_CUS_SHIFT = 8
 AHV_SELECT_RESET_KEY = 1
 AHV_KEY_EMPTY = -(1 << 63)
-AHV_XCD_BALANCE_BYTES = 128
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -35,7 +34,7 @@ SIGNATURES = {
     "ahv_score_hypotheses_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32, _vp]),
     "ahv_score_hypotheses_clocked_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _u32,
                                                 _vp, _vp]),
-    "ahv_verify_pair_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "ahv_verify_pair_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
     "ahv_unpack_best": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ahv_reset_best": (_int, [_vp, _int, _vp]),
     "ahv_rotate_volume_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),

@@ -98,7 +98,7 @@ static hipError_t zero_span(void* p, size_t bytes, hipStream_t s)
 static int score_common(const char* who, const float* vol_src, const float* tgt, bool tgt_is_volume, const float* R,
                         int64_t r_batch_stride, int64_t n_offset, const float* W1, const float* W2, const float* b2, int B,
                         int64_t N, float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags,
-                        uint64_t* clock_stamps, void* xcd_balance, void* stream)
+                        uint64_t* clock_stamps, void* stream)
 {
     if (B < 0 || N < 0) return fail(AHV_EINVAL, "%s: negative size (B=%d, N=%lld)", who, B, (long long)N);
     if (B > 0 && N > 0 && (!vol_src || !tgt || !R || !W1 || !W2 || !b2))
@@ -137,7 +137,6 @@ static int score_common(const char* who, const float* vol_src, const float* tgt,
     a.scores = scores; a.best_key = best_key; a.feat_tgt_out = feat_tgt_out; a.num_cu = cu;
     a.spare_cu = (int)((flags & AHV_SCORE_SPARE_CUS_MASK) >> AHV_SCORE_SPARE_CUS_SHIFT);
     a.split_f16 = split; a.no_teams = (flags & AHV_SCORE_NO_TEAMS) != 0; a.clock_stamps = clock_stamps;
-    a.xcd_balance = xcd_balance;
     hipError_t e = ahv::launch_score_hypotheses(a, s);
     if (e != hipSuccess) return hip_fail("score: launch", e);
     return AHV_OK;
@@ -149,7 +148,7 @@ int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const 
                              unsigned flags, void* stream)
 {
     return score_common("score", vol_src, feat_tgt, false, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores, best_key,
-                        nullptr, flags, nullptr, nullptr, stream);
+                        nullptr, flags, nullptr, stream);
 }
 
 int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt, const float* R,
@@ -159,18 +158,16 @@ int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt
 {
     if (!clock_stamps) return fail(AHV_EINVAL, "score_clocked: null clock_stamps");
     return score_common("score_clocked", vol_src, feat_tgt, false, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores,
-                        best_key, nullptr, flags, clock_stamps, nullptr, stream);
+                        best_key, nullptr, flags, clock_stamps, stream);
 }
 
 int ahv_verify_pair_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,
                         int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
                         float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags, uint64_t* clock_stamps,
-                        void* xcd_balance, void* stream)
+                        void* stream)
 {
-    if (xcd_balance && (reinterpret_cast<uintptr_t>(xcd_balance) & 7))
-        return fail(AHV_EINVAL, "verify_pair: xcd_balance must be 8-byte aligned");
     return score_common("verify_pair", vol_src, vol_tgt, true, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores,
-                        best_key, feat_tgt_out, flags, clock_stamps, xcd_balance, stream);
+                        best_key, feat_tgt_out, flags, clock_stamps, stream);
 }
 
 int ahv_unpack_best(const int64_t* best_key, int B, float* best_score, int64_t* best_idx, void* stream)

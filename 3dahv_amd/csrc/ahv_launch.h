@@ -22,7 +22,6 @@ struct ScoreLaunch {
     bool split_f16;         // AHV_SCORE_SPLIT_F16
     bool no_teams;          // AHV_SCORE_NO_TEAMS
     uint64_t* clock_stamps; // diagnostic entry point, else NULL
-    void* xcd_balance;      // 128 B of caller-owned device memory steering the per-XCD shares (ahv_score.hip XcdBalance), or NULL
 };
 
 struct ScorePlan {

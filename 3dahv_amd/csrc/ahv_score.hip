@@ -21,13 +21,6 @@
 
 namespace ahv {
 
-__device__ __forceinline__ long uniform64(long x)
-{
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x & 0xFFFFFFFFul));
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
-    return (long)(((unsigned long)hi << 32) | lo);
-}
-
 // a value the compiler cannot see through: keeps address arithmetic where it is written (not hoisted out of a loop)
 __device__ __forceinline__ int opaque(int x)
 {
@@ -111,72 +104,6 @@ __device__ unsigned long long g_wgclk[1024 * 2];  // s_memtime at loop start / e
 #endif
 
 // ---------------------------------------------------------------------------------------
-// XCD balance.  The eight XCDs of the chip hold DIFFERENT clocks under this load (2.06 ... 2.12 GHz on one box, stable per
-// XCD over seconds), so with equal shares their workgroups finish 16-32 us apart and the launch lasts as long as the slowest
-// XCD: ~12 us of a 0.69-ms launch are end-of-kernel idling (profiles/r03_scorer_segments.txt).  A ticket queue costs more than
-// it recovers (round 3); a STATIC split calibrated by the previous launch costs nothing in the loop: the caller may pass 128
-// bytes of device memory (zero-initialised once, then owned by the kernels) through which each launch tells the next how long
-// the workgroups of every XCD were busy; the next launch cuts the single-wave hypotheses into eight contiguous ranges in
-// proportion to the measured rates.  Pure scheduling: which wave scores a hypothesis never changes its score.
-// Used for B = 1 launches of a full grid with at least 8 rounds; every workgroup derives the SAME split from the same eight
-// numbers (and falls back to equal shares when they are not plausible), the last workgroup to finish writes the next ones.
-// ---------------------------------------------------------------------------------------
-struct XcdBalance {
-    float share[8];               // fraction of the single-wave hypotheses for XCD x; all zero (or implausible) = equal
-    unsigned long long busy[8];   // this launch: sum over the XCD's workgroups of kernel entry -> loop exit (10-ns ticks)
-    unsigned arrived;             // workgroups that have reported
-    unsigned launches;            // launches that updated the shares (diagnostics)
-};
-static_assert(sizeof(XcdBalance) <= 128, "the caller provides 128 bytes");
-
-__device__ __forceinline__ bool xcd_shares_plausible(const float (&w)[8])
-{
-    float sum = 0.0f;
-    bool ok = true;
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-        ok = ok && (w[x] > 0.09f) && (w[x] < 0.17f);  // 0.125 +- a third: far outside any clock spread
-        sum += w[x];
-    }
-    return ok && fabsf(sum - 1.0f) < 1e-3f;
-}
-
-// [lo, hi) of XCD `xcd` when n hypotheses are cut in proportion to w (the same arithmetic in every workgroup)
-__device__ __forceinline__ void xcd_range(const float (&w)[8], long n, int xcd, long& lo, long& hi)
-{
-    double cum = 0.0;
-    long off[9];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-        off[x] = (long)((double)n * cum);
-        cum += (double)w[x];
-    }
-    off[8] = n;
-    lo = off[0];
-    hi = off[1];
-#pragma unroll
-    for (int x = 1; x < 8; ++x)
-        if (xcd == x) {
-            lo = off[x];
-            hi = off[x + 1];
-        }
-    if (hi < lo) hi = lo;
-    if (hi > n) hi = n;
-}
-
-// the shares every workgroup of a launch works from: the buffer's, or equal ones if those are not plausible (the buffer is
-// only written by the last workgroup of a launch, so all workgroups of the NEXT launch read the same eight numbers)
-__device__ __forceinline__ void load_xcd_shares(float (&w)[8], const XcdBalance* b)
-{
-#pragma unroll
-    for (int x = 0; x < 8; ++x) w[x] = b->share[x];
-    if (!xcd_shares_plausible(w)) {
-#pragma unroll
-        for (int x = 0; x < 8; ++x) w[x] = 0.125f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // Dual variant: 512 threads = two waves per SIMD, 16x16x4 MFMA, W1 fragments in LDS (ahv_dual.h).
 // ---------------------------------------------------------------------------------------
 constexpr int kDualThreads = 512;
@@ -190,8 +117,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
     long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
     const float* __restrict__ b2, int B, long N, long n_main, float* __restrict__ scores,
-    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, unsigned long long* __restrict__ clk,
-    XcdBalance* __restrict__ balance)
+    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, unsigned long long* __restrict__ clk)
 {
     static_assert(!(SPLIT && TGT), "the split-f16 kernel takes ready-made target features");
     // The fp32 instances own their SIMDs: touching v255 makes the kernel's register allocation 256 per wave whatever the
@@ -205,10 +131,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
     __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
     __shared__ TeamSync lds_team;  // 84 of the 512 bytes the three images leave
-    // this workgroup's start: 100-MHz real time and shader clock, for the XCD balance and the diagnostic stamps (parked in LDS:
-    // registers that live across the hypothesis loop are what this kernel has none to spare of)
+    // this workgroup's start: 100-MHz real time and shader clock for the diagnostic stamps (parked in LDS: registers that
+    // live across the hypothesis loop are what this kernel has none to spare of)
     __shared__ unsigned long long lds_t_entry[2];
-    if ((balance != nullptr || clk != nullptr) && threadIdx.x == 0) {
+    if (clk != nullptr && threadIdx.x == 0) {
         lds_t_entry[0] = __builtin_amdgcn_s_memrealtime();
         lds_t_entry[1] = __builtin_amdgcn_s_memtime();
     }
@@ -247,20 +173,6 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const GatherDst gdst = gather_dst_swizzled(lane);
     const SplitDst sdst = split_dst(lane);
     const long hstep = (long)gridDim.x * 8;
-    // XCD balance (see XcdBalance): this workgroup's XCD scores the contiguous range [bal_lo, bal_hi) of the single-wave
-    // hypotheses, dealt to its gridDim.x / 8 workgroups and their waves like the whole set is dealt otherwise
-    const bool balanced = balance != nullptr && B == 1 && gridDim.y == 1 && (gridDim.x & 7) == 0 && gridDim.x >= 64 &&
-                          n_main >= 8 * hstep;
-    long bal_lo = 0, bal_hi = 0;
-    if (balanced) {
-        float w[8];
-        load_xcd_shares(w, balance);
-        xcd_range(w, n_main, blockIdx.x & 7, bal_lo, bal_hi);
-        // the double arithmetic runs on the vector unit: back to scalar registers (the values are wave-uniform), or the
-        // hypothesis counter and its bound become four vector registers across the hot loop
-        bal_lo = uniform64(bal_lo);
-        bal_hi = uniform64(bal_hi);
-    }
     // Diagnostic entry point (clk != NULL): shader-clock and 100 MHz real-time stamps around this workgroup's whole run
     // (lds_t_entry above, the end stamps below).  The stamps go to `clk` alone; no output depends on them.
 
@@ -351,27 +263,21 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // the persistent grid then spreads over ALL CUs with few waves each (a lone wave on a SIMD runs
         // ~1.6x faster than a pair) instead of filling some CUs completely and leaving the rest idle.
         long h = (long)wave * gridDim.x + residue;
-        long h_end = n_main, h_step = hstep;
-        if (balanced) {
-            h = bal_lo + (long)wave * (gridDim.x >> 3) + (blockIdx.x >> 3);
-            h_end = bal_hi;
-            h_step = gridDim.x;  // 8 waves x (gridDim.x / 8) workgroups of this XCD
-        }
         // The rotation of the NEXT hypothesis travels as ONE vector load (lane i < 9 fetches element i) and is
         // broadcast with v_readlane at the top of the next iteration.  Not as scalar loads: SMEM shares lgkmcnt
         // with the LDS and returns out of order, so the first LDS wait behind an s_load has to wait for the s_load
         // too -- a first-touch read of R from HBM (~2 us) in front of every hypothesis' first gather step.
         const int rl = lane < 9 ? lane : 8;
-        float Rn = h < h_end ? Rb[h * 9 + rl] : 0.0f;  // nothing of R is touched when this wave has no hypothesis (N = 0: R may be null)
+        float Rn = h < n_main ? Rb[h * 9 + rl] : 0.0f;  // nothing of R is touched when this wave has no hypothesis (N = 0: R may be null)
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-        for (; h < h_end; h += h_step) {
+        for (; h < n_main; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rn), i));
             {
-                const long hn = (h + h_step < h_end) ? h + h_step : h;
+                const long hn = (h + hstep < n_main) ? h + hstep : h;
                 Rn = Rb[hn * 9 + rl];
             }
             f32x4 acc[2][4];
@@ -532,43 +438,6 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         }
 #endif
     }
-    if (balanced) {
-        __syncthreads();  // every wave of this workgroup is through
-        if (wave == 0 && lane == 0) {
-            // Only atomics carry data between workgroups here: the returning form is complete at the L2 when its value is
-            // back, so making the second depend on the first orders them without any cache maintenance.
-            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - lds_t_entry[0];
-            const unsigned long long old = __hip_atomic_fetch_add(&balance->busy[blockIdx.x & 7], dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned n = __hip_atomic_fetch_add(&balance->arrived, 1u + (unsigned)(old >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (n == gridDim.x - 1) {  // last one out: rates of this launch -> shares of the next
-                float bal_w[8];
-                load_xcd_shares(bal_w, balance);  // what this launch worked from (nobody has written them since)
-                float rate[8], tot = 0.0f;
-                bool ok = true;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    const unsigned long long busy = __hip_atomic_exchange(&balance->busy[x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    long lo, hi;
-                    xcd_range(bal_w, n_main, x, lo, hi);
-                    ok = ok && busy > 0 && hi > lo;
-                    rate[x] = (float)(hi - lo) / (float)(busy > 0 ? busy : 1ull);
-                    tot += rate[x];
-                }
-                float nw[8], sum = 0.0f;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    // half of the way to the measured rates: one noisy launch cannot throw the split
-                    nw[x] = ok ? 0.5f * (bal_w[x] + rate[x] / tot) : 0.125f;
-                    nw[x] = fminf(fmaxf(nw[x], 0.10f), 0.16f);
-                    sum += nw[x];
-                }
-#pragma unroll
-                for (int x = 0; x < 8; ++x) balance->share[x] = nw[x] / sum;
-                balance->launches += 1u;
-                __hip_atomic_store(&balance->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
     if (clk != nullptr) {
         __syncthreads();
         if (wave == 0 && lane == 0) {
@@ -634,20 +503,19 @@ hipError_t launch_score_hypotheses(const ScoreLaunch& a, hipStream_t stream)
     const dim3 grid(p.gx, p.gy), block(kDualThreads);
     auto* key = reinterpret_cast<key_t*>(a.best_key);
     auto* clk = reinterpret_cast<unsigned long long*>(a.clock_stamps);
-    auto* bal = reinterpret_cast<XcdBalance*>(a.xcd_balance);
     if (a.split_f16) {
         if (a.tgt_is_volume) return hipErrorInvalidValue;  // the ABI routes this case through forward_3d2d first
         hipLaunchKernelGGL((score_hypotheses_dual_kernel<true, false>), grid, block, 0, stream, a.vol_src, a.tgt, a.R,
                            (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
-                           key, a.feat_tgt_out, clk, bal);
+                           key, a.feat_tgt_out, clk);
     } else if (a.tgt_is_volume) {
         hipLaunchKernelGGL((score_hypotheses_dual_kernel<false, true>), grid, block, 0, stream, a.vol_src, a.tgt, a.R,
                            (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
-                           key, a.feat_tgt_out, clk, bal);
+                           key, a.feat_tgt_out, clk);
     } else {
         hipLaunchKernelGGL((score_hypotheses_dual_kernel<false, false>), grid, block, 0, stream, a.vol_src, a.tgt, a.R,
                            (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
-                           key, a.feat_tgt_out, clk, bal);
+                           key, a.feat_tgt_out, clk);
     }
     return hipGetLastError();
 }

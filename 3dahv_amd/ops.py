@@ -227,15 +227,12 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
 def verify_pair(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor,
                 b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True, best_key: torch.Tensor | None = None,
                 reset_best: bool | None = None, split_f16: bool | None = None, want_feat_tgt: bool = False,
-                clock_stamps: torch.Tensor | None = None, no_teams: bool = False, spare_cus: int = 0,
-                balance: torch.Tensor | None = None):
+                clock_stamps: torch.Tensor | None = None, no_teams: bool = False, spare_cus: int = 0):
     """The whole per-pair verify step of test_co3d.py:137-145 behind ONE entry point (``ahv_verify_pair_f32``):
     ``forward_3d2d(vol_tgt)`` is built inside the scoring launch instead of in a launch of its own.  Arguments as
     ``score_hypotheses`` with the target VOLUME ``vol_tgt (B,16,8,8,8)`` in place of ``feat_tgt``.  Returns
     ``(scores (B,N) or None, best_key (B,) int64)`` and, with ``want_feat_tgt``, the target features ``(B,32,64)`` as
     third element (always materialised for the split-f16 kernel, which runs forward_3d2d as a launch of its own).
-    ``balance``: the per-device state of ``xcd_balance(device)`` -- consecutive B = 1 launches then calibrate their
-    per-XCD shares on each other (the XCDs hold different clocks; pure scheduling, scores unchanged).
     Inference only (no autograd edge)."""
     _refuse_grad("verify_pair", vol_src, vol_tgt, W1, W2, b2)
     if vol_tgt.dim() != 5 or tuple(vol_tgt.shape) != tuple(vol_src.shape):
@@ -246,12 +243,12 @@ def verify_pair(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, W
         feat = torch.empty((vol_src.shape[0], 32, 64), dtype=torch.float32, device=vol_src.device)
     scores, key = _score_hypotheses_nograd(vol_src, vol_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best,
                                            split, clock_stamps, no_teams=no_teams, spare_cus=spare_cus, tgt_is_volume=True,
-                                           feat_tgt_out=feat, balance=balance)
+                                           feat_tgt_out=feat)
     return (scores, key, feat) if want_feat_tgt else (scores, key)
 
 
 def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best, split_f16,
-                             clock_stamps, no_teams=False, spare_cus=0, tgt_is_volume=False, feat_tgt_out=None, balance=None):
+                             clock_stamps, no_teams=False, spare_cus=0, tgt_is_volume=False, feat_tgt_out=None):
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
         raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
     B = vol_src.shape[0]
@@ -279,9 +276,6 @@ def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_sc
         flags |= _lib.AHV_SCORE_NO_TEAMS
     if not 0 <= int(spare_cus) <= 255:
         raise RuntimeError("spare_cus must be in 0..255")
-    if balance is not None and (balance.device != dev or balance.dtype != torch.int64 or not balance.is_contiguous()
-                                or balance.numel() * 8 < _lib.AHV_XCD_BALANCE_BYTES):
-        raise RuntimeError("balance must be the int64 state tensor of ops.xcd_balance(device)")
     flags |= int(spare_cus) << _lib.AHV_SCORE_SPARE_CUS_SHIFT
     lib = _lib.load()
     head = (vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, n_offset, W1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
@@ -293,7 +287,6 @@ def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_sc
         if tgt_is_volume:
             _lib.check(lib.ahv_verify_pair_f32(*head, feat_tgt_out.data_ptr() if feat_tgt_out is not None else None, flags,
                                                clock_stamps.data_ptr() if clock_stamps is not None else None,
-                                               balance.data_ptr() if balance is not None else None,
                                                _stream(dev)), "ahv_verify_pair_f32")
         elif clock_stamps is None:
             _lib.check(lib.ahv_score_hypotheses_f32(*head, flags, _stream(dev)), "ahv_score_hypotheses_f32")
@@ -425,20 +418,6 @@ def _rot_layout(R: torch.Tensor, B: int):
     if R.dim() == 4 and R.shape[0] == B and tuple(R.shape[2:]) == (3, 3):
         return R.shape[1], R.shape[1] * 9
     raise RuntimeError("R must be (N,3,3) or (B,N,3,3), got %s" % (tuple(R.shape),))
-
-
-_XCD_BALANCE = {}
-
-
-def xcd_balance(device) -> torch.Tensor:
-    """The per-device state through which consecutive ``verify_pair(..., balance=...)`` launches calibrate their per-XCD
-    shares (``AHV_XCD_BALANCE_BYTES`` of device memory, zeroed once, then owned by the kernels; ``include/ahv.h``).  One
-    tensor per device for the life of the process; launches that share it must be ordered on one stream."""
-    dev = torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    if key not in _XCD_BALANCE:
-        _XCD_BALANCE[key] = torch.zeros(_lib.AHV_XCD_BALANCE_BYTES // 8, dtype=torch.int64, device=dev)
-    return _XCD_BALANCE[key]
 
 
 @torch.no_grad()

@@ -237,8 +237,6 @@ class VerifyLoop:
         self.vs, self.vt, self.R, self.head, self.n_offset = vol_src, vol_tgt, R_local, head, n_offset
         self.spare, self.split = spare_cus, split
         self.B = vol_src.shape[0]
-        # per-XCD shares calibrated from launch to launch (B = 1 launches of >= 8 rounds; scheduling only: ops.xcd_balance)
-        self.balance = ops.xcd_balance(dev) if os.environ.get("AHV_BENCH_XCD_BALANCE", "1") == "1" else None
         self.keys = torch.full((self.RING, self.group, self.B), -(1 << 63), dtype=torch.int64, device=dev)
         self.pending, self.out, self.done = {}, {}, -1
 
@@ -266,8 +264,7 @@ class VerifyLoop:
             ev[0].record()
         # `stamps` given: the same kernel also writes every workgroup's s_memtime / s_memrealtime pair (shader clock)
         self.ops.verify_pair(self.vs, self.vt, self.R, *self.head, n_offset=self.n_offset, want_scores=False, best_key=key,
-                             reset_best=False, split_f16=self.split, clock_stamps=stamps, spare_cus=self.spare,
-                             balance=self.balance)
+                             reset_best=False, split_f16=self.split, clock_stamps=stamps, spare_cus=self.spare)
         if ev is not None:
             ev[1].record()
         if j == self.group - 1 or last:  # the group is complete (or the run ends inside it)
@@ -392,12 +389,12 @@ def worker(args):
     def timed(lp, steps, warmup, events=None, stamps=None):
         """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
         import gc
-        if warmup:
-            lp.run(warmup)
-        torch.cuda.synchronize()
-        gc.collect()
+        gc.collect()  # BEFORE the warm-up: between it and the timed steps the GPU would idle for tens of ms and drop its clock
         gc.disable()  # a generation-2 collection inside the issue loop is a multi-millisecond host stall: the queue runs dry
         try:
+            if warmup:
+                lp.run(warmup)
+            torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -537,10 +534,6 @@ def worker(args):
                          "algorithmic_flops_note": "50 000 hypotheses x 1 839 104; the in-launch target features (one more "
                                                    "forward_3d2d per workgroup, ~0.5 %% extra work) are NOT counted",
                          "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP,
-                         "xcd_shares": ([round(float(x), 5) for x in loop.balance[:4].view(torch.float32).cpu()]
-                                        if loop.balance is not None else None),
-                         "xcd_shares_is": "fraction of the hypotheses each XCD scores, calibrated by the kernels from launch to "
-                                          "launch on how busy the XCDs' workgroups were (they hold different clocks); 0.125 = equal",
                          "shader_clock_ghz": clock_ghz,
                          "shader_clock_source": "s_memtime / s_memrealtime stamps of the TIMED launches (all %d, all "
                                                 "workgroups, median)" % args.steps,

@@ -69,7 +69,6 @@ extern "C" {
  * (ABI 1.x packed the same fields in UNSIGNED order with 0 as the empty key; 2.0 = that key ^ 0x8000000000000000.)
  */
 #define AHV_KEY_EMPTY INT64_MIN
-#define AHV_XCD_BALANCE_BYTES 128
 
 /* flags of ahv_score_hypotheses_f32 */
 #define AHV_SCORE_RESET_BEST 1u /* set best_key[0..B) to AHV_KEY_EMPTY on the stream before scoring */
@@ -169,20 +168,13 @@ int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt
  *                gt_sim reuses it, modules/model.py:137-143).  REQUIRED with AHV_SCORE_SPLIT_F16, whose kernel
  *                takes ready-made features: that case runs forward_3d2d into it and then the scorer (two launches).
  *  clock_stamps  NULL, or as in ahv_score_hypotheses_clocked_f32 (diagnostics)
- *  xcd_balance   NULL, or AHV_XCD_BALANCE_BYTES of device memory, 8-byte aligned, zero-initialised ONCE by the caller and
- *                then left to the kernels: the eight XCDs of the chip hold different clocks under this load, so with
- *                equal shares the launch idles ~12 us at its end waiting for the slowest one; through this buffer every
- *                launch tells the next how busy each XCD's workgroups were, and the next one cuts the hypotheses into
- *                eight contiguous ranges in proportion.  Pure scheduling -- which wave scores a hypothesis never changes
- *                its score -- used for B = 1 launches of at least eight rounds (ignored otherwise).  One buffer per
- *                device and stream of launches; garbage in it falls back to equal shares.
  * With N = 0 and feat_tgt_out given only the target features are produced.  The in-launch features are summed in
  * another order than ahv_forward_3d2d_f32's (both fp32, both within 1e-6 of the reference).
  */
 int ahv_verify_pair_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,
                         int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
                         float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags, uint64_t* clock_stamps,
-                        void* xcd_balance, void* stream);
+                        void* stream);
 
 /*
  * Decode packed keys: best_score[b], best_idx[b] (int64, global hypothesis index).

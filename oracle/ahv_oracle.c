@@ -380,10 +380,9 @@ int ahv_score_hypotheses_f32_cpu(const float* vol_src, const float* feat_tgt, co
 int ahv_verify_pair_f32_cpu(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,
                             int64_t n_offset, const float* W1, const float* W2, const float* b2, int B, int64_t N,
                             float* scores, int64_t* best_key, float* feat_tgt_out, unsigned flags, uint64_t* clock_stamps,
-                            void* xcd_balance, void* stream)
+                            void* stream)
 {
     (void)clock_stamps;
-    (void)xcd_balance; /* scheduling only */
     if (B < 0 || N < 0) return -1;
     if (B > 0 && (!vol_tgt || !W1 || !W2 || !b2)) return -1;
     float* ft = feat_tgt_out ? feat_tgt_out : (float*)calloc((size_t)(B > 0 ? B : 1) * AHV_O * AHV_P, sizeof(float));

@@ -81,7 +81,7 @@ def test_config1_golden_through_the_product_signatures(ahv, twin):
     # the whole step behind one entry point: same scores, same key, and the target features on request
     scores2, key2, ft2 = np.empty((1, N), np.float32), np.zeros(1, np.int64), np.empty((1, 32, 64), np.float32)
     rc = twin.ahv_verify_pair_f32(ptr(vs), ptr(vt), ptr(R), 0, 0, ptr(W1), ptr(W2), ptr(b2), 1, N, ptr(scores2), ptr(key2),
-                                  ptr(ft2), ahv._lib.AHV_SCORE_RESET_BEST, None, None, None)
+                                  ptr(ft2), ahv._lib.AHV_SCORE_RESET_BEST, None, None)
     assert rc == 0 and np.array_equal(scores2, scores) and np.array_equal(key2, key) and np.array_equal(ft2, ft)
     kept = key.copy()
     assert twin.ahv_select_rotation_f32(ptr(key), ptr(R), 0, 0, N, 1, ptr(R_out), ptr(best), ptr(idx), 0, None) == 0

@@ -110,7 +110,7 @@ def test_verify_pair_target_features_only_and_errors(ops, ahv, dev, G):
     key = torch.zeros(1, dtype=torch.int64, device=dev)
     rc = lib.ahv_verify_pair_f32(G["vol_src"].data_ptr(), G["vol_tgt"].data_ptr(), G["R"].data_ptr(), 0, 0, G["W1"].data_ptr(),
                                  G["W2"].data_ptr(), G["b2"].data_ptr(), 1, 128, None, key.data_ptr(), None,
-                                 ahv._lib.AHV_SCORE_SPLIT_F16, None, None, None)
+                                 ahv._lib.AHV_SCORE_SPLIT_F16, None, None)
     assert rc == -1 and b"feat_tgt_out" in lib.ahv_last_error()
 
 
@@ -176,43 +176,6 @@ def test_spare_cus_change_the_grid_not_the_scores(ops, ahv, G, dev):
         assert (s - ref).abs().max().item() <= ORDER_ATOL and torch.equal(ops.unpack_best(k)[1], ops.unpack_best(ref_key)[1])
     with pytest.raises(RuntimeError):
         ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], spare_cus=256)
-
-
-def test_xcd_balance_is_pure_scheduling(ops, ahv, G, dev):
-    """ahv_verify_pair_f32's xcd_balance buffer: consecutive launches re-cut the hypotheses over the XCDs in proportion to
-    how busy their workgroups were.  Which wave scores a hypothesis never changes its score: every launch of the series
-    returns the bits of the launch without a buffer; the shares stay a plausible partition; garbage in the buffer falls
-    back to equal shares; launches the feature does not apply to (small N, B > 1) leave the buffer alone."""
-    R = to_dev(ahv.rotations.haar_rotations_np(50000, seed=59), dev)
-    ref, ref_key = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"], no_teams=True)
-    state = torch.zeros(16, dtype=torch.int64, device=dev)
-    for it in range(6):
-        s, k = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"], no_teams=True, balance=state)
-        assert torch.equal(s, ref) and torch.equal(k, ref_key), it
-        share = state[:4].view(torch.float32).cpu().numpy()
-        assert abs(float(share.sum()) - 1.0) < 1e-4 and share.min() >= 0.0999 and share.max() <= 0.1601, share
-        words = state.view(torch.int32).cpu().numpy()
-        assert int(words[25]) == it + 1 and int(words[24]) == 0 and not state[4:12].any()   # updated once, counters back at 0
-    assert float(np.abs(share - 0.125).max()) < 0.02      # a clock spread of a few per cent, not more
-    # the default path (teams for the remainder) and the shared per-device state
-    s, k = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"], balance=ops.xcd_balance(dev))
-    assert (s - ref).abs().max().item() <= ORDER_ATOL and torch.equal(ops.unpack_best(k)[1], ops.unpack_best(ref_key)[1])
-    # garbage: equal shares are used, and the first update brings the buffer back to a plausible partition
-    junk = torch.full((16,), 0x7F7F7F7F7F7F7F7F, dtype=torch.int64, device=dev)
-    junk[4:13] = 0
-    s, k = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"], no_teams=True, balance=junk)
-    assert torch.equal(s, ref) and torch.equal(k, ref_key)
-    share = junk[:4].view(torch.float32).cpu().numpy()
-    assert abs(float(share.sum()) - 1.0) < 1e-4 and share.min() >= 0.0999
-    # not applicable: fewer than eight rounds, or a batch -- same results, buffer untouched
-    before = state.clone()
-    s, _ = ops.verify_pair(G["vol_src"], G["vol_tgt"], R[:4096], G["W1"], G["W2"], G["b2"], no_teams=True, balance=state)
-    assert torch.equal(s, ref[:, :4096]) and torch.equal(state, before)
-    two = lambda t: torch.cat([t, t])
-    s, _ = ops.verify_pair(two(G["vol_src"]), two(G["vol_tgt"]), R[:20000], G["W1"], G["W2"], G["b2"], no_teams=True, balance=state)
-    assert torch.equal(s[0], ref[0, :20000]) and torch.equal(s[1], ref[0, :20000]) and torch.equal(state, before)
-    with pytest.raises(RuntimeError):
-        ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"], balance=torch.zeros(4, dtype=torch.int64, device=dev))
 
 
 # ------------------------------------------------------------------------------------------- keys

@@ -2,7 +2,7 @@
 // Includes the kernel source directly so that diagnostic builds (-DAHV_STAMPS) can read the
 // in-kernel cycle stamps.  Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DAHV_STAMPS] \
 //                                   -I3dahv_amd/csrc tools/kbench.cpp -o tools/kbench
-// Run (on the GPU box):  tools/kbench [N] [iters] [variant] [spare_cus] [no_teams] [xcd_balance]
+// Run (on the GPU box):  tools/kbench [N] [iters] [variant] [spare_cus] [no_teams]
 //   variant 3 = fp32 kernel (target features given), 4 = split-f16, 5 = fp32 with the target features built in the
 //   launch (ahv_verify_pair_f32); without [variant]: 3, 4 and 5 in turn.
 #include "../3dahv_amd/csrc/ahv_score.hip"
@@ -41,10 +41,6 @@ int main(int argc, char** argv)
     int64_t* dkey;
     const int spare = argc > 4 ? atoi(argv[4]) : 0;
     const bool no_teams = argc > 5 && atoi(argv[5]) != 0;
-    const bool use_balance = argc > 6 && atoi(argv[6]) != 0;  // consecutive launches calibrate their per-XCD shares
-    void* dbal = nullptr;
-    CK(hipMalloc(&dbal, 128));
-    CK(hipMemset(dbal, 0, 128));
     CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
     CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
     CK(hipMalloc(&dsc, N * 4)); CK(hipMalloc(&dkey, 8)); CK(hipMalloc(&dvt, vtgt.size() * 4));
@@ -75,7 +71,7 @@ int main(int argc, char** argv)
         if (variant < 3) { printf("variants 0-2 are retired\n"); return 1; }
         auto launch = [&]() {
             ahv::ScoreLaunch a = {dvol, variant == 5 ? dvt : dft, variant == 5, dR, 0, 0, dW1, dW2, db2, 1, N, dsc, dkey, nullptr,
-                                  cu, spare, variant == 4, no_teams, nullptr, use_balance ? dbal : nullptr};
+                                  cu, spare, variant == 4, no_teams, nullptr};
             return ahv::launch_score_hypotheses(a, 0);
         };
         for (int rep = 0; rep < 3; ++rep) {
@@ -98,14 +94,6 @@ int main(int argc, char** argv)
         double md = 0;
         for (long n = 0; n < N; ++n) md = std::max(md, (double)std::abs(sc[n] - ref[n]));
         printf("variant %d: max |score - variant3| = %.3g, score[0]=%.6f\n", variant, md, sc[0]);
-        if (use_balance) {
-            float sh[8];
-            unsigned tail[36];
-            CK(hipMemcpy(sh, dbal, 32, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(tail, dbal, 128, hipMemcpyDeviceToHost));
-            printf("  xcd shares after %u updates: %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n", tail[25], sh[0], sh[1], sh[2], sh[3], sh[4],
-                   sh[5], sh[6], sh[7]);
-        }
     }
 #ifdef AHV_STAMPS
     // stamps belong to the last variant run (3 = dual): 4 x (gather, gemm1) quarters, gemm2, score+tail
