@@ -358,7 +358,7 @@ def worker(args):
         costs the queue ~6 us of idling (the 12 us per step of round 3's every-launch bracketing were 1.7 % of `value`);
         the in-kernel real-time stamps of EVERY timed launch are reported beside them."""
         k = 8 if steps >= 24 else max(1, steps // 3)
-        idx = list(range(0, steps, k))
+        idx = list(range(k // 2, steps, k))  # mid-interval: an unbiased sample (step 0 runs behind the barrier's idle gap)
         return dict(zip(idx, new_events(len(idx)))), k
 
     def prewarm(min_ms, max_ms=1500.0, batch=8):
