@@ -104,13 +104,14 @@ class _EstimatorBase(nn.Module):
 
     # -- the verify step shared by test_step / validation_step / the harness
     @torch.no_grad()
-    def verify(self, img_feat_src, img_feat_tgt, proposals, want_scores: bool = False):
+    def verify(self, img_feat_src, img_feat_tgt, proposals, want_scores: bool = False, want_feat_tgt: bool = False):
         """For B volume pairs and shared proposals (N,3,3): scores (optional), best score, best index,
-        R_pred = proposals[idx]  (test_co3d.py:137-146, modules/model.py:186-196)."""
-        scores, key = self.feature_aligner.score_hypotheses(img_feat_src, img_feat_tgt, proposals,
-                                                            want_scores=want_scores)
-        best, idx, R_pred = ops.select_rotation(key, proposals)   # torch.max + proposals[idx] in one launch
-        return scores, best, idx, R_pred
+        R_pred = proposals[idx]  (test_co3d.py:137-146, modules/model.py:186-196): one fused launch + one select.
+        ``want_feat_tgt``: also return forward_3d2d(img_feat_tgt) as the launch built it (fifth element)."""
+        res = ops.verify_pair(img_feat_src, img_feat_tgt, proposals, *self.feature_aligner.head_weights(),
+                              want_scores=want_scores, want_feat_tgt=want_feat_tgt)
+        best, idx, R_pred = ops.select_rotation(res[1], proposals)   # torch.max + proposals[idx] in one launch
+        return (res[0], best, idx, R_pred, res[2]) if want_feat_tgt else (res[0], best, idx, R_pred)
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, cfg=None, map_location="cpu", strict: bool = True,
@@ -274,9 +275,9 @@ class EstimatorObjaverse(_EstimatorBase):
         gt_src_2_tgt_R = torch.bmm(R_tgt, torch.inverse(R_src))
         if proposals is None:
             proposals = self.fresh_proposals(img_src.device)
-        _, pred_sim, _, pred_R = self.verify(vol_src, vol_tgt, proposals)
-        # gt_sim: each sample's own GT rotation = per-sample R with N = 1 (modules/model.py:137-143)
-        f_tgt = self.feature_aligner.forward_3d2d(vol_tgt)
+        _, pred_sim, _, pred_R, f_tgt = self.verify(vol_src, vol_tgt, proposals, want_feat_tgt=True)
+        # gt_sim: each sample's own GT rotation = per-sample R with N = 1 (modules/model.py:137-143), against the target
+        # features the verify launch built
         gt_sim, _ = ops.score_hypotheses(vol_src, f_tgt, gt_src_2_tgt_R[:, None].contiguous(),
                                          *self.feature_aligner.head_weights())
         geo_dis = geodesic_deg(pred_R, gt_src_2_tgt_R)

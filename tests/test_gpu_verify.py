@@ -150,6 +150,11 @@ def test_team_tail_against_single_waves(ops, ahv, G, dev, n):
     assert torch.equal(s_rev.flip(1), s_1)
     s_rev_t, _, _ = two_launch(ops, G, R.flip(0).contiguous())
     assert (s_rev_t.flip(1) - s_1).abs().max().item() <= ORDER_ATOL
+    # the one-launch step on the same set: in-launch target features AND (where the plan has one) a team tail
+    s_v, k_v = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"])
+    assert (s_v - s_1).abs().max().item() <= ORDER_ATOL and torch.equal(ops.unpack_best(k_v)[1], ops.unpack_best(k_1)[1])
+    s_v1, _ = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, G["W1"], G["W2"], G["b2"], no_teams=True)
+    assert (s_v1 - s_1).abs().max().item() <= ORDER_ATOL
 
 
 def test_team_tail_against_the_oracle(ops, oracle, ahv, G, g128, dev):
