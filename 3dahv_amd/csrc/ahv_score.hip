@@ -259,9 +259,13 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         key_t best = kKeyEmpty;
         const float* Rb = R + (long)b * r_batch_stride;
         const int residue = xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
-        // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): the last, partial round of
-        // the persistent grid then spreads over ALL CUs with few waves each (a lone wave on a SIMD runs
-        // ~1.6x faster than a pair) instead of filling some CUs completely and leaving the rest idle.
+        // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): a partial last round of the persistent
+        // grid spreads over ALL CUs with few waves each instead of filling some CUs completely and leaving the rest idle.
+        // The deal inside a workgroup is STATIC.  The older wave of a SIMD issues first and finishes its share ~110 us before
+        // its partner (in-kernel stamps); letting every wave CLAIM its next slot from an LDS counter keeps the pairs together
+        // to the end -- and is not faster: 0.6902 against 0.6838 ms at N = 50 000, 0.358 against 0.348 at 25 000, equal at
+        // 6 250, 1 % faster only at 200 000 (profiles/r04j_wave_claim.txt).  The workgroup's time is set by what its CU gets
+        // through, not by how its waves share it.
         long h = (long)wave * gridDim.x + residue;
         // The rotation of the NEXT hypothesis travels as ONE vector load (lane i < 9 fetches element i) and is
         // broadcast with v_readlane at the top of the next iteration.  Not as scalar loads: SMEM shares lgkmcnt
