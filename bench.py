@@ -463,7 +463,7 @@ def worker(args):
             s_all, _ = ops.verify_pair(vs, vt, R_all, *head, split_f16=split, no_teams=True)
             v, ix = torch.max(s_all, dim=1)
             assert torch.equal(lp.out["idx"], ix), (lp.out["idx"], ix)
-            assert (lp.out["best"] - v).abs().max().item() <= 1e-6
+            assert (lp.out["best"] - v).abs().max().item() <= 5e-6  # teams may score a shard's remainder: equal to rounding
             B = vs.shape[0]
             return {"n_hyp_total": n_total, "B": B, "n_hyp_per_rank": hi - lo, "steps": steps, "warmup": warmup,
                     "ms_per_step": t / steps * 1e3, "hypotheses_per_s": B * n_total * steps / t,
