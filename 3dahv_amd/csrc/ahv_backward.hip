@@ -19,7 +19,9 @@
 #include <cstdint>
 
 #include "ahv_device.h"
+#ifndef AHV_DIAG_NO_FP32_LOW_HALF  // (tools/kbench_bwd A/B build of the unprotected kernels)
 #define AHV_FP32_LOW_HALF  // these kernels leave registers free on their SIMDs: see low_half (ahv_dual.h)
+#endif
 #include "ahv_dual.h"
 
 namespace ahv {

@@ -10,5 +10,5 @@ timeout 900 hipcc $F -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_l
 timeout 900 hipcc $F -DAHV_STAMPS -DAHV_DIAG_LINEAR_GATHER tools/kbench.cpp -o tools/kbench_stamps_lin
 # what low_half() (the packed-fp32 op_sel protection of the XDL kernel) would cost the fp32 kernels
 timeout 900 hipcc $F -DAHV_DIAG_FP32_LOW_HALF tools/kbench.cpp -o tools/kbench_lowhalf
-timeout 900 hipcc $F -DAHV_DIAG_FP32_LOW_HALF tools/kbench_bwd.cpp -o tools/kbench_bwd_lowhalf
+timeout 900 hipcc $F -DAHV_DIAG_NO_FP32_LOW_HALF tools/kbench_bwd.cpp -o tools/kbench_bwd_nolowhalf   # the backward kernels WITHOUT it (they ship with it)
 timeout 900 hipcc $F tools/kbench_bwd.cpp -o tools/kbench_bwd
