@@ -196,8 +196,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Group g = 2 (lane >> 5) + (second group of its half-wave), slot k = rank of the lane inside its group:
 //   z = 2 Q + (k & 1),  x = 4 (g & 1) + ((k >> 1) & 3),  y = 2 (g >> 1) + (k >> 3) [+ 4 in pass 1].
 // z is the FASTEST bit of k so that the contiguous lanes an LDS store is served by hold both z of their voxels: the
-// split-f16 kernel's 16-byte image stores (ahv_split.h) are then 2-way instead of 4-way bank conflicts (measured: conflict
-// cycles 1 680 -> 1 168 of 3 447 LDS cycles per hypothesis, profiles/r03e_split_pmc_summary.json).
+// split-f16 kernel's 16-byte image stores (ahv_split.h) were then 2-way instead of 4-way bank conflicts (measured: conflict
+// cycles 1 680 -> 1 168 of 3 447 LDS cycles per hypothesis, profiles/r03e_split_pmc_summary.json), and conflict-free
+// once the image's swizzle took the 8-lane store groups into account (round 4, split_addr).
 // The two groups of a half-wave differ in x bit 2, which keeps the ds_write_b32 of the blended voxels into the
 // XOR-swizzled quarter image (qoff) on 32 distinct banks.
 struct LaneVox {
