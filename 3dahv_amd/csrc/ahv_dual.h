@@ -399,7 +399,10 @@ __device__ __forceinline__ void hat_voxel_rt(HatVoxel& v, const float* srcT, con
 // conflicts, and leaves the rest to the partner wave.  The stream is cut in two so that its head can be issued
 // from inside the PREVIOUS quarter's GEMM (hat_prologue: coordinates, weights and the first kHatDepth row
 // requests, placed ahead of that GEMM's last MFMA chunk), which hides the gather's start-up round trip as well.
-constexpr int kHatDepth = 6;  // depths 4 and 8 measured slower (round 2)
+// The depth is the fp32 kernels' (4 and 8 measured slower there, round 2).  The split-f16 kernel is bound by what the LDS
+// gets through, not by its round trips: there every depth from 1 to 7 times the same, and it runs at depth 2 and spends
+// the registers on W1 fragments instead (kSplitHatDepth, ahv_split.h).  A kernel only touches the slots below its depth.
+constexpr int kHatDepth = 6;
 static_assert(kHatDepth >= 1 && kHatDepth <= 8, "the prologue requests rows of pass 0 only");
 
 struct HatState {
@@ -409,19 +412,20 @@ struct HatState {
 
 // MIR: the quarter being gathered is the point mirror of the one whose voxels st.vx was set up for (hat_mirror below):
 // its pass-p voxel is the mirror of the other quarter's pass-(1 - p) voxel.
-template <int S, bool MIR = false>
+template <int S, bool MIR = false, int DEPTH = kHatDepth>
 __device__ __forceinline__ void hat_request(HatState& st)
 {
+    static_assert(DEPTH >= 1 && DEPTH <= kHatDepth, "ring slots");
     const f32x4* row = reinterpret_cast<const f32x4*>(st.vx[MIR ? 1 - (S >> 3) : (S >> 3)].base + hat_off(S & 7));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st.ring[S % kHatDepth][j] = row[j];
+    for (int j = 0; j < 4; ++j) st.ring[S % DEPTH][j] = row[j];
 }
 
 template <int S, int END, bool MIR = false>
-struct HatRequests {
+struct HatRequests {  // the first END requests of a quarter = a ring of depth END being filled
     static __device__ __forceinline__ void run(HatState& st)
     {
-        hat_request<S, MIR>(st);
+        hat_request<S, MIR, END>(st);
         HatRequests<S + 1, END, MIR>::run(st);
     }
 };
@@ -452,20 +456,21 @@ __device__ __forceinline__ void hat_mirror(HatState& st, const float* srcT)
 }
 
 // head of the mirrored quarter's gather (the counterpart of hat_prologue)
+template <int DEPTH = kHatDepth>
 __device__ __forceinline__ void hat_prologue_mirror(HatState& st, const float* srcT)
 {
     hat_mirror(st, srcT);
-    HatRequests<0, kHatDepth, true>::run(st);
+    HatRequests<0, DEPTH, true>::run(st);
 }
 
-template <int Q, bool XDL = kFp32LowHalf>
+template <int Q, bool XDL = kFp32LowHalf, int DEPTH = kHatDepth>
 __device__ __forceinline__ void hat_prologue(HatState& st, const float* srcT, const GatherHyp& h)
 {
     // voxel 0, its first row requests, THEN voxel 1: setting both voxels up together (packed over the two passes, 24
     // instructions fewer per hypothesis) was measured slower -- 0.6911 vs 0.6880 ms per 50 000 hypotheses, round 3 -- the
     // first six row requests then wait for both set-ups
     hat_voxel<Q, XDL>(st.vx[0], srcT, h, 0);
-    HatRequests<0, kHatDepth>::run(st);
+    HatRequests<0, DEPTH>::run(st);
     hat_voxel<Q, XDL>(st.vx[1], srcT, h, 1);
 }
 
@@ -481,6 +486,7 @@ __device__ __forceinline__ void hat_prologue_rt(HatState& st, const float* srcT,
 template <int ROW>
 struct HatStoreF32 {
     static constexpr bool kXdlKernel = kFp32LowHalf;  // fp32 MFMAs only: no protection needed (see low_half)
+    static constexpr int kDepth = kHatDepth;
     float* d[2];  // the lane's voxel of pass 0 / pass 1 in channel plane 0
     __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
     {
@@ -502,7 +508,7 @@ struct HatSteps {
         const f32x2 wn = {wsc, wsc};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 v = st.ring[S % kHatDepth][j];
+            const f32x4 v = st.ring[S % Store::kDepth][j];
             const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
             if (n == 0) {
                 o[2 * j] = lo * wn;
@@ -513,7 +519,7 @@ struct HatSteps {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (S + kHatDepth < 16) hat_request<(S + kHatDepth < 16 ? S + kHatDepth : 0), MIR>(st);
+        if (S + Store::kDepth < 16) hat_request<(S + Store::kDepth < 16 ? S + Store::kDepth : 0), MIR, Store::kDepth>(st);
         if (n == 7) store(p, o);
         HatSteps<S + 1, Store, MIR>::run(st, o, store);
     }

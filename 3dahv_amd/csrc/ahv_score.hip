@@ -44,29 +44,32 @@ __device__ __forceinline__ float swap_add16(float a, float b)
 // test_co3d.py:143) as a reduce-scatter: a lane holds 8 of the 32 channels of position (16t + lane&15) for the
 // four tiles t; after two exchange steps lane (col, kq) owns the complete sums of ONE position (tile kq, column
 // col), so the normalisation runs once per lane.  Result uniform (read from lane 63).
+// One tile's share: sums of squares and dot products of a lane's 8 channels of position (16 t + lane & 15).
 template <bool XDL>  // XDL: the kernel issues XDL MFMAs (low_half, ahv_dual.h)
-__device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x4 (&tg)[4][2], int lane)
+__device__ __forceinline__ void hyp_tile_sums(float& ss, float& dt, const f32x4& v0, const f32x4& v1, const f32x4& g0, const f32x4& g1)
 {
-    // sums of squares and dot products on v_pk_fma_f32: even and odd registers accumulate side by side and meet in
-    // one addition (32 packed instead of 64 scalar FMAs per hypothesis; the order of the eight additions differs from
-    // a sequential sum in the last bit at most)
-    float ss[4], dt[4];
+    // on v_pk_fma_f32: even and odd registers accumulate side by side and meet in one addition (8 packed instead of 16
+    // scalar FMAs per tile; the order of the eight additions differs from a sequential sum in the last bit at most)
+    f32x2 s2 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f32x2 s2 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f};
+    for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const f32x2 x = {v[m2][t][2 * hh], v[m2][t][2 * hh + 1]};
-                const f32x2 g = {tg[t][m2][2 * hh], tg[t][m2][2 * hh + 1]};
-                s2 = __builtin_elementwise_fma(x, x, s2);
-                d2 = __builtin_elementwise_fma(x, g, d2);
-            }
-        // hipcc adds the halves of a pair with v_pk_add_f32 op_sel:[0,1]: the low lane reads a high half
-        ss[t] = s2[0] + (XDL ? low_half(s2[1]) : s2[1]);
-        dt[t] = d2[0] + (XDL ? low_half(d2[1]) : d2[1]);
-    }
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4& vv = m2 ? v1 : v0;
+            const f32x4& gg = m2 ? g1 : g0;
+            const f32x2 x = {vv[2 * hh], vv[2 * hh + 1]};
+            const f32x2 g = {gg[2 * hh], gg[2 * hh + 1]};
+            s2 = __builtin_elementwise_fma(x, x, s2);
+            d2 = __builtin_elementwise_fma(x, g, d2);
+        }
+    // hipcc adds the halves of a pair with v_pk_add_f32 op_sel:[0,1]: the low lane reads a high half
+    ss = s2[0] + (XDL ? low_half(s2[1]) : s2[1]);
+    dt = d2[0] + (XDL ? low_half(d2[1]) : d2[1]);
+}
+
+// From the per-tile sums to the hypothesis' score.  Result uniform (read from lane 63).
+__device__ __forceinline__ float hyp_score_tail(const float (&ss)[4], const float (&dt)[4])
+{
     // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: with
     // (first, second) = (tile i, tile i+2) every lane then holds, in the two registers, its own half-sum of the
     // tile it keeps (i below lane 32, i+2 above) and the partner lane's half-sum of that same tile.  One VALU
@@ -86,6 +89,19 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
     const float c = d1 * __builtin_amdgcn_rsqf(fmaxf(s1, 1e-24f));
     const float tot = wave_sum_dpp(c);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63)) * (1.0f / 64.0f);
+}
+
+// F.normalize(dim=1), dot with the unit-norm target, mean over the 64 positions (modules/modules.py:122,
+// test_co3d.py:143) as a reduce-scatter: a lane holds 8 of the 32 channels of position (16t + lane&15) for the
+// four tiles t; after two exchange steps lane (col, kq) owns the complete sums of ONE position (tile kq, column
+// col), so the normalisation runs once per lane.
+template <bool XDL>
+__device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x4 (&tg)[4][2], int lane)
+{
+    float ss[4], dt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hyp_tile_sums<XDL>(ss[t], dt[t], v[0][t], v[1][t], tg[t][0], tg[t][1]);
+    return hyp_score_tail(ss, dt);
 }
 
 #ifdef AHV_STAMPS
@@ -155,12 +171,13 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     unsigned long long wg_t_loop = 0;
 #endif
     if (!SPLIT && tid < (int)(sizeof(TeamSync) / 4)) reinterpret_cast<unsigned*>(&lds_team)[tid] = 0u;
-    int w1_exp = 0;
+    int w1_exp = 0, w2_exp = 0;
     if (SPLIT) {
         float m = 0.0f;
         for (int i = tid; i < 32 * 384; i += kDualThreads) m = fmaxf(m, fabsf(W1[i]));
         w1_exp = split_prescale_exp(block_absmax(m, lds_q, tid));
         stage_w1_split(reinterpret_cast<f16x8*>(lds_w1), W1, ldexpf(1.0f, w1_exp), tid, kDualThreads);
+        w2_exp = split_prescale_exp(block_absmax(fmaxf(fabsf(W2[tid]), fabsf(W2[tid + 512])), lds_q, tid));
     } else {
         stage_w1_table(lds_w1, W1, tid, kDualThreads);
     }
@@ -172,6 +189,11 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
     const GatherLane glane = gather_lane(lane);
     const GatherDst gdst = gather_dst_swizzled(lane);
     const SplitDst sdst = split_dst(lane);
+    SplitResident w1res;
+    if (SPLIT) {
+        __syncthreads();  // the table is staged
+        split_load_resident(w1res, reinterpret_cast<const f16x8*>(lds_w1), lane);
+    }
     const long hstep = (long)gridDim.x * 8;
     // Diagnostic entry point (clk != NULL): shader-clock and 100 MHz real-time stamps around this workgroup's whole run
     // (lds_t_entry above, the end stamps below).  The stamps go to `clk` alone; no output depends on them.
@@ -183,17 +205,12 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // loop, i.e. in scratch (2-4 MB of spill stores per launch showed up as WRITE_SIZE, profiles/r04c_pmc_summary.json).
         const int lane_s = opaque(lane), tid_s = wave * 64 + lane_s;  // (not from threadIdx.x: that register may die here)
         DualFrags f = f0;
+        Split2Frags w2s;
+        int exp_sum = 0;  // of the three prescales of this sample: they leave again behind GEMM2 (gemm2_split)
         if (SPLIT) {
-            load_dual_frags(f, W2, b2, lane_s);  // re-read per sample: keeping an unscaled copy costs 16 registers the gather needs
-            const int v_exp = stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid_s);
-            const float unscale = ldexpf(1.0f, -(w1_exp + v_exp));  // exact; relu commutes with it
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f.a2[m][r][0] *= unscale;
-                    f.a2[m][r][1] *= unscale;
-                }
+            load_dual_frags(f, W2, b2, lane_s);
+            split_w2_frags(w2s, f, ldexpf(1.0f, w2_exp));
+            exp_sum = w2_exp + w1_exp + stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid_s);
         } else {
             stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid_s, kDualThreads);
             if constexpr (TGT) {
@@ -305,18 +322,18 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 HatState st;
                 // quarters in the order 0, 3, 1, 2 (point mirror, as in the fp32 path); the prologues run between the GEMMs:
                 // the request ring does not fit beside the GEMM's operands
-                hat_prologue<0, true>(st, srcT, gh);
+                hat_prologue<0, true, kSplitHatDepth>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(1)
-                gemm1_quarter_split<0>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(2)
-                hat_prologue_mirror(st, srcT);
+                gemm1_quarter_split<0>(acc, w1res, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(2)
+                hat_prologue_mirror<kSplitHatDepth>(st, srcT);
                 hat_body_split<true>(st, cbuf, sdst); wave_lds_fence(); AHV_TS(3)
-                gemm1_quarter_split<3>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(4)
-                hat_prologue<1, true>(st, srcT, gh);
+                gemm1_quarter_split<3>(acc, w1res, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(4)
+                hat_prologue<1, true, kSplitHatDepth>(st, srcT, gh);
                 hat_body_split(st, cbuf, sdst); wave_lds_fence(); AHV_TS(5)
-                gemm1_quarter_split<1>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(6)
-                hat_prologue_mirror(st, srcT);
+                gemm1_quarter_split<1>(acc, w1res, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(6)
+                hat_prologue_mirror<kSplitHatDepth>(st, srcT);
                 hat_body_split<true>(st, cbuf, sdst); wave_lds_fence(); AHV_TS(7)
-                gemm1_quarter_split<2>(acc, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
+                gemm1_quarter_split<2>(acc, w1res, w1s, cbuf, lane, [] {}); wave_lds_fence(); AHV_TS(8)
             } else {
                 // gather quarter q (16 blend steps) -> GEMM1 on it; the head of quarter q+1's gather (coordinates,
                 // weights, first row requests) is issued from inside GEMM q, ahead of its last MFMA chunks
@@ -336,16 +353,33 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             }
 
             tg_wait();
-            f32x4 v[2][4];
-            gemm2_dual(v, acc, f);
-            AHV_TS(9)
-            f32x4 tg[4][2];
+            float s;
+            if constexpr (SPLIT) {
+                // tile by tile: the 8 outputs of a tile go straight into its sums (32 registers of v never exist at once)
+                const Gemm2Scale sc = gemm2_split_scale(acc, exp_sum);
+                float ss[4], dt[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t) * 64 + lane) * kSrcStride + 16);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + 1) * 64 + lane) * kSrcStride + 16);
+                    f32x4 v0, v1;
+                    gemm2_split_tile(v0, v1, acc[0][t], acc[1][t], w2s, f.bias, sc);
+                    hyp_tile_sums<true>(ss[t], dt[t], v0, v1, g0, g1);
+                }
+                AHV_TS(9)
+                s = hyp_score_tail(ss, dt);
+            } else {
+                f32x4 v[2][4];
+                gemm2_dual(v, acc, f);
+                AHV_TS(9)
+                f32x4 tg[4][2];
 #pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-                    tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
-            const float s = hyp_score_rs<SPLIT || kFp32LowHalf>(v, tg, lane);
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2)
+                        tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
+                s = hyp_score_rs<kFp32LowHalf>(v, tg, lane);
+            }
             if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
             const key_t key = pack_key(s, (unsigned)(n_offset + h));
             best = key > best ? key : best;

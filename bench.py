@@ -39,7 +39,8 @@ HBM_BYTES_PER_HYP = 36         # the timed launch keeps only the arg-max (want_s
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (at the 2.4 GHz maximum clock)
 MAX_CLOCK_GHZ = 2.4
 PEAK_LDS_TBPS = 256 * 256 * 2.4e9 / 1e12   # 157.3: 256 B/clk/CU (ds_read_b128), 256 CUs, 2.4 GHz
-SPLIT_LDS_BYTES_PER_HYP = 262144 + 32768 + 98304 + 147456 + 8192   # split-f16 kernel, see its lds_roofline entry
+SPLIT_LDS_BYTES_PER_HYP = 262144 + 32768 + 98304 + 65536 + 8192   # split-f16 kernel, see its lds_roofline entry
+SPLIT_LDS_BYTES_PER_HYP_R3 = 262144 + 32768 + 98304 + 147456 + 8192   # round 3's formulation: every W1 fragment from the LDS
 TRAFFIC_JSON = os.path.join("profiles", "traffic.json")
 
 
@@ -585,10 +586,14 @@ def worker(args):
                 # bytes one hypothesis moves through the LDS in this formulation / the guide's LDS rate
                 "lds_roofline": {"bound": "lds", "bytes_per_hypothesis": SPLIT_LDS_BYTES_PER_HYP,
                                  "bytes_breakdown": "gather 8 voxels x 8 corners x 4 ds_read_b128 per lane 262144 + image "
-                                                    "stores 32768 + B fragments 98304 + W1 fragments 147456 + target 8192",
+                                                    "stores 32768 + B fragments 98304 + W1 fragments 65536 (64 of the 144 "
+                                                    "fragment reads; the other 80 are served from registers) + target 8192",
                                  "achieved": SPLIT_LDS_BYTES_PER_HYP * N_HYP / (ms4 * 1e-3) / 1e12,
                                  "peak": PEAK_LDS_TBPS, "unit": "TB/s",
                                  "frac": SPLIT_LDS_BYTES_PER_HYP * N_HYP / (ms4 * 1e-3) / 1e12 / PEAK_LDS_TBPS,
+                                 # the same time priced with the bytes of round 3's formulation (what the 0.47 of
+                                 # rounds 3 was quoted on): comparable across rounds, not a statement about LDS traffic
+                                 "frac_at_round3_bytes": SPLIT_LDS_BYTES_PER_HYP_R3 * N_HYP / (ms4 * 1e-3) / 1e12 / PEAK_LDS_TBPS,
                                  "note": "peak = 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS); bank "
                                          "conflicts of the rotated gather (1.64 LDS cycles per conflict-free cycle, "
                                          "simulated and measured) are inside the achieved figure"}}
