@@ -1,4 +1,4 @@
-"""AHV_SCORE_SPLIT_F16 ("split"): GEMM1 on the f16 matrix pipe with hi/lo split operands, fp32 accumulation.
+"""AHV_SCORE_SPLIT_F16 ("split"): GEMM1 and GEMM2 on the f16 matrix pipe with hi/lo split operands, fp32 accumulation.
 
 Opt-in (the default kernel is all-fp32).  These tests pin what makes it usable as an fp32 stand-in:
 the same parity bar as the fp32 kernels against the golden vectors, an error against an fp64 evaluation
@@ -78,6 +78,29 @@ def test_split_is_scale_free(ops, ahv, variant, dev, vscale, wscale):
     assert (s4.double() - truth).abs().max().item() < 1e-6
     assert (s32.double() - truth).abs().max().item() < 1e-6
     assert torch.equal(i4, truth.argmax(dim=1))
+
+
+def test_split_dynamic_range_inside_a_sample(ops, ahv, variant, dev):
+    """The prescales are per sample (GEMM1) and per lane and hypothesis (GEMM2's activations): what they cannot level is a
+    range INSIDE a sample.  Voxel magnitudes falling by 10^3 across the volume (so that whole positions of the feature map
+    see small activations beside large ones) stay inside the same bound against the fp64 evaluation."""
+    g128 = load_golden("score_n128")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R = t(ahv.rotations.haar_rotations_np(900, 12))
+    ramp = torch.logspace(0, -3, 8, device=dev)
+    W1, W2, b2 = t(g128["W1"]), t(g128["W2"]), t(g128["b2"])
+    vt = t(g128["vol_tgt"])
+    for axis in (2, 3, 4):
+        shape = [1, 1, 1, 1, 1]
+        shape[axis] = 8
+        vs = t(g128["vol_src"]) * ramp.view(shape)
+        truth = f64_truth(vs, vt, R, W1, W2, b2)
+        s4, i4 = scores_with(ops, variant, 4, vs, vt, R, W1, W2, b2)
+        s32, i32 = scores_with(ops, variant, 3, vs, vt, R, W1, W2, b2)
+        e4, e32 = (s4.double() - truth).abs().max().item(), (s32.double() - truth).abs().max().item()
+        print(f"axis {axis}: max |score - f64| fp32 {e32:.2e}, split {e4:.2e}")
+        assert e32 < 1e-6 and e4 < 1e-6
+        assert torch.equal(i4, truth.argmax(dim=1))
 
 
 def test_split_zero_and_nonfinite_operands(ops, ahv, variant, dev):
