@@ -137,6 +137,24 @@ __device__ __forceinline__ unsigned pk_rtz(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
+// hi = (x0, x1) rounded towards zero to f16 = their top 11 significant bits; lo = x - hi exactly (then rounded to f16), each
+// difference on ONE instruction that reads its f16 operand in place (v_fma_mix_f32: fma(f16 -> f32, -1, x)) -- four
+// instructions per pair of values where masking x, subtracting and converting took six (five with a packed subtraction):
+// 1 336 -> 1 192 vector instructions per hypothesis, -1.5 % of kernel time.  hipcc has no pattern for it (it converts and
+// subtracts): op_sel_hi marks source 0 as f16, op_sel picks its half.  (v_fma_mixlo_f16 / mixhi_f16 would write the lo pair
+// directly, three instructions per pair: measured 0.6 % SLOWER -- the second writes into the register of the first.)
+// The op_sel here picks a 16-bit half of an f16 source; it is not the packed-fp32 cross-half read of the hazard low_half
+// guards against, and the forced-gap and fresh-process tests of tests/test_gpu_split.py run through these instructions.
+__device__ __forceinline__ unsigned split_hi_lo(unsigned& lo, float x0, float x1)
+{
+    const unsigned h = pk_rtz(x0, x1);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(x1));
+    lo = pk_rtz(l0, l1);
+    return h;
+}
+
 // The gather is the fp32 kernel's (ahv_dual.h: hat weights on a clamped base row, one base address per voxel, a
 // request ring six rows deep, the 4 x 2 x 2-box lane map); only the store differs: the sixteen blended channels are
 // split into hi (the top 11 significant bits, exactly an f16 in the normal range) and lo (the rest) and leave as
@@ -179,10 +197,7 @@ struct HatStoreSplit {
                 // scalars first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this
                 // hipcc (ROCm 7.2) whatever the index
                 const float x0 = o[4 * half + i][0], x1 = o[4 * half + i][1];
-                const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xFFFFE000u);
-                const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xFFFFE000u);
-                hi[i] = pk_rtz(h0, h1);
-                lo[i] = pk_rtz(x0 - h0, x1 - h1);
+                hi[i] = split_hi_lo(lo[i], x0, x1);
             }
             *reinterpret_cast<u32x4*>(dst + (MIR ? d.chunk_m[half] : d.chunk[half])) = u32x4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<u32x4*>(dst + kSplitLoPlane + (MIR ? d.chunk_m[half] : d.chunk[half])) = u32x4{lo[0], lo[1], lo[2], lo[3]};
@@ -392,11 +407,7 @@ __device__ __forceinline__ void gemm2_split_tile(f32x4& v0, f32x4& v1, const f32
         // scalars first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this hipcc
         // (ROCm 7.2) whatever the index
         const float x0 = x[0], x1 = x[1];
-        const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xFFFFE000u);
-        const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xFFFFE000u);
-        const f32x2 l = x - f32x2{h0, h1};
-        hi[i] = pk_rtz(h0, h1);
-        lo[i] = pk_rtz(l[0], l[1]);
+        hi[i] = split_hi_lo(lo[i], x0, x1);
     }
     const f16x8 bh = __builtin_bit_cast(f16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
     const f16x8 bl = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
