@@ -29,7 +29,7 @@ _SPLIT_F16 = contextvars.ContextVar("ahv_split_f16", default=False)
 
 class split_f16_scorer:
     """``with ops.split_f16_scorer(): ...`` -- inside the block (this thread / context only) ``score_hypotheses``
-    passes ``AHV_SCORE_SPLIT_F16``: GEMM1 as split-f16 MFMA products with fp32 accumulation (1.8x faster, scores as
+    passes ``AHV_SCORE_SPLIT_F16``: both GEMMs as split-f16 MFMA products with fp32 accumulation (2.1x faster, scores as
     close to the fp64 truth as the fp32 kernel's -- DESIGN.md section 4.1).  Opt-in; the default is the all-fp32
     kernel.  The choice travels with each call as a flag bit: the library keeps no process-wide selector, so
     concurrent threads / streams cannot disturb each other.  ``score_hypotheses(..., split_f16=True)`` selects

@@ -72,13 +72,14 @@ extern "C" {
 
 /* flags of ahv_score_hypotheses_f32 */
 #define AHV_SCORE_RESET_BEST 1u /* set best_key[0..B) to AHV_KEY_EMPTY on the stream before scoring */
-#define AHV_SCORE_SPLIT_F16 2u  /* opt-in kernel for THIS call: GEMM1 (the 384 -> 32 projection) as three f16 MFMA
-                                 * products of hi/lo-split operands with fp32 accumulation (the dropped lo*lo term is
-                                 * 2^-22 relative; power-of-two prescales chosen on the device keep every finite fp32
-                                 * input exact in range).  Scores are as close to the fp64 truth as the default
-                                 * kernel's (~7e-8), the arithmetic is not IEEE fp32 operation by operation, hence
-                                 * opt-in.  GEMM2, normalisation and score stay fp32.  1.8x faster.  The selector is
-                                 * per call: there is no process-wide kernel switch. */
+#define AHV_SCORE_SPLIT_F16 2u  /* opt-in kernel for THIS call: GEMM1 (the 384 -> 32 projection) and GEMM2 (32 -> 32) as
+                                 * three f16 MFMA products of hi/lo-split operands with fp32 accumulation (the dropped
+                                 * lo*lo term is 2^-22 relative; power-of-two prescales chosen on the device -- per launch
+                                 * for the weights, per sample for the volume, per hypothesis for the activations -- keep
+                                 * every finite fp32 input in range).  Scores are as close to the fp64 truth as the
+                                 * default kernel's (~7e-8), the arithmetic is not IEEE fp32 operation by operation,
+                                 * hence opt-in.  The blend, normalisation and score stay fp32.  2.1x faster.  The
+                                 * selector is per call: there is no process-wide kernel switch. */
 
 #define AHV_SCORE_NO_TEAMS 4u   /* every hypothesis by ONE wave.  Default: the remainder of a launch that would fill less than
                                  * a quarter of the device's wave slots is scored by teams of four waves (a quarter of the
