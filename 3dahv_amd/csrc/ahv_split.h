@@ -1,4 +1,4 @@
-// ahv_split.h -- GEMM1 of the fused scorer on the f16 matrix pipe with split operands (OPT-IN per call through
+// ahv_split.h -- GEMM1 and GEMM2 of the fused scorer on the f16 matrix pipe with split operands (OPT-IN per call through
 // AHV_SCORE_SPLIT_F16: the default stays the all-fp32 dual kernel).
 //
 // Why: fp32 MFMA tops out at 157 TFLOP/s and shares its issue slots with VALU work (ahv_dual.h), so the
