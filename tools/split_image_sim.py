@@ -97,6 +97,32 @@ def plane_read_conflicts(m0, h0, h1, h2):
     return 4 * _extra(s, 16)
 
 
+def conflicts_of_address_function(addr):
+    """(store, read) extra LDS cycles per hypothesis of an arbitrary hi-plane address function addr(a0, b, e, chunk) ->
+    byte offset (chunk 0 / 1), with the lo plane a constant offset away: the check tests/test_split_image_layout.py runs on
+    the expression it reads out of ahv_split.h."""
+    lv = [lane_vox(l) for l in range(64)]
+    st = 0
+    for q in range(4):
+        for p in range(2):
+            for c in range(2):
+                if q in (1, 2):
+                    a = np.array([addr(1 - a0, 4 * p + 3 - bq, 7 - e, c) for (e, a0, bq) in lv])
+                else:
+                    a = np.array([addr(a0, 4 * p + bq, e, c) for (e, a0, bq) in lv])
+                st += 2 * _extra(((a // 16) % 8)[WRITE_GROUPS], 8)      # the hi and the lo store of the chunk
+    rd = 0
+    for ks in range(4):
+        for slab in "xyz":
+            a = []
+            for lane in range(64):
+                n, kq = lane & 15, lane >> 4
+                i0, j, kh, kc = n >> 3, n & 7, kq >> 1, kq & 1
+                a.append(addr(i0, j, 2 * ks + kh, kc) if slab == "x" else addr(i0, 2 * ks + kh, j, kc) if slab == "y" else addr(kh, 2 * ks + i0, j, kc))
+            rd += 2 * _extra(((np.array(a) // 16) % 16)[READ_GROUPS], 16)  # hi and lo fragment
+    return st, 4 * rd
+
+
 def subsets(bits):
     for r in range(len(bits) + 1):
         for c in itertools.combinations(bits, r):
