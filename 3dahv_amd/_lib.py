@@ -46,6 +46,8 @@ SIGNATURES = {
     "ahv_so3_grid_f32": (_int, [_i64, _i64, _i64, _vp, _vp]),
     "ahv_select_rotation_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _u32, _vp]),
     "ahv_compose_rotations_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp]),
+    "ahv_coarse_to_fine_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
 }
 
 class BlockWeights(ctypes.Structure):

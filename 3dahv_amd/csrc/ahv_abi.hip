@@ -75,7 +75,7 @@ int cu_count()
 
 extern "C" {
 
-int ahv_abi_version(void) { return (2 << 16) | 0; }
+int ahv_abi_version(void) { return (2 << 16) | 1; }
 
 const char* ahv_last_error(void) { return g_err; }
 
@@ -257,6 +257,37 @@ int ahv_compose_rotations_f32(const int64_t* best_key, const float* R, int64_t r
     hipError_t e = ahv::launch_compose_rotations(best_key, R, r_batch_stride, n_offset, N, D, N2, B, out,
                                                  static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail("compose_rotations: launch", e);
+    return AHV_OK;
+}
+
+int ahv_coarse_to_fine_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride, int64_t N,
+                           const float* D, int64_t N2, const float* W1, const float* W2, const float* b2, int B,
+                           float* scores_coarse, float* scores_fine, int64_t* keys, uint32_t* sync, float* feat_tgt_out,
+                           float* R_pred, float* fine_score, int64_t* fine_idx, float* coarse_score, int64_t* coarse_idx,
+                           unsigned flags, void* stream)
+{
+    if (B < 0 || N < 0 || N2 < 0) return fail(AHV_EINVAL, "coarse_to_fine: negative size (B=%d, N=%lld, N2=%lld)", B, (long long)N, (long long)N2);
+    if (B == 0) return AHV_OK;
+    if (N == 0 || N2 == 0) return fail(AHV_EINVAL, "coarse_to_fine: empty hypothesis set (N=%lld, N2=%lld)", (long long)N, (long long)N2);
+    if (!vol_src || !vol_tgt || !R || !D || !W1 || !W2 || !b2) return fail(AHV_EINVAL, "coarse_to_fine: null input pointer");
+    if (!keys || !sync) return fail(AHV_EINVAL, "coarse_to_fine: keys and sync are required (2 B keys, 2 B + 1 counters)");
+    if (r_batch_stride != 0 && r_batch_stride < N * 9)
+        return fail(AHV_EINVAL, "coarse_to_fine: r_batch_stride %lld must be 0 or >= N*9", (long long)r_batch_stride);
+    if (N > 4294967296ll || N2 > 4294967296ll) return fail(AHV_EINVAL, "coarse_to_fine: indices must fit in 32 bits");
+    if (flags & ~(AHV_SCORE_NO_TEAMS | AHV_SCORE_SPARE_CUS_MASK)) return fail(AHV_EINVAL, "coarse_to_fine: unknown flags 0x%x", flags);
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    ahv::CoarseToFineLaunch a;
+    ahv::ScoreLaunch& c = a.coarse;
+    c.vol_src = vol_src; c.tgt = vol_tgt; c.tgt_is_volume = true; c.R = R; c.r_batch_stride = r_batch_stride; c.n_offset = 0;
+    c.W1 = W1; c.W2 = W2; c.b2 = b2; c.B = B; c.N = N; c.scores = scores_coarse; c.best_key = keys;
+    c.feat_tgt_out = feat_tgt_out; c.num_cu = cu;
+    c.spare_cu = (int)((flags & AHV_SCORE_SPARE_CUS_MASK) >> AHV_SCORE_SPARE_CUS_SHIFT);
+    c.split_f16 = false; c.no_teams = (flags & AHV_SCORE_NO_TEAMS) != 0; c.clock_stamps = nullptr;
+    a.D = D; a.N2 = N2; a.scores2 = scores_fine; a.best_key2 = keys + B; a.sync = sync; a.R_pred = R_pred;
+    a.fine_score = fine_score; a.coarse_score = coarse_score; a.fine_idx = fine_idx; a.coarse_idx = coarse_idx;
+    hipError_t e = ahv::launch_coarse_to_fine(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("coarse_to_fine: launch", e);
     return AHV_OK;
 }
 

@@ -32,4 +32,19 @@ struct ScorePlan {
 ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool teams);
 hipError_t launch_score_hypotheses(const ScoreLaunch& a, hipStream_t stream);
 
+// ahv_coarse_to_fine_f32: the verify step on the coarse set (a.coarse, tgt = the target volume, n_offset 0) and, in the
+// same launch, on the refinement set R* D[n] of its winner (coarse_to_fine_kernel, ahv_score.hip)
+struct CoarseToFineLaunch {
+    ScoreLaunch coarse;
+    const float* D;            // [N2][3][3]
+    int64_t N2;
+    float* scores2;            // [B][N2] or NULL
+    int64_t* best_key2;        // [B], EMPTY on entry and exit
+    uint32_t* sync;            // [2 B + 1], zero on entry and exit (last word: error flag, sticky)
+    float* R_pred;             // [B][3][3]
+    float *fine_score, *coarse_score;
+    int64_t *fine_idx, *coarse_idx;
+};
+hipError_t launch_coarse_to_fine(const CoarseToFineLaunch& a, hipStream_t stream);
+
 }  // namespace ahv

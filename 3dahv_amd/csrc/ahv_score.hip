@@ -128,14 +128,33 @@ constexpr int kDualThreads = 512;
 // TGT = true: `tgt` is the target VOLUME [B][16][8][8][8] and team 1 of every workgroup builds forward_3d2d of it while
 // the other waves are on their first hypothesis (ahv_verify_pair_f32); else `tgt` = the features [B][32][64].
 // Hypotheses [0, n_main) go to single waves, [n_main, N) to teams of four (n_main = N: no teams).
-template <bool SPLIT, bool TGT>
-__global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
+// C2F = true (coarse_to_fine_kernel, ahv_coarse_to_fine_f32): TWO stages in one launch.  Stage 0 is the verify step above on
+// the coarse set R; the workgroups of a sample then meet at a device-wide counter, read the winner's rotation R* and
+// stage 1 scores the refinement set R* D[n] (composed per hypothesis from the 36 bytes of D[n], the arithmetic of
+// compose_rotations_kernel) against the target features stage 0 left in LDS; the workgroup that finishes a sample last
+// decodes both keys (what the two select launches did) and hands keys and counters back empty.
+struct C2fArgs {
+    const float* D;          // [N2][3][3] refinement rotations
+    long N2, n_main2;        // stage 1's hypotheses and how many of them go to single waves
+    key_t* best_key2;        // [B] stage 1's key (EMPTY on entry and on exit, like best_key)
+    float* scores2;          // [B][N2] or NULL
+    unsigned* sync;          // [2 B + 1]: per sample {arrived at the meeting point, finished}, then an error word; 0 on entry
+    float* R_pred;           // [B][3][3]   = R* D[n*]
+    float *fine_score, *coarse_score;  // [B]
+    long *fine_idx, *coarse_idx;       // [B]
+};
+constexpr unsigned kC2fSpinLimit = 1u << 20;  // polls (~1 us each) before a workgroup gives the meeting point up: the
+                                              // launch then ends with the error word set instead of hanging the device
+
+template <bool SPLIT, bool TGT, bool C2F>
+__device__ __forceinline__ void score_hypotheses_body(
     const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
     long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
     const float* __restrict__ b2, int B, long N, long n_main, float* __restrict__ scores,
-    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, unsigned long long* __restrict__ clk)
+    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, unsigned long long* __restrict__ clk, const C2fArgs& cf)
 {
     static_assert(!(SPLIT && TGT), "the split-f16 kernel takes ready-made target features");
+    static_assert(!C2F || (TGT && !SPLIT), "the two-stage launch is the fp32 verify kernel");
     // The fp32 instances own their SIMDs: touching v255 makes the kernel's register allocation 256 per wave whatever the
     // allocator needs, so the two waves of a SIMD hold all 512 registers and no wave of another kernel can be resident beside
     // them -- which is what keeps hipcc's packed op_sel forms safe here (low_half, ahv_dual.h; tests/test_isa_hazard.py).
@@ -273,9 +292,55 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         wg_t_loop = __builtin_amdgcn_s_memrealtime();
         const unsigned long long wg_c_loop = __builtin_amdgcn_s_memtime();
 #endif
-        key_t best = kKeyEmpty;
-        const float* Rb = R + (long)b * r_batch_stride;
+        const float* Rb0 = R + (long)b * r_batch_stride;
         const int residue = xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        float Rstar[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // C2F stage 1: the coarse winner's rotation (uniform)
+        // hypothesis rotation from the nine values a wave has just broadcast: stage 1 composes R* d (compose_rotations_kernel)
+        auto hyp_rotation = [&](float (&Rm)[9], bool compose) {
+            if (C2F && compose) {
+                float d[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) d[i] = Rm[i];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        Rm[a * 3 + c] = Rstar[a * 3] * d[c] + Rstar[a * 3 + 1] * d[3 + c] + Rstar[a * 3 + 2] * d[6 + c];
+            }
+        };
+      for (int stage = 0; stage < (C2F ? 2 : 1); ++stage) {
+        // per-stage views (stage 1 exists in the C2F instance only)
+        const bool st1 = C2F && stage != 0;
+        const float* Rb = st1 ? cf.D : Rb0;
+        const long N_s = st1 ? cf.N2 : N, n_main_s = st1 ? cf.n_main2 : n_main, n_offset_s = st1 ? 0l : n_offset;
+        float* scores_s = st1 ? cf.scores2 : scores;
+        key_t* key_s = st1 ? cf.best_key2 : best_key;
+        if (st1) {
+            // Meeting point of the sample's gridDim.x workgroups: every atomicMax of stage 0 is ahead of the add (workgroup
+            // barrier, then a release add at agent scope); the poll is an acquire load at agent scope (sc1: the XCDs' L2s
+            // are not coherent with each other for plain loads).  All workgroups of the grid are resident -- at most one
+            // per CU by construction of the plan -- so the wait ends; if something else holds CUs for a second it gives up.
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(cf.sync + 2 * b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned polls = 0;
+                while (__hip_atomic_load(cf.sync + 2 * b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++polls > kC2fSpinLimit) {
+                        __hip_atomic_fetch_or(cf.sync + 2 * B, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const key_t kc = __hip_atomic_load(best_key + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long idx = key_index(kc) - n_offset;
+            idx = (kc == kKeyEmpty || idx < 0 || idx >= N) ? 0 : idx;  // as compose_rotations_kernel: stay in bounds
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                Rstar[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Rb0[idx * 9 + i])));
+        }
+        key_t best = kKeyEmpty;
         // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): a partial last round of the persistent
         // grid spreads over ALL CUs with few waves each instead of filling some CUs completely and leaving the rest idle.
         // The deal inside a workgroup is STATIC.  The older wave of a SIMD issues first and finishes its share ~110 us before
@@ -289,16 +354,17 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
         // with the LDS and returns out of order, so the first LDS wait behind an s_load has to wait for the s_load
         // too -- a first-touch read of R from HBM (~2 us) in front of every hypothesis' first gather step.
         const int rl = lane < 9 ? lane : 8;
-        float Rn = h < n_main ? Rb[h * 9 + rl] : 0.0f;  // nothing of R is touched when this wave has no hypothesis (N = 0: R may be null)
+        float Rn = h < n_main_s ? Rb[h * 9 + rl] : 0.0f;  // nothing of R is touched when this wave has no hypothesis (N = 0: R may be null)
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-        for (; h < n_main; h += hstep) {
+        for (; h < n_main_s; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rn), i));
+            hyp_rotation(Rm, st1);
             {
-                const long hn = (h + hstep < n_main) ? h + hstep : h;
+                const long hn = (h + hstep < n_main_s) ? h + hstep : h;
                 Rn = Rb[hn * 9 + rl];
             }
             f32x4 acc[2][4];
@@ -380,8 +446,8 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                         tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
                 s = hyp_score_rs<kFp32LowHalf>(v, tg, lane);
             }
-            if (scores != nullptr && lane == 0) scores[(long)b * N + h] = s;
-            const key_t key = pack_key(s, (unsigned)(n_offset + h));
+            if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h] = s;
+            const key_t key = pack_key(s, (unsigned)(n_offset_s + h));
             best = key > best ? key : best;
             AHV_TS(10)
 #ifdef AHV_STAMPS
@@ -395,15 +461,16 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             // rounds; member 0 emits the score of round r after the arrive point of round r + 1 (or of the flush below),
             // where the four partial means of round r are known to be in place.
             const long tstep = 2l * gridDim.x;
-            long ht = n_main + (long)team * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
-            if (ht < N) {
+            long ht = n_main_s + (long)team * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+            if (ht < N_s) {
                 long h_prev = -1;
                 float Rt = Rb[ht * 9 + rl];  // (not requested ahead of the main loop: a register across it costs more than this wait)
-                for (; ht < N; ht += tstep) {
+                for (; ht < N_s; ht += tstep) {
                     float Rm[9];
 #pragma unroll
                     for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rt), i));
-                    if (ht + tstep < N) Rt = Rb[(ht + tstep) * 9 + rl];
+                    hyp_rotation(Rm, st1);
+                    if (ht + tstep < N_s) Rt = Rb[(ht + tstep) * 9 + rl];
                     GatherHyp gh;
                     gather_hyp(gh, Rm, glane);
                     HatState st;
@@ -419,8 +486,8 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                     if (member == 0 && h_prev >= 0) {  // behind the arrive point of this round: last round's partials are complete
                         const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
                         const float sc = ((pp[0] + pp[1]) + (pp[2] + pp[3])) * (1.0f / 64.0f);
-                        if (scores != nullptr && lane == 0) scores[(long)b * N + h_prev] = sc;
-                        const key_t key = pack_key(sc, (unsigned)(n_offset + h_prev));
+                        if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h_prev] = sc;
+                        const key_t key = pack_key(sc, (unsigned)(n_offset_s + h_prev));
                         best = key > best ? key : best;
                     }
                     tg_wait();
@@ -447,22 +514,52 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                 if (member == 0) {
                     const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
                     const float sc = ((pp[0] + pp[1]) + (pp[2] + pp[3])) * (1.0f / 64.0f);
-                    if (scores != nullptr && lane == 0) scores[(long)b * N + h_prev] = sc;
-                    const key_t key = pack_key(sc, (unsigned)(n_offset + h_prev));
+                    if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h_prev] = sc;
+                    const key_t key = pack_key(sc, (unsigned)(n_offset_s + h_prev));
                     best = key > best ? key : best;
                 }
                 team_signal(&lds_team.done[team], lane);  // keeps arrive and done in step: one of each per meeting point
                 ++team_rounds;
             }
         }
-        ++samples_done;
 #ifdef AHV_STAMPS
         if (lane == 0) {
             const int gw = (blockIdx.x * 8 + wave) & 2047;
             for (int i = 0; i < 11; ++i) g_stamps[gw * 16 + i] = tsum[i];
         }
 #endif
-        if (best_key != nullptr && lane == 0 && best != kKeyEmpty) atomicMax(best_key + b, best);
+        if (key_s != nullptr && lane == 0 && best != kKeyEmpty) atomicMax(key_s + b, best);
+      }  // stage
+        ++samples_done;
+        if constexpr (C2F) {
+            // The workgroup that finishes the sample last decodes both keys: what select_rotation_kernel did, twice.
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned before = __hip_atomic_fetch_add(cf.sync + 2 * b + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (before == gridDim.x - 1) {
+                    const key_t kc = __hip_atomic_load(best_key + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const key_t kf = __hip_atomic_load(cf.best_key2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cf.coarse_score) cf.coarse_score[b] = (kc == kKeyEmpty) ? -INFINITY : key_score(kc);
+                    if (cf.coarse_idx) cf.coarse_idx[b] = (kc == kKeyEmpty) ? -1l : key_index(kc);
+                    if (cf.fine_score) cf.fine_score[b] = (kf == kKeyEmpty) ? -INFINITY : key_score(kf);
+                    const long fi = (kf == kKeyEmpty) ? -1l : key_index(kf);
+                    if (cf.fine_idx) cf.fine_idx[b] = fi;
+                    if (cf.R_pred) {
+                        float Rm[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) Rm[i] = (fi >= 0 && fi < cf.N2) ? cf.D[fi * 9 + i] : 0.0f;
+                        if (fi >= 0 && fi < cf.N2) hyp_rotation(Rm, true);
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) cf.R_pred[b * 9 + i] = Rm[i];
+                    }
+                    // keys and counters back empty for the next launch (everybody is past the meeting point: they all counted)
+                    __hip_atomic_store(best_key + b, kKeyEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cf.best_key2 + b, kKeyEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cf.sync + 2 * b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cf.sync + 2 * b + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
 #ifdef AHV_STAMPS
         __syncthreads();
         if (tid == 0) {
@@ -486,6 +583,28 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
             o[3] = __builtin_amdgcn_s_memrealtime();
         }
     }
+}
+
+template <bool SPLIT, bool TGT>
+__global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
+    long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int B, long N, long n_main, float* __restrict__ scores,
+    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, unsigned long long* __restrict__ clk)
+{
+    score_hypotheses_body<SPLIT, TGT, false>(vol_src, tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, n_main, scores, best_key,
+                                             feat_tgt_out, clk, C2fArgs{});
+}
+
+// the two-stage launch (C2fArgs above): `tgt` is the target volume, R the coarse set
+__global__ __launch_bounds__(kDualThreads, 2) void coarse_to_fine_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
+    long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int B, long N, long n_main, float* __restrict__ scores,
+    key_t* __restrict__ best_key, float* __restrict__ feat_tgt_out, C2fArgs cf)
+{
+    score_hypotheses_body<false, true, true>(vol_src, tgt, R, r_batch_stride, n_offset, W1, W2, b2, B, N, n_main, scores, best_key,
+                                             feat_tgt_out, nullptr, cf);
 }
 
 __global__ void unpack_best_kernel(const key_t* __restrict__ best_key, int B, float* __restrict__ best_score,
@@ -555,6 +674,34 @@ hipError_t launch_score_hypotheses(const ScoreLaunch& a, hipStream_t stream)
                            (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
                            key, a.feat_tgt_out, clk);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_coarse_to_fine(const CoarseToFineLaunch& a, hipStream_t stream)
+{
+    const ScoreLaunch& c = a.coarse;
+    const bool teams = !c.no_teams;
+    const ScorePlan p = plan_score_launch(c.B, c.N, c.num_cu, c.spare_cu, teams);
+    // stage 1 runs on the SAME grid: its remainder rule with stage 0's gx
+    const int64_t slots = 8 * (int64_t)p.gx, full2 = a.N2 / slots, rem2 = a.N2 - full2 * slots;
+    const int64_t n_main2 = (teams && rem2 > 0 && rem2 <= 2 * (int64_t)p.gx && (full2 == 0 || full2 >= 4)) ? full2 * slots : a.N2;
+    // every workgroup must be resident for the meeting point: at most one per CU (159.5 KiB of LDS each)
+    if ((int64_t)p.gx * p.gy > c.num_cu) return hipErrorInvalidConfiguration;
+    C2fArgs cf;
+    cf.D = a.D;
+    cf.N2 = (long)a.N2;
+    cf.n_main2 = (long)n_main2;
+    cf.best_key2 = reinterpret_cast<key_t*>(a.best_key2);
+    cf.scores2 = a.scores2;
+    cf.sync = a.sync;
+    cf.R_pred = a.R_pred;
+    cf.fine_score = a.fine_score;
+    cf.coarse_score = a.coarse_score;
+    cf.fine_idx = reinterpret_cast<long*>(a.fine_idx);
+    cf.coarse_idx = reinterpret_cast<long*>(a.coarse_idx);
+    hipLaunchKernelGGL(coarse_to_fine_kernel, dim3(p.gx, p.gy), dim3(kDualThreads), 0, stream, c.vol_src, c.tgt, c.R,
+                       (long)c.r_batch_stride, (long)c.n_offset, c.W1, c.W2, c.b2, c.B, (long)c.N, (long)p.n_main, c.scores,
+                       reinterpret_cast<key_t*>(c.best_key), c.feat_tgt_out, cf);
     return hipGetLastError();
 }
 

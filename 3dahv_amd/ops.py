@@ -466,6 +466,73 @@ def compose_rotations(best_key: torch.Tensor, R: torch.Tensor, D: torch.Tensor, 
     return out
 
 
+class CoarseToFineState:
+    """Scratch of ``coarse_to_fine`` for B samples on one device: the two packed keys (EMPTY between steps), the meeting
+    point's counters (zero between steps) and the launch's error word.  One per caller and stream; reusing it keeps the
+    step free of clearing launches."""
+
+    def __init__(self, B: int, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("3dahv_amd ops run on the GPU only (no CPU fallback); got device %s" % dev)
+        self.B = B
+        self.keys = torch.full((2, B), _lib.AHV_KEY_EMPTY, dtype=torch.int64, device=dev)
+        self.sync = torch.zeros((2 * B + 1,), dtype=torch.int32, device=dev)
+
+    def gave_up(self) -> bool:
+        """True if a workgroup of some step abandoned the meeting point (host sync; the flag is sticky)."""
+        return bool(self.sync[-1].item() != 0)
+
+
+@torch.no_grad()
+def coarse_to_fine(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, D: torch.Tensor, W1: torch.Tensor,
+                   W2: torch.Tensor, b2: torch.Tensor, state: CoarseToFineState | None = None, want_scores: bool = False,
+                   want_feat_tgt: bool = False, no_teams: bool = False, spare_cus: int = 0, out: dict | None = None) -> dict:
+    """BASELINE.json configs[4] on one rank as ONE launch (``ahv_coarse_to_fine_f32``): the verify step on the coarse set
+    ``R (N,3,3) or (B,N,3,3)``, then -- behind a device-wide meeting point -- on the refinements ``R* @ D[n]`` of its winner,
+    ``D (N2,3,3)``; the last workgroup decodes both keys.  Returns a dict with ``fine_score, fine_idx`` (index into D),
+    ``R_pred (B,3,3)``, ``coarse_score, coarse_idx`` and, on request, ``coarse_scores (B,N)``, ``fine_scores (B,N2)``,
+    ``feat_tgt (B,32,64)``.  ``out``: a dict from an earlier call whose tensors are written again (static buffers for
+    graph capture).  With the hypothesis sets sharded over ranks use ``refine.CoarseToFine`` (five launches, two
+    all-reduces).  Inference only."""
+    _refuse_grad("coarse_to_fine", vol_src, vol_tgt, W1, W2, b2)
+    if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL or tuple(vol_tgt.shape) != tuple(vol_src.shape):
+        raise RuntimeError("vol_src and vol_tgt must be (B,16,8,8,8), got %s and %s" % (tuple(vol_src.shape), tuple(vol_tgt.shape)))
+    B = vol_src.shape[0]
+    dev = _need_gpu(vol_src, vol_tgt, R, D, W1, W2, b2)
+    N, rstride = _rot_layout(R, B)
+    if D.dim() != 3 or tuple(D.shape[1:]) != (3, 3):
+        raise RuntimeError("D must be (N2,3,3)")
+    N2 = D.shape[0]
+    W1, W2, b2 = _head(W1, W2, b2)
+    if state is None:
+        state = CoarseToFineState(B, dev)
+    elif state.B != B or state.keys.device != dev:
+        raise RuntimeError("the CoarseToFineState was made for B = %d on %s" % (state.B, state.keys.device))
+    vs, vt, Rc, Dc = (t.detach().contiguous() for t in (vol_src, vol_tgt, R, D))
+    o = out if out is not None else {}
+    def buf(name, shape, dtype=torch.float32, wanted=True):
+        if not wanted:
+            return None
+        if name not in o:
+            o[name] = torch.empty(shape, dtype=dtype, device=dev)
+        return o[name]
+    sc = buf("coarse_scores", (B, N), wanted=want_scores)
+    sf = buf("fine_scores", (B, N2), wanted=want_scores)
+    ft = buf("feat_tgt", (B, 32, 64), wanted=want_feat_tgt)
+    rp, fs, cs = buf("R_pred", (B, 3, 3)), buf("fine_score", (B,)), buf("coarse_score", (B,))
+    fi, ci = buf("fine_idx", (B,), torch.int64), buf("coarse_idx", (B,), torch.int64)
+    p = lambda t: 0 if t is None else t.data_ptr()
+    if not 0 <= spare_cus <= 255:
+        raise RuntimeError("spare_cus must be in [0, 255]")
+    flags = (_lib.AHV_SCORE_NO_TEAMS if no_teams else 0) | (spare_cus << _lib.AHV_SCORE_SPARE_CUS_SHIFT)
+    _call(dev, "ahv_coarse_to_fine_f32", vs.data_ptr(), vt.data_ptr(), Rc.data_ptr(), rstride, N, Dc.data_ptr(), N2,
+          W1.data_ptr(), W2.data_ptr(), b2.data_ptr(), B, p(sc), p(sf), state.keys.data_ptr(), state.sync.data_ptr(), p(ft),
+          rp.data_ptr(), fs.data_ptr(), fi.data_ptr(), cs.data_ptr(), ci.data_ptr(), flags)
+    o["state"] = state
+    return o
+
+
 @torch.no_grad()
 def so3_grid(n_total: int, device, offset: int = 0, n: int | None = None) -> torch.Tensor:
     """Rows ``[offset, offset + n)`` of the deterministic ``n_total``-point super-Fibonacci SO(3) grid, generated on

@@ -7,6 +7,8 @@ small rotations (``rotations.refine_rotations(I, N2, max_angle)``; D[0] = I, so 
 score below stage 1).  Everything between the two stages stays on the device: the winner index is
 decoded from the packed key by ``ahv_compose_rotations_f32``; no host round trip, so the whole step
 (2 fused scorer launches -- the first builds the target features in-launch --, compose, 2 selects) replays from a graph.
+On one rank the step also exists as ONE launch (``fused=True``: ``ahv_coarse_to_fine_f32``, the workgroups meet at a
+device-wide counter between the stages).
 
 Multi-rank (one process per GPU): both hypothesis sets are sharded contiguously (``dist.shard_range``);
 each stage ends in the 8*B-byte packed-key all-reduce(max) (int64 MAX on the key as the kernel packs it) -- two collectives per
@@ -35,13 +37,20 @@ class CoarseToFine:
 
     One step = FIVE launches: the coarse stage as one ``verify_pair`` launch (the target features are built inside it and
     kept for the fine stage), ``compose_rotations``, the fine stage, and one ``select_rotation`` per stage, each of which
-    also hands its key back empty for the next step (no clearing launches).  ``no_teams`` makes every score independent
-    of how the hypothesis sets are split over ranks, bit for bit (``ops.score_hypotheses``)."""
+    also hands its key back empty for the next step (no clearing launches).
+    ``fused=True`` (one rank, no collectives, the HIP backend): the step is ONE launch, ``ops.coarse_to_fine`` -- both
+    stages, a device-wide meeting point between them and the decoding of both keys inside ``ahv_coarse_to_fine_f32``.
+    Same results bit for bit; measured 1.5 % faster (189.7 against 192.6 us for 10 000 + 1 000 hypotheses: the queue
+    already hides the launches it removes), and its meeting point assumes nothing else holds compute units for long --
+    hence opt-in.
+    ``no_teams`` makes every score independent of how the hypothesis sets are split over ranks, bit for bit
+    (``ops.score_hypotheses``)."""
 
     def __init__(self, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, R_coarse: torch.Tensor,
                  D: Optional[torch.Tensor] = None, n_fine: int = 1000, max_angle_deg: float = 10.0,
                  batch: int = 1, use_graph: bool = True, group=None, seed: int = 0, backend=None,
-                 want_scores: bool = False, force_collectives: bool = False, no_teams: bool = False):
+                 want_scores: bool = False, force_collectives: bool = False, no_teams: bool = False,
+                 fused: Optional[bool] = None):
         dev = R_coarse.device
         self.ops = ops if backend is None else backend
         self.W1, self.W2, self.b2 = W1, W2, b2
@@ -68,6 +77,12 @@ class CoarseToFine:
         self._R_fine = torch.empty((batch, self.D.shape[0], 3, 3), dtype=torch.float32, device=dev)
         self._graph = None
         self._static = None
+        can_fuse = backend is None and not self.collectives and self.world == 1 and dev.type == "cuda"
+        if fused and not can_fuse:
+            raise RuntimeError("the one-launch step needs one rank, no collectives and the HIP backend")
+        self.fused = bool(fused)
+        self._fused_state = ops.CoarseToFineState(batch, dev) if self.fused else None
+        self._fused_out = {}
 
     def _merge(self, key):
         if self.collectives:  # world > 1, or forced on a 1-rank group: same call, same captured node
@@ -87,6 +102,12 @@ class CoarseToFine:
     # ---- the step, written once; runs eagerly or under capture
     def _step(self, vol_src, vol_tgt):
         o = self.ops
+        if self.fused:
+            r = o.coarse_to_fine(vol_src, vol_tgt, self.R_coarse, self.D, self.W1, self.W2, self.b2, state=self._fused_state,
+                                 want_scores=self.want_scores, no_teams=self.no_teams, out=self._fused_out)
+            # (the refinement set is never materialised here: R_fine stays None)
+            self.last = {"coarse_scores": r.get("coarse_scores"), "fine_scores": r.get("fine_scores"), "R_fine": None}
+            return r["fine_score"], r["fine_idx"], r["R_pred"], r["coarse_score"], r["coarse_idx"]
         key1, key2 = self._keys
         kw = {"no_teams": True} if self.no_teams else {}
         Rc = self.R_coarse[self.c_lo:self.c_hi]

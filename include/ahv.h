@@ -100,7 +100,7 @@ extern "C" {
                                  * then needs no launch of its own to clear the key */
 
 /* ABI version (major<<16 | minor).  2.0: signed-order keys (above), flags argument of ahv_select_rotation_f32,
- * ahv_reset_best, ahv_verify_pair_f32. */
+ * ahv_reset_best, ahv_verify_pair_f32.  2.1: ahv_coarse_to_fine_f32. */
 int ahv_abi_version(void);
 
 /* Thread-local text of the last error returned on this thread ("" if none). */
@@ -241,6 +241,31 @@ int ahv_argmax_f32(const float* scores, int B, int64_t N, int64_t n_offset, int6
 int ahv_select_rotation_f32(int64_t* best_key, const float* R, int64_t r_batch_stride, int64_t n_offset,
                             int64_t N, int B, float* R_out, float* best_score, int64_t* best_idx, unsigned flags,
                             void* stream);
+
+/*
+ * The whole coarse-to-fine step of BASELINE.json configs[4] in ONE launch (one rank; with the hypothesis sets sharded
+ * over ranks the stages are separate launches with a key all-reduce between them: ahv_verify_pair_f32,
+ * ahv_compose_rotations_f32, ahv_score_hypotheses_f32, ahv_select_rotation_f32):
+ *   stage 0  ahv_verify_pair_f32 on the coarse set R [N] (target features built in the launch);
+ *   the workgroups meet at a device-wide counter, every one reads the winner R* = R[idx*];
+ *   stage 1  scores the refinement set R* D[n], n < N2, composed per hypothesis as ahv_compose_rotations_f32 would;
+ *   the workgroup that finishes last decodes both keys as ahv_select_rotation_f32 would.
+ *  R              [N][3][3] (r_batch_stride 0) or [B][N][3][3];  D [N2][3][3]
+ *  scores_coarse  [B][N] or NULL;  scores_fine [B][N2] or NULL;  feat_tgt_out [B][32][64] or NULL
+ *  keys           [2][B] int64 scratch, AHV_KEY_EMPTY on entry; handed back AHV_KEY_EMPTY
+ *  sync           [2 B + 1] uint32 scratch, zero on entry; words 0 .. 2B-1 are handed back zero.  Word 2B is an error
+ *                 flag the launch sets (and nobody clears) if a workgroup gave the meeting point up after ~1 s -- something
+ *                 else held compute units for that long; the outputs of that step are then not to be used.
+ *  R_pred         [B][3][3] = R* D[n*];  fine_score / fine_idx (index into D) / coarse_score / coarse_idx [B]; any may be NULL
+ *  flags          AHV_SCORE_NO_TEAMS, AHV_SCORE_SPARE_CUS(k)
+ * The grid is one workgroup per compute unit at most, so all of it is resident and the meeting point is reached;
+ * two such launches on one device at a time (two processes) may make each other wait.  Graph-capturable (a plain launch).
+ */
+int ahv_coarse_to_fine_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride, int64_t N,
+                           const float* D, int64_t N2, const float* W1, const float* W2, const float* b2, int B,
+                           float* scores_coarse, float* scores_fine, int64_t* keys, uint32_t* sync, float* feat_tgt_out,
+                           float* R_pred, float* fine_score, int64_t* fine_idx, float* coarse_score, int64_t* coarse_idx,
+                           unsigned flags, void* stream);
 
 /*
  * Coarse-to-fine refinement set, composed on the device (no host round trip, graph-capturable):

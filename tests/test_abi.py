@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib, ahv):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.ahv_abi_version() == (2 << 16)
+    assert lib.ahv_abi_version() == (2 << 16) | 1  # 2.1: ahv_coarse_to_fine_f32
     assert isinstance(lib.ahv_last_error(), bytes)
 
 
@@ -64,6 +64,21 @@ def test_argument_validation_needs_no_gpu(lib, ahv):
     assert bw(1, 1, 1, 0, 1, 1, 1, 1, 10, 1, 20, 1 << 30, 1, 1, 1, 1, 1, None) == -1 and b"aligned" in lib.ahv_last_error()
     assert lib.ahv_so3_grid_f32(10, 8, 5, 1, None) == -1 and b"so3_grid" in lib.ahv_last_error()
     assert lib.ahv_so3_grid_f32(10, 0, 0, None, None) == 0
+    # the one-launch coarse-to-fine step: argument order (vol_src, vol_tgt, R, r_stride, N, D, N2, W1, W2, b2, B, scores x 2,
+    # keys, sync, feat_tgt_out, R_pred, fine score / idx, coarse score / idx, flags, stream)
+    c2f = lib.ahv_coarse_to_fine_f32
+    ok = [1, 1, 1, 0, 10, 1, 4, 1, 1, 1, 2, None, None, 1, 1, None, 1, 1, 1, 1, 1, 0, None]
+    def call(**kw):
+        a = list(ok)
+        for k, v in kw.items():
+            a[int(k[1:])] = v
+        return c2f(*a)
+    assert call(_13=None) == -1 and b"keys and sync" in lib.ahv_last_error()
+    assert call(_5=None) == -1 and b"null input" in lib.ahv_last_error()
+    assert call(_6=0) == -1 and b"empty hypothesis set" in lib.ahv_last_error()
+    assert call(_3=5) == -1 and b"r_batch_stride" in lib.ahv_last_error()
+    assert call(_21=ahv._lib.AHV_SCORE_SPLIT_F16) == -1 and b"flags" in lib.ahv_last_error()
+    assert call(_10=0) == 0   # B = 0: nothing to do
 
 
 def test_ops_refuse_cpu_tensors(ahv):

@@ -59,6 +59,81 @@ def test_coarse_to_fine_matches_two_stage_reference(ahv, setup, use_graph):
         assert torch.allclose(R_pred, fine[torch.arange(3), i2], atol=1e-6)
 
 
+# ---- the one-launch step (ahv_coarse_to_fine_f32) against the five-launch one ------------------------------------
+@pytest.mark.parametrize("B,n_coarse,n_fine", [(3, 2000, 300), (1, 10_000, 1000), (2, 4096, 2048), (1, 7, 5)])
+def test_one_launch_step_equals_the_five_launch_step(ahv, setup, B, n_coarse, n_fine):
+    """Same scores bit for bit (every hypothesis by one wave: no_teams), same winners, same R_pred; the keys and the
+    meeting point's counters come back empty, so the same state serves step after step."""
+    dev, vs3, vt3, W1, W2, b2 = setup
+    ops = ahv.ops
+    vs, vt = vs3[:B].contiguous(), vt3[:B].contiguous()
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(n_coarse, 17)).to(dev)
+    five = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=n_fine, max_angle_deg=10.0, batch=B, use_graph=False,
+                                   want_scores=True, no_teams=True)
+    assert not five.fused
+    state = ops.CoarseToFineState(B, dev)
+    out = {}
+    for rep in range(3):
+        a, b = (vs, vt) if rep != 1 else (vt, vs)
+        score, idx, R_pred, c_score, c_idx = [t.clone() for t in five(a, b)]
+        r = ops.coarse_to_fine(a, b, R, five.D, W1, W2, b2, state=state, want_scores=True, want_feat_tgt=True, no_teams=True, out=out)
+        assert torch.equal(r["coarse_scores"], five.last["coarse_scores"])
+        assert torch.equal(r["fine_scores"], five.last["fine_scores"])
+        assert torch.equal(r["coarse_idx"], c_idx) and torch.equal(r["coarse_score"], c_score)
+        assert torch.equal(r["fine_idx"], idx) and torch.equal(r["fine_score"], score)
+        assert torch.equal(r["R_pred"], R_pred)
+        assert torch.equal(r["feat_tgt"], ops.verify_pair(a, b, R[:1], W1, W2, b2, want_feat_tgt=True)[2])
+        assert torch.all(state.keys == ahv._lib.AHV_KEY_EMPTY) and torch.count_nonzero(state.sync) == 0
+    assert not state.gave_up()
+
+
+def test_one_launch_step_with_team_tails_and_per_sample_sets(ahv, setup):
+    """Default plan (team tails where the plan takes them) and a (B,N,3,3) coarse set: winners and R_pred as the
+    five-launch step finds them, scores to rounding."""
+    dev, vs, vt, W1, W2, b2 = setup
+    ops = ahv.ops
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(3 * 8300, 23).reshape(3, 8300, 3, 3)).to(dev)
+    five = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=300, batch=3, use_graph=False, want_scores=True)
+    score, idx, R_pred, c_score, c_idx = [t.clone() for t in five(vs, vt)]
+    r = ops.coarse_to_fine(vs, vt, R, five.D, W1, W2, b2, want_scores=True)
+    assert torch.equal(r["coarse_idx"], c_idx) and torch.equal(r["fine_idx"], idx)
+    assert torch.allclose(r["coarse_scores"], five.last["coarse_scores"], atol=5e-7, rtol=0)
+    assert torch.allclose(r["fine_scores"], five.last["fine_scores"], atol=5e-7, rtol=0)
+    assert torch.allclose(r["fine_score"], score, atol=5e-7, rtol=0) and torch.equal(r["R_pred"], R_pred)
+    assert not r["state"].gave_up()
+
+
+def test_one_launch_step_through_CoarseToFine_eager_and_from_a_graph(ahv, setup):
+    dev, vs, vt, W1, W2, b2 = setup
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(5000, 29)).to(dev)
+    eager = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=500, batch=3, use_graph=False, fused=True)
+    graph = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=500, batch=3, use_graph=True, fused=True)
+    five = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=500, batch=3, use_graph=False)
+    assert eager.fused and graph.fused and graph.use_graph and not five.fused
+    for rep in range(4):
+        a, b = (vs, vt) if rep % 2 == 0 else (vt, vs)
+        e = [t.clone() for t in eager(a, b)]
+        g = [t.clone() for t in graph(a, b)]
+        f = [t.clone() for t in five(a, b)]
+        for x, y, z in zip(e, g, f):
+            assert torch.equal(x, y)
+            assert torch.equal(x, z) if x.dtype == torch.int64 else torch.allclose(x, z, atol=5e-7, rtol=0)
+    assert not eager._fused_state.gave_up() and not graph._fused_state.gave_up()
+
+
+def test_one_launch_step_argument_checks(ahv, setup):
+    dev, vs, vt, W1, W2, b2 = setup
+    ops = ahv.ops
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(64, 1)).to(dev)
+    D = R[:8].contiguous()
+    with pytest.raises(RuntimeError, match="made for B"):
+        ops.coarse_to_fine(vs, vt, R, D, W1, W2, b2, state=ops.CoarseToFineState(2, dev))
+    with pytest.raises(RuntimeError, match="empty hypothesis set"):
+        ops.coarse_to_fine(vs, vt, R, D[:0], W1, W2, b2)
+    with pytest.raises(RuntimeError, match="one rank"):
+        ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=8, batch=3, fused=True, backend=ops)
+
+
 # ---- BASELINE.json configs[4] at full size: 10 000 coarse + 1 000 refined, hipGraph, against the ORACLE ----------
 @pytest.mark.parametrize("B", [1, 3])
 def test_configs4_full_size_graph_vs_oracle(ahv, oracle, setup, B):

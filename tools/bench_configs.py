@@ -74,16 +74,18 @@ if not only or "5" in only:
     # configs[4]: coarse 10k + 1k refined hypotheses, the whole verify step replayed from one hipGraph
     vs, vt = vol[0, :1], vol[1, :1]
     R = torch.from_numpy(ahv.rotations.haar_rotations_np(10_000, 11)).to(dev)
-    for use_graph in (False, True):
-        c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, max_angle_deg=10.0, batch=1, use_graph=use_graph)
+    # one rank: the step is ONE launch (ahv_coarse_to_fine_f32); fused=False = the five launches a sharded step is made of
+    for fused, use_graph in ((True, False), (True, True), (False, False), (False, True)):
+        c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, max_angle_deg=10.0, batch=1, use_graph=use_graph, fused=fused)
         ms = timeit(lambda: c2f(vs, vt), 200, warm=5)
         out = c2f(vs, vt)
         # the producer writes straight into the step's static inputs: no staging copies in front of the replay
         c2f.buffers[0].copy_(vs)
         c2f.buffers[1].copy_(vt)
         ms_in_place = timeit(lambda: c2f(), 200, warm=5)
+        assert not (fused and c2f._fused_state.gave_up())
         print(json.dumps({"config": "5 coarse10k+fine1k", "graph": use_graph, "us_per_step": ms * 1e3,
-                          "us_per_step_inputs_in_place": ms_in_place * 1e3, "launches_per_step": 5,
+                          "us_per_step_inputs_in_place": ms_in_place * 1e3, "launches_per_step": 1 if fused else 5,
                           "hyp_per_s": 11_000 / ms_in_place * 1e3, "fine_score": out[0].item(), "coarse_score": out[3].item()}))
 
 if not only or "shard" in only:
