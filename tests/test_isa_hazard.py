@@ -64,8 +64,8 @@ def test_xdl_kernel_has_no_cross_half_packed_f32(tmp_path):
     bad = [l.strip() for l in packed if "op_sel:[" in l]
     assert not bad, "low lane reads a high half next to XDL MFMAs:\n" + "\n".join(bad[:10])
     # and the fp32 kernels of the same file (target features given / built in the launch) have no XDL MFMA
-    fp32 = [b for n, b in fns.items() if "score_hypotheses_dual_kernelILb0" in n]
-    assert len(fp32) == 2 and not any(XDL.search(b) for b in fp32)
+    fp32 = [b for n, b in fns.items() if "score_hypotheses_dual_kernelILb0" in n or "coarse_to_fine_kernel" in n]
+    assert len(fp32) == 3 and not any(XDL.search(b) for b in fp32)
 
 
 def test_scorers_use_no_scratch_memory(tmp_path):
@@ -74,18 +74,18 @@ def test_scorers_use_no_scratch_memory(tmp_path):
     and parked in scratch across the hypothesis loop -- megabytes of spill stores per launch in WRITE_SIZE), and in
     particular no scratch access inside a hypothesis loop (the innermost loop with MFMAs and > 2 000 instructions)."""
     asm = _isa(os.path.join(CSRC, "ahv_score.hip"), tmp_path)
-    meta = re.findall(r"\.name:\s+(\S*score_hypotheses_dual_kernel\S*)\s+\.private_segment_fixed_size:\s+(\d+).*?"
+    meta = re.findall(r"\.name:\s+(\S*(?:score_hypotheses_dual_kernel|coarse_to_fine_kernel)\S*)\s+\.private_segment_fixed_size:\s+(\d+).*?"
                       r"\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", asm, flags=re.S)
-    assert len(meta) == 3, meta
+    assert len(meta) == 4, meta  # three instances of the scorer + the two-stage launch (the fp32 verify kernel's body)
     for name, private, vgprs, spills in meta:
         assert int(private) == 0 and int(spills) == 0 and int(vgprs) <= 256, (name, private, vgprs, spills)
         # occupancy argument of low_half (ahv_dual.h): two waves per SIMD (launch bounds), vector registers handed out in
         # granules of 8 -- with more than 248 per wave the pair owns all 512 registers of the SIMD and no wave of another
         # kernel (an XDL MFMA kernel in particular) can be resident beside an fp32 scorer
-        if "ILb0E" in name:
+        if "ILb0E" in name or "coarse_to_fine_kernel" in name:
             assert int(vgprs) > 248, (name, vgprs)
-    fns = {n: b for n, b in _functions(asm).items() if "score_hypotheses_dual_kernel" in n}
-    assert len(fns) == 3
+    fns = {n: b for n, b in _functions(asm).items() if "score_hypotheses_dual_kernel" in n or "coarse_to_fine_kernel" in n}
+    assert len(fns) == 4
     for name, body in fns.items():
         lines = body.splitlines()
         labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\w+):", l)] if m}
