@@ -73,6 +73,12 @@ SIGNATURES["ahv_transformer_workspace_bytes"] = (ctypes.c_size_t, [_int])
 SIGNATURES["ahv_transformer_blocks_f32"] = (_int, [ctypes.POINTER(BlockWeights), _int, _vp, _vp, _int, _vp,
                                                    ctypes.c_size_t, _vp])
 
+# measurement / developer entry points (include/ahv_diag.h): not part of the drop-in boundary
+DIAG_SIGNATURES = {
+    "ahv_score_hypotheses_clocked_f32": SIGNATURES.pop("ahv_score_hypotheses_clocked_f32"),
+    "ahv_diag_score_plan": (_int, [_int, _i64, _u32, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_i64)]),
+}
+
 _lib = None
 
 
@@ -103,7 +109,7 @@ def load():
             "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C 3dahv_amd/csrc`."
         )
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

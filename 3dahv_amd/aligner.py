@@ -593,5 +593,10 @@ class Feature_Aligner(nn.Module):
     def score_hypotheses(self, img_feat_src, img_feat_tgt, proposals, n_offset: int = 0, want_scores: bool = True):
         """forward_3d2d(tgt) + rotate_volume + forward_3d2d + score + running arg-max for every proposal in ONE launch
         (test_co3d.py:137-145, ``ops.verify_pair``).  Returns (scores (B,N) | None, packed best keys (B,))."""
-        return ops.verify_pair(img_feat_src, img_feat_tgt, proposals, *self.head_weights(), n_offset=n_offset,
-                               want_scores=want_scores)
+        head = self.head_weights()
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (img_feat_src, img_feat_tgt) + tuple(head)):
+            # training-shaped call: the one-launch step has no autograd edge; the differentiable pair of ops has
+            # (forward_3d2d and the fused scorer both carry the HIP backward) -- nothing is detached silently
+            feat_tgt = ops.forward_3d2d(img_feat_tgt, *head)
+            return ops.score_hypotheses(img_feat_src, feat_tgt, proposals, *head, n_offset=n_offset, want_scores=True)
+        return ops.verify_pair(img_feat_src, img_feat_tgt, proposals, *head, n_offset=n_offset, want_scores=want_scores)

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/ahv.h"
+#include "../../include/ahv_diag.h"
 #include "ahv_launch.h"
 
 namespace ahv {
@@ -159,6 +160,19 @@ int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt
     if (!clock_stamps) return fail(AHV_EINVAL, "score_clocked: null clock_stamps");
     return score_common("score_clocked", vol_src, feat_tgt, false, R, r_batch_stride, n_offset, W1, W2, b2, B, N, scores,
                         best_key, nullptr, flags, clock_stamps, stream);
+}
+
+int ahv_diag_score_plan(int B, int64_t N, unsigned flags, int* gx, int* gy, int64_t* n_main)
+{
+    if (B < 1 || N < 0) return fail(AHV_EINVAL, "score_plan: bad shape (B=%d, N=%lld)", B, (long long)N);
+    const int cu = cu_count();
+    if (cu < 0) return fail(AHV_EDEVICE, "no usable HIP device");
+    const bool teams = !(flags & AHV_SCORE_SPLIT_F16) && !(flags & AHV_SCORE_NO_TEAMS);
+    const ahv::ScorePlan p = ahv::plan_score_launch(B, N, cu, (int)((flags & AHV_SCORE_SPARE_CUS_MASK) >> AHV_SCORE_SPARE_CUS_SHIFT), teams);
+    if (gx) *gx = p.gx;
+    if (gy) *gy = p.gy;
+    if (n_main) *n_main = p.n_main;
+    return AHV_OK;
 }
 
 int ahv_verify_pair_f32(const float* vol_src, const float* vol_tgt, const float* R, int64_t r_batch_stride,

@@ -336,7 +336,8 @@ __device__ __forceinline__ void gemm2(f32x4 (&v)[2][4], const f32x4 (&acc)[2][4]
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float u = fmaxf(acc[m][t][r], 0.0f);
+                const float a = acc[m][t][r];
+                const float u = a < 0.0f ? 0.0f : a;  // F.relu: a NaN stays a NaN (v_max would drop it)
                 v[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][0], u, v[0][t], 0, 0, 0);
                 v[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[m][r][1], u, v[1][t], 0, 0, 0);
             }

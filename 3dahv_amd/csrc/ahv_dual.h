@@ -64,6 +64,47 @@ __device__ __forceinline__ void stage_w1_table(float* table, const float* __rest
     }
 }
 
+// The same in two halves, so that a kernel can issue the six loads ahead of other work and scatter them later
+// (16-byte-aligned W1 only).
+struct W1Regs {
+    f32x4 w[6];
+};
+
+__device__ __forceinline__ void w1_regs_load(W1Regs& r, const float* __restrict__ W1, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.w[k] = *reinterpret_cast<const f32x4*>(W1 + 4 * (tid + 512 * k));
+}
+
+__device__ __forceinline__ void w1_regs_store(float* table, const W1Regs& r, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = tid + 512 * k, o = i / 96, kk = 4 * (i - 96 * o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) table[w1_table_slot(o, kk + e)] = r.w[k][e];
+    }
+}
+
+// Source volume of one sample, split the same way: thread v < 512 owns voxel v -- its 16 channels are 16 coalesced
+// 4-byte loads (one per channel plane) and ONE 64-byte row of the channel-last image (four ds_write_b128).
+struct SrcRegs {
+    float x[16];
+};
+
+__device__ __forceinline__ void src_regs_load(SrcRegs& r, const float* __restrict__ vol, int tid)
+{
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r.x[c] = vol[c * 512 + tid];
+}
+
+__device__ __forceinline__ void src_regs_store(float* srcT, const SrcRegs& r, int tid)
+{
+    f32x4* row = reinterpret_cast<f32x4*>(srcT + ((tid >> 6) * kSrcPlaneRows + ((tid >> 3) & 7) * kSrcRowsY + (tid & 7)) * kSrcStride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[j] = f32x4{r.x[4 * j], r.x[4 * j + 1], r.x[4 * j + 2], r.x[4 * j + 3]};
+}
+
 struct DualFrags {
     float a2[2][4][2];  // GEMM2 [m][r][m2]: W2[16m2+row][16m + 4kq + r]
     f32x4 bias[2];      // [m2]: b2[16m2 + 4kq + r]
@@ -388,9 +429,14 @@ __device__ __forceinline__ void hat_voxel(HatVoxel& v, const float* srcT, const 
 }
 
 // the same with the quarter known only at run time (wave-uniform: ahv_team.h, one quarter per wave)
+// Same values as hat_voxel<Q> for Q = qf, bit for bit: quarter 0 takes the coordinates as they are (hat_voxel<0> does not
+// multiply: 0 * inf would differ), and fma(1, d, i) is the rounded sum d + i that hat_voxel<1> computes.
 __device__ __forceinline__ void hat_voxel_rt(HatVoxel& v, const float* srcT, const GatherHyp& h, int p, float qf)
 {
-    hat_voxel_at<kFp32LowHalf>(v, srcT, __builtin_elementwise_fma(f32x2{qf, qf}, h.dqxy, h.ixy[p]), fmaf(qf, h.dqz, h.izp[p]));
+    const f32x2 ixy = __builtin_elementwise_fma(f32x2{qf, qf}, h.dqxy, h.ixy[p]);
+    const float iz = fmaf(qf, h.dqz, h.izp[p]);
+    const bool q0 = qf == 0.0f;
+    hat_voxel_at<kFp32LowHalf>(v, srcT, f32x2{q0 ? h.ixy[p][0] : ixy[0], q0 ? h.ixy[p][1] : ixy[1]}, q0 ? h.izp[p] : iz);
 }
 
 // Quarter Q of the rotated volume into `buf`.  The two voxels of a lane (passes 0, 1) are blended as ONE stream
@@ -541,12 +587,12 @@ __device__ __forceinline__ void hat_body(HatState& st, float* buf, const GatherD
 }
 
 // the same into a LINEAR image X[c][voxel = a0*64 + b*8 + e] with ROW floats per channel plane (backward kernels)
-template <int ROW>
+template <int ROW, bool MIR = false>
 __device__ __forceinline__ void hat_body_linear(HatState& st, float* img, const GatherDst& dst)
 {
     f32x2 o[8];
-    const HatStoreF32<ROW> store = {{img + dst.o0, img + dst.o1}};
-    HatSteps<0, HatStoreF32<ROW>>::run(st, o, store);
+    const HatStoreF32<ROW> store = {{img + (MIR ? dst.m0 : dst.o0), img + (MIR ? dst.m1 : dst.o1)}};
+    HatSteps<0, HatStoreF32<ROW>, MIR>::run(st, o, store);
 }
 
 }  // namespace ahv

@@ -4,43 +4,100 @@
 // These are the HBM-bound siblings of the fused scorer (ahv_score.hip).
 #include "ahv_device.h"
 #include "ahv_dual.h"
+#include "ahv_exact.h"
 
 namespace ahv {
 
 // ---------------------------------------------------------------------------------
 // rotate_volume, fast path: volume (16,8,8,8) shared by all N hypotheses (the stride-0
-// expand of test_co3d.py:137).  Source image in LDS (40 KiB -> 4 workgroups per CU);
-// one wave per hypothesis, 8 passes of 64 consecutive voxels, so that each of the 16
-// channel stores of a pass writes one contiguous 256-B segment of out[n][c][:].
-// HBM: 36 B in + 32 KiB out per hypothesis -> write-bandwidth bound.
+// expand of test_co3d.py:137).  HBM: 36 B in + 32 KiB out per hypothesis -> write-bandwidth bound,
+// provided the kernel needs less than the ~3 500 cycles per hypothesis and CU that 5.7 TB/s leave it.
+// Rounds 1-4 (tri_coef + tri_blend per voxel, 4-byte stores in 256-byte segments) needed ~2 100 vector
+// instructions per hypothesis and reached 5.14 TB/s = 0.82 of a copy.  Round 5: the fused scorer's gather --
+// hat weights on a clamped base row, one base address per voxel, the request ring, packed FMAs, the
+// point-mirror quarters (ahv_dual.h: ~650 vector instructions per hypothesis) -- blends a QUARTER
+// (128 voxels x 16 channels) into the wave's LDS image X[c][voxel]; the image is read back row-wise and leaves as
+// eight global_store_dwordx4 per quarter (16 bytes per lane, two 512-byte channel segments per instruction,
+// non-temporal): the transposition goes through the LDS, not through registers (round 4's four-voxels-per-lane
+// attempt needed 240 of them).  One wave per hypothesis, 4 waves per workgroup, 79.5 KiB of LDS -> 2 workgroups per CU.
+// A NaN / inf voxel: the workgroup sees it while staging and every hypothesis of the launch goes through
+// exact_gather_quarter (ahv_exact.h: grid_sample's per-corner zeros padding, utils.py:129) instead.
 // ---------------------------------------------------------------------------------
 constexpr int kRotThreads = 256;
+constexpr int kRotImgFloats = 16 * 128;  // one quarter X[c][voxel], voxel = a0 * 64 + h * 8 + w: the output's own order
+
+// image -> out[n][c][128 Q + ...]: lane l reads channel 2 k + (l >> 5), voxels 4 (l & 31) .. + 3
+__device__ __forceinline__ void rot_flush_quarter(float* __restrict__ o, const float* img, int lane)
+{
+    const int v4 = 4 * (lane & 31), ch = lane >> 5;
+    f32x4 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const f32x4*>(img + (2 * k + ch) * 128 + v4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(x[k], reinterpret_cast<f32x4*>(o + (2 * k + ch) * 512 + v4));
+}
 
 __global__ __launch_bounds__(kRotThreads) void rotate_volume_16x8_kernel(
     const float* __restrict__ vol, const float* __restrict__ R, long N, float* __restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float srcT[kSrcFloats];
+    __shared__ __attribute__((aligned(1024))) float srcT[kSrcFloats];
+    __shared__ __attribute__((aligned(16))) float img[4 * kRotImgFloats];
+    __shared__ unsigned nf;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    stage_src_volume(srcT, vol, tid, kRotThreads);
+    if (tid == 0) nf = 0u;
     __syncthreads();
-    const int e = lane & 7, b = lane >> 3;  // w, h of this lane; d = pass
-    const float x = (2.0f * e + 1.0f) * 0.125f - 1.0f;
-    const float y = (2.0f * b + 1.0f) * 0.125f - 1.0f;
-    for (long n = (long)blockIdx.x * 4 + wave; n < N; n += (long)gridDim.x * 4) {
+    {
+        bool bad = false;
+        for (int i = tid; i < 16 * 512; i += kRotThreads) {
+            const int c = i >> 9, v = i & 511;
+            const float x = vol[i];
+            bad = bad || non_finite(x);
+            srcT[((v >> 6) * kSrcPlaneRows + ((v >> 3) & 7) * kSrcRowsY + (v & 7)) * kSrcStride + c] = x;
+        }
+        if (bad) nf = 1u;
+    }
+    __syncthreads();
+    const bool exact = __builtin_amdgcn_readfirstlane((int)nf) != 0;
+    float* buf = img + wave * kRotImgFloats;
+    const GatherLane glane = gather_lane(lane);
+    GatherDst gdst = gather_dst_linear(lane);
+    asm volatile("" : "+v"(gdst.m0), "+v"(gdst.m1));
+    const int rl = lane < 9 ? lane : 8;
+    const long nstep = (long)gridDim.x * 4;
+    long n = (long)blockIdx.x * 4 + wave;
+    float Rn = n < N ? R[n * 9 + rl] : 0.0f;
+    for (; n < N; n += nstep) {
         float Rm[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Rm[i] = R[n * 9 + i];
-        float* o = out + n * (16 * 512) + lane;
-#pragma unroll 2
-        for (int a = 0; a < 8; ++a) {
-            const float z = (2.0f * a + 1.0f) * 0.125f - 1.0f;
-            TriCoef k;
-            tri_coef(k, Rm, x, y, z);
-            float v[16];
-            tri_blend(v, srcT, k);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(v[c], o + c * 512 + a * 64);
+        for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rn), i));
+        Rn = R[(n + nstep < N ? n + nstep : n) * 9 + rl];
+        float* o = out + n * (16 * 512);
+        if (!exact) {
+            GatherHyp gh;
+            gather_hyp(gh, Rm, glane);
+            HatState st;
+            // quarters in the order 0, 3, 1, 2: quarter 3 - Q is the point mirror of quarter Q and reuses its set-up
+            hat_prologue<0>(st, srcT, gh);
+            hat_body_linear<128>(st, buf, gdst); wave_lds_fence();
+            rot_flush_quarter(o, buf, lane); wave_lds_fence();
+            hat_prologue_mirror(st, srcT);
+            hat_body_linear<128, true>(st, buf, gdst); wave_lds_fence();
+            rot_flush_quarter(o + 3 * 128, buf, lane); wave_lds_fence();
+            hat_prologue<1>(st, srcT, gh);
+            hat_body_linear<128>(st, buf, gdst); wave_lds_fence();
+            rot_flush_quarter(o + 128, buf, lane); wave_lds_fence();
+            hat_prologue_mirror(st, srcT);
+            hat_body_linear<128, true>(st, buf, gdst); wave_lds_fence();
+            rot_flush_quarter(o + 2 * 128, buf, lane); wave_lds_fence();
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                exact_gather_quarter<true>(buf, srcT, Rm, q, lane);
+                wave_lds_fence();
+                rot_flush_quarter(o + q * 128, buf, lane);
+                wave_lds_fence();
+            }
         }
     }
 }
@@ -50,15 +107,17 @@ __global__ __launch_bounds__(kRotThreads) void rotate_volume_16x8_kernel(
 // accepts every 5-D volume).  One thread per output voxel, channels looped; the source
 // is read through the caches.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void axis_generic(float g, int size, float& w0, float& w1, long& i0, long& i1)
+__device__ __forceinline__ void axis_generic(float g, int size, float& w0, float& w1, long& i0, long& i1, bool& in0, bool& in1)
 {
     float i = ((g + 1.0f) * (float)size - 1.0f) * 0.5f;
     i = fminf(fmaxf(i, -2.0f), (float)size + 1.0f);
     const float fl = floorf(i);
     const float t = i - fl;
     const int a = (int)fl, b = a + 1;
-    w0 = (a >= 0 && a < size) ? 1.0f - t : 0.0f;
-    w1 = (b >= 0 && b < size) ? t : 0.0f;
+    in0 = a >= 0 && a < size;
+    in1 = b >= 0 && b < size;
+    w0 = in0 ? 1.0f - t : 0.0f;
+    w1 = in1 ? t : 0.0f;
     i0 = min(max(a, 0), size - 1);
     i1 = min(max(b, 0), size - 1);
 }
@@ -82,16 +141,19 @@ __global__ __launch_bounds__(256) void rotate_volume_generic_kernel(
         const float gz = r[6] * x + r[7] * y + r[8] * z;
         float wx[2], wy[2], wz[2];
         long ox[2], oy[2], oz[2];
-        axis_generic(gx, W, wx[0], wx[1], ox[0], ox[1]);
-        axis_generic(gy, H, wy[0], wy[1], oy[0], oy[1]);
-        axis_generic(gz, D, wz[0], wz[1], oz[0], oz[1]);
+        bool ix[2], iy[2], iz[2];
+        axis_generic(gx, W, wx[0], wx[1], ox[0], ox[1], ix[0], ix[1]);
+        axis_generic(gy, H, wy[0], wy[1], oy[0], oy[1], iy[0], iy[1]);
+        axis_generic(gz, D, wz[0], wz[1], oz[0], oz[1], iz[0], iz[1]);
         float wgt[8];
         long off[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
             wgt[k] = wz[dz] * wy[dy] * wx[dx];
-            off[k] = (oz[dz] * H + oy[dy]) * W + ox[dx];
+            // zeros padding is per corner: an out-of-range corner is SKIPPED (its weight here is 0, but 0 * a non-finite
+            // voxel would be NaN where F.grid_sample leaves the voxel out); an in-range corner counts even with weight 0
+            off[k] = (iz[dz] && iy[dy] && ix[dx]) ? (oz[dz] * H + oy[dy]) * W + ox[dx] : -1;
         }
         const float* src = vol + n * vol_batch_stride;
         float* o = out + n * C * plane + v;
@@ -99,7 +161,8 @@ __global__ __launch_bounds__(256) void rotate_volume_generic_kernel(
             const float* sc = src + c * plane;
             float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += wgt[k] * sc[off[k]];
+            for (int k = 0; k < 8; ++k)
+                if (off[k] >= 0) acc += wgt[k] * sc[off[k]];
             o[c * plane] = acc;
         }
     }
@@ -133,9 +196,10 @@ __global__ __launch_bounds__(256) void rotate_volume_backward_kernel(
         const float gz = r[6] * x + r[7] * y + r[8] * z;
         float wx[2], wy[2], wz[2];
         long ox[2], oy[2], oz[2];
-        axis_generic(gx, W, wx[0], wx[1], ox[0], ox[1]);
-        axis_generic(gy, H, wy[0], wy[1], oy[0], oy[1]);
-        axis_generic(gz, D, wz[0], wz[1], oz[0], oz[1]);
+        bool ix[2], iy[2], iz[2];
+        axis_generic(gx, W, wx[0], wx[1], ox[0], ox[1], ix[0], ix[1]);
+        axis_generic(gy, H, wy[0], wy[1], oy[0], oy[1], iy[0], iy[1]);
+        axis_generic(gz, D, wz[0], wz[1], oz[0], oz[1], iz[0], iz[1]);
         float wgt[8];
         long off[8];
 #pragma unroll
@@ -143,6 +207,7 @@ __global__ __launch_bounds__(256) void rotate_volume_backward_kernel(
             const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
             wgt[k] = wz[dz] * wy[dy] * wx[dx];
             off[k] = (oz[dz] * H + oy[dy]) * W + ox[dx];
+            if (!(iz[dz] && iy[dy] && ix[dx])) wgt[k] = 0.0f;  // skipped below: an out-of-range corner receives nothing
         }
         float* dst = grad_vol + n * vol_batch_stride;
         const float* g = grad_out + n * C * plane + v;
@@ -279,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
         AHV_F3_QUARTER(3)
 #undef AHV_F3_QUARTER
         f32x4 v[2][4];
-        gemm2_dual(v, acc, f);
+        gemm2_dual_exact(v, acc, f);  // the op-level drop-in materialises the reference's tensor: F.relu's NaN propagation too
         float* o = out + m * (32 * 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -394,7 +459,7 @@ __global__ __launch_bounds__(512) void forward_3d2d_small_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float a20 = W2[row * 32 + 16 * m + 4 * kq + r], a21 = W2[(16 + row) * 32 + 16 * m + 4 * kq + r];
-            const float x = fmaxf(u[m][r], 0.0f);
+            const float x = u[m][r] < 0.0f ? 0.0f : u[m][r];  // F.relu: a NaN stays a NaN (v_max would drop it)
             v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, x, v[0], 0, 0, 0);
             v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, x, v[1], 0, 0, 0);
         }
@@ -578,7 +643,7 @@ hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, cons
 {
     if (C == 16 && D == 8 && H == 8 && W == 8 && vol_batch_stride == 0) {
         long blocks = (N + 3) / 4;
-        const long cap = (long)num_cu * 4;
+        const long cap = (long)num_cu * 2;  // 79.5 KiB of LDS per workgroup: two per CU are resident
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(rotate_volume_16x8_kernel, dim3((unsigned)blocks), dim3(kRotThreads), 0, stream, vol,
                            R, (long)N, out);

@@ -17,6 +17,7 @@
 #include "ahv_dual.h"
 #include "ahv_split.h"
 #include "ahv_team.h"
+#include "ahv_exact.h"
 #include "ahv_launch.h"
 
 namespace ahv {
@@ -70,6 +71,11 @@ __device__ __forceinline__ void hyp_tile_sums(float& ss, float& dt, const f32x4&
 // From the per-tile sums to the hypothesis' score.  Result uniform (read from lane 63).
 __device__ __forceinline__ float hyp_score_tail(const float (&ss)[4], const float (&dt)[4])
 {
+    // No contraction here: hipcc fused the cosine's multiplication into the first addition of wave_sum_dpp
+    // (v_mul, v_mov_dpp, v_fmac: the sum then holds one UNROUNDED product per lane), which a team -- whose cosines pass
+    // through a select first -- did not: the one place where a team's score was an ulp off a lone wave's (round 5,
+    // tools/team_stage_diff.py).  With the product rounded in both, the two are the same sums.  One instruction fewer, too.
+#pragma clang fp contract(off)
     // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: with
     // (first, second) = (tile i, tile i+2) every lane then holds, in the two registers, its own half-sum of the
     // tile it keeps (i below lane 32, i+2 above) and the partner lane's half-sum of that same tile.  One VALU
@@ -102,6 +108,67 @@ __device__ __forceinline__ float hyp_score_rs(const f32x4 (&v)[2][4], const f32x
 #pragma unroll
     for (int t = 0; t < 4; ++t) hyp_tile_sums<XDL>(ss[t], dt[t], v[0][t], v[1][t], tg[t][0], tg[t][1]);
     return hyp_score_tail(ss, dt);
+}
+
+#ifdef AHV_DIAG_STAGE
+// Diagnostic builds only (tools/team_stage_diff.py): instead of the score a hypothesis returns an order-independent XOR
+// checksum of the BITS of one intermediate stage -- 1: GEMM1 pre-activations u, 2: head outputs v, 3: per-position sums of
+// squares and dot products, 4: per-position cosines -- computed the same way by a lone wave and by a team, so that the first
+// stage at which the two formulations differ can be read off.
+__device__ __forceinline__ unsigned diag_wave_xor(unsigned x)
+{
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) x ^= (unsigned)__shfl_xor((int)x, sft, 64);
+    return x;
+}
+__device__ __forceinline__ unsigned diag_bits4(const f32x4& a)
+{
+    return __float_as_uint(a[0]) ^ (__float_as_uint(a[1]) * 3u) ^ (__float_as_uint(a[2]) * 5u) ^ (__float_as_uint(a[3]) * 7u);
+}
+#endif
+
+// A team member's share of hyp_score_rs (ahv_team.h): the sums of position tile t alone, associated exactly as
+// hyp_score_tail associates them -- lane rows (kq 0 + kq 2) + (kq 1 + kq 3), the normalisation per position, the row_shr
+// steps of wave_sum_dpp over the tile's 16 positions (rows 1-3 enter as zeros: x + 0 is exact).  Lane 63 returns P_t; the
+// one-wave kernel's last two DPP steps make ((P_3 + P_2) + (P_1 + P_0)) of them, which is what member 0 does.
+template <bool XDL>
+__device__ __forceinline__ float team_tile_score(const f32x4 (&v)[2], const f32x4& g0, const f32x4& g1, int lane)
+{
+#pragma clang fp contract(off)
+    float ss, dt;
+    hyp_tile_sums<XDL>(ss, dt, v[0], v[1], g0, g1);
+    ss += __shfl_xor(ss, 32, 64);
+    dt += __shfl_xor(dt, 32, 64);
+    ss += __shfl_xor(ss, 16, 64);
+    dt += __shfl_xor(dt, 16, 64);
+    const float c = lane < 16 ? dt * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)) : 0.0f;
+#ifdef AHV_DIAG_STAGE
+    if (AHV_DIAG_STAGE == 3) return __uint_as_float(diag_wave_xor(lane < 16 ? (__float_as_uint(ss) ^ (__float_as_uint(dt) * 3u)) : 0u));
+    if (AHV_DIAG_STAGE == 4) return __uint_as_float(diag_wave_xor(lane < 16 ? __float_as_uint(c) : 0u));
+#endif
+    return wave_sum_dpp(c);
+}
+
+// Quarter `member` of the rotated volume into the wave's image `buf`, gathered exactly as the one-wave kernel gathers it:
+// quarters 3 and 2 are the point mirrors of quarters 0 and 1 (hat_mirror, ahv_dual.h) -- same weights, same rows, same
+// sums, bit for bit.  `done_ctr` / `done_target`: the image is free once the team's last round has been read.  Two
+// straight-line paths (a merge between the row requests and the blend made hipcc keep two copies of the request ring).
+__device__ __forceinline__ void team_gather(float* buf, const float* srcT, const GatherHyp& gh, const GatherDst& gdst, int member,
+                                            unsigned* done_ctr, unsigned done_target)
+{
+    HatState st;
+    if (member < 2) {
+        hat_prologue_rt(st, srcT, gh, (float)member);
+        team_wait(done_ctr, done_target);
+        hat_body(st, buf, gdst);
+    } else {
+        const float qf = (float)(3 - member);
+        hat_voxel_rt(st.vx[0], srcT, gh, 0, qf);
+        hat_voxel_rt(st.vx[1], srcT, gh, 1, qf);
+        hat_prologue_mirror(st, srcT);
+        team_wait(done_ctr, done_target);
+        hat_body<true>(st, buf, gdst);
+    }
 }
 
 #ifdef AHV_STAMPS
@@ -146,6 +213,62 @@ struct C2fArgs {
 constexpr unsigned kC2fSpinLimit = 1u << 20;  // polls (~1 us each) before a workgroup gives the meeting point up: the
                                               // launch then ends with the error word set instead of hanging the device
 
+// The exact path's share of one workgroup wave (ahv_exact.h): hypotheses h0, h0 + hstep, ... < N of sample-relative set R
+// (Rstar != null: the coarse-to-fine stage-1 composition R* d).  Everything it needs comes in as arguments or from LDS --
+// it reloads the GEMM2 fragments itself -- so that the call site keeps nothing alive for it.  Returns the running best key.
+struct ExactCompose {  // by value: taking the address of the caller's R* would move it to scratch for the hot loop too
+    float r[9];
+    bool on;
+};
+
+struct NoCompose {  // the instances without a second stage pass nothing
+    static constexpr bool on = false;
+    static constexpr float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+};
+
+template <bool SPLIT, typename Compose>
+__device__ __attribute__((noinline)) key_t score_share_exact(const float* lds_src, const float* lds_w1, float* buf, const float* W1,
+                                                             const float* W2, const float* b2, const float* Rb, Compose Rstar,
+                                                             long N, long h0, long hstep, float* scores_b, long n_offset, key_t best)
+{
+    const int lane = threadIdx.x & 63;
+    const int rl = lane < 9 ? lane : 8;
+    DualFrags f;
+    load_dual_frags(f, W2, b2, lane);
+    for (long he = h0; he < N; he += hstep) {
+        const float Re = Rb[he * 9 + rl];
+        float Rm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Re), i));
+        if (Rstar.on) {  // compose_rotations_kernel's arithmetic, as the hot loop's hyp_rotation
+            float d[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) d[i] = Rm[i];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Rm[a * 3 + c] = Rstar.r[a * 3] * d[c] + Rstar.r[a * 3 + 1] * d[3 + c] + Rstar.r[a * 3 + 2] * d[6 + c];
+        }
+        f32x4 acc[2][4];
+        if constexpr (SPLIT) exact_hypothesis_gemm1(acc, buf, lds_src, Rm, W1FragsGlobal{W1, lane}, lane);
+        else exact_hypothesis_gemm1(acc, buf, lds_src, Rm, W1FragsLds{reinterpret_cast<const f32x4*>(lds_w1) + lane}, lane);
+        f32x4 v[2][4];
+        gemm2_dual_exact(v, acc, f);
+        f32x4 tg[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+                tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
+        const float s = hyp_score_rs<SPLIT || kFp32LowHalf>(v, tg, lane);
+        if (scores_b != nullptr && lane == 0) scores_b[he] = s;
+        const key_t key = pack_key(s, (unsigned)(n_offset + he));
+        best = key > best ? key : best;
+    }
+    return best;
+}
+
 template <bool SPLIT, bool TGT, bool C2F>
 __device__ __forceinline__ void score_hypotheses_body(
     const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
@@ -166,6 +289,7 @@ __device__ __forceinline__ void score_hypotheses_body(
     __shared__ __attribute__((aligned(16))) float lds_w1[kW1TableFloats];
     __shared__ __attribute__((aligned(16))) float lds_q[8 * kQuarterFloats];
     __shared__ TeamSync lds_team;  // 84 of the 512 bytes the three images leave
+    __shared__ NonFinite lds_nf;   // a NaN / inf among the voxels or head weights being staged (ahv_exact.h)
     // this workgroup's start: 100-MHz real time and shader clock for the diagnostic stamps (parked in LDS: registers that
     // live across the hypothesis loop are what this kernel has none to spare of)
     __shared__ unsigned long long lds_t_entry[2];
@@ -190,18 +314,54 @@ __device__ __forceinline__ void score_hypotheses_body(
     unsigned long long wg_t_loop = 0;
 #endif
     if (!SPLIT && tid < (int)(sizeof(TeamSync) / 4)) reinterpret_cast<unsigned*>(&lds_team)[tid] = 0u;
+    if (tid < (int)(sizeof(NonFinite) / 4)) reinterpret_cast<unsigned*>(&lds_nf)[tid] = 0u;
+    // fp32 instances: EVERY global load of the prologue -- the W1 rows, the first sample's source volume, team 1's quarter
+    // of the target volume (or the target features), W2 / b2 -- is issued here, before the first LDS store, so that the
+    // workgroup pays ONE first-touch round trip instead of three in a row (W1 -> barrier -> volume -> barrier: 4.8 us of
+    // prologue in round 4, profiles/r04z_small_launch_stamps.txt).  The registers are free: nothing else is live yet.
+    SrcRegs sv;        // the NEXT sample's source voxels: loaded here for the first sample, at the bottom of the sample loop
+    TgtRegs tv;        // for the following ones (never live across the hypothesis loop)
+    W1Regs w1r;
+    const bool w1_rows = (reinterpret_cast<unsigned long long>(W1) & 15ull) == 0;
+    if (!SPLIT) {
+        if (w1_rows) w1_regs_load(w1r, W1, tid);
+        src_regs_load(sv, vol_src + (long)blockIdx.y * (16 * 512), tid);  // (blockIdx.y < B by construction of the grid)
+        tgt_regs_load<TGT>(tv, tgt, (int)blockIdx.y, tid);
+    }
     int w1_exp = 0, w2_exp = 0;
     if (SPLIT) {
         float m = 0.0f;
-        for (int i = tid; i < 32 * 384; i += kDualThreads) m = fmaxf(m, fabsf(W1[i]));
-        w1_exp = split_prescale_exp(block_absmax(m, lds_q, tid));
+        bool bad = non_finite(W2[tid]) || non_finite(W2[tid + 512]) || non_finite(b2[tid & 31]);
+        for (int i = tid; i < 32 * 384; i += kDualThreads) {
+            m = fmaxf(m, fabsf(W1[i]));
+            bad = bad || non_finite(W1[i]);
+        }
+        w1_exp = split_prescale_exp(block_absmax(m, lds_q, tid));  // (block_absmax: two barriers behind the zeroing above)
+        if (bad) lds_nf.weights = 1u;
         stage_w1_split(reinterpret_cast<f16x8*>(lds_w1), W1, ldexpf(1.0f, w1_exp), tid, kDualThreads);
         w2_exp = split_prescale_exp(block_absmax(fmaxf(fabsf(W2[tid]), fabsf(W2[tid + 512])), lds_q, tid));
-    } else {
-        stage_w1_table(lds_w1, W1, tid, kDualThreads);
     }
     DualFrags f0;
-    if (!SPLIT) load_dual_frags(f0, W2, b2, lane);
+    bool w_bad = false;  // fp32 instances: this thread saw a non-finite head weight
+    if (!SPLIT) {
+        load_dual_frags(f0, W2, b2, lane);
+        bool bad = false;
+        if (w1_rows) {
+            w1_regs_store(lds_w1, w1r, tid);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bad = bad || non_finite(w1r.w[k][e]);
+        } else {  // a view that starts off a 16-byte boundary: float by float
+            stage_w1_table(lds_w1, W1, tid, kDualThreads);
+            for (int i = tid; i < 32 * 384; i += kDualThreads) bad = bad || non_finite(W1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bad = bad || non_finite((&f0.a2[0][0][0])[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bad = bad || non_finite(f0.bias[i >> 2][i & 3]);
+        w_bad = bad;  // published behind the first staging barrier (the zeroing of lds_nf above is another wave's store)
+    }
     const int team = wave >> 2, member = wave & 3;
     unsigned team_rounds = 0;  // exchanges this wave's team has completed (wave-uniform; the counters of TeamSync only grow)
     unsigned samples_done = 0;
@@ -223,26 +383,37 @@ __device__ __forceinline__ void score_hypotheses_body(
         // the staging code are built HERE, once per sample: hoisted out of the sample loop they live across the hypothesis
         // loop, i.e. in scratch (2-4 MB of spill stores per launch showed up as WRITE_SIZE, profiles/r04c_pmc_summary.json).
         const int lane_s = opaque(lane), tid_s = wave * 64 + lane_s;  // (not from threadIdx.x: that register may die here)
+        const unsigned gen = samples_done + 1u;  // generation of this sample's non-finite flags (ahv_exact.h)
+        if (w_bad) lds_nf.weights = 1u;
         DualFrags f = f0;
         Split2Frags w2s;
         int exp_sum = 0;  // of the three prescales of this sample: they leave again behind GEMM2 (gemm2_split)
         if (SPLIT) {
             load_dual_frags(f, W2, b2, lane_s);
             split_w2_frags(w2s, f, ldexpf(1.0f, w2_exp));
-            exp_sum = w2_exp + w1_exp + stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid_s);
+            bool bad;
+            exp_sum = w2_exp + w1_exp + stage_src_volume_scaled(lds_src, vol_src + (long)b * (16 * 512), lds_q, tid_s, bad);
+            if (bad) lds_nf.src_gen = gen;
         } else {
-            stage_src_volume(lds_src, vol_src + (long)b * (16 * 512), tid_s, kDualThreads);
+            src_regs_store(lds_src, sv, tid_s);
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) bad = bad || non_finite(sv.x[c]);
+            if (bad) lds_nf.src_gen = gen;
             if constexpr (TGT) {
-                // team 1: each wave's un-rotated quarter of the TARGET volume goes into its private image here, ahead of
-                // the staging barrier (the image is free between the two barriers), so that its first-touch latency
-                // elapses while the workgroup waits for the source volume anyway
-                if (team == 1) stage_quarter_global(buf, tgt + (long)b * (16 * 512), member, lane_s);
+                bool tbad = false;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) tbad = tbad || non_finite(tv.q[c].x) || non_finite(tv.q[c].y);
+                if (tbad) lds_nf.tgt_gen = gen;  // (threads of team 0 hold zeros)
             }
+            // TGT: team 1's un-rotated quarters of the TARGET volume go into its members' private images here, ahead of
+            // the staging barrier (the images are free between the two barriers).  Else: the target features as the
+            // per-lane fragments the score needs, parked in the 16-byte pad of source rows 0..511 (row (2t + m2)*64 +
+            // lane): 32 registers less per wave, and the 80-byte row stride makes the eight ds_read_b128 of the
+            // epilogue conflict-free.
+            tgt_regs_store<TGT>(lds_src, buf, tv, tid_s);
         }
-        // Target features as the per-lane fragments the score needs, parked in the 16-byte pad of source
-        // rows 0..511 (row (2t + m2)*64 + lane): 32 registers less per wave, and the 80-byte row stride
-        // makes the eight ds_read_b128 of the epilogue conflict-free.
-        if (!TGT) {
+        if (SPLIT) {
             const float* ft = tgt + (long)b * (32 * 64);
             const int l = tid_s & 63, t = tid_s >> 7, m2 = (tid_s >> 6) & 1;
             f32x4 x;
@@ -251,6 +422,13 @@ __device__ __forceinline__ void score_hypotheses_body(
             *reinterpret_cast<f32x4*>(lds_src + tid_s * kSrcStride + 16) = x;
         }
         __syncthreads();
+        // a sample with a NaN / inf voxel or head weight leaves the hot loop for the exact path (ahv_exact.h); uniform
+        const bool nf_w = __builtin_amdgcn_readfirstlane((int)lds_nf.weights) != 0;
+#ifdef AHV_DIAG_NO_EXACT  // diagnostic builds (tools/kbench): without the exact path's call, to price its mere presence
+        const bool exact = false;
+#else
+        const bool exact = nf_w || (unsigned)__builtin_amdgcn_readfirstlane((int)lds_nf.src_gen) == gen;
+#endif
         bool tg_ready = !TGT;
         if constexpr (TGT) {
             // forward_3d2d(vol_tgt[b]) (test_co3d.py:141, modules/modules.py:112-124) by team 1, one quarter per wave, while
@@ -260,13 +438,12 @@ __device__ __forceinline__ void score_hypotheses_body(
             // use (tg_wait below); the ~0.2 hypotheses' worth of work lands on the four waves that have one hypothesis
             // less than their SIMD partners whenever the last round is partial.
             if (team == 1) {
-                TeamAcc ta;
-                gemm1_quarter_team(ta, lds_w1, buf, lane_s, member);
-                wave_lds_fence();
                 f32x4 u[2], v[2];
-                team_exchange(u, ta, lds_q + 4 * kQuarterFloats, lds_team, 1, member, team_rounds, lane_s);
+                team_round(u, lds_w1, lds_q + 4 * kQuarterFloats, lds_team, 1, member, team_rounds, lane_s);
                 ++team_rounds;
-                const float inv = 1.0f / fmaxf(sqrtf(team_head(v, u, f0)), 1e-12f);  // F.normalize(dim=1), eps 1e-12
+                if (nf_w || (unsigned)__builtin_amdgcn_readfirstlane((int)lds_nf.tgt_gen) == gen) team_head_exact(v, u, f0);
+                else team_head(v, u, f0);
+                const float inv = 1.0f / fmaxf(sqrtf(team_sumsq(v)), 1e-12f);  // F.normalize(dim=1), eps 1e-12
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
                     const f32x4 x = v[m2] * inv;
@@ -341,6 +518,88 @@ __device__ __forceinline__ void score_hypotheses_body(
                 Rstar[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Rb0[idx * 9 + i])));
         }
         key_t best = kKeyEmpty;
+        const int rl = lane < 9 ? lane : 8;  // lane i < 9 fetches element i of a rotation
+        auto score_remainder_by_teams = [&]() {
+            // The remainder [n_main, N): one hypothesis per TEAM (ahv_team.h), scored FIRST -- at the head of a launch the
+            // workgroup's other team is busy too (its own remainder hypothesis, the target features, or the first main-round
+            // hypotheses), so the team's ~1/4-hypothesis pieces share the SIMDs with useful work; behind the main rounds a
+            // team round is pure latency on an emptying CU.  Team slot g = team * gridDim.x + residue, so the remainder
+            // spreads over all workgroups first and over their second team next.  Every member runs the same rounds;
+            // member 0 emits the score of round r after the arrive point of round r + 1 (or of the flush below), where the
+            // four partial sums of round r are known to be in place.  Scores are a lone wave's bit for bit.
+            const long tstep = 2l * gridDim.x;
+            long ht = n_main_s + (long)team * gridDim.x + residue;
+            if (ht < N_s) {
+                long h_prev = -1;
+                float Rt = Rb[ht * 9 + rl];
+                auto team_emit = [&]() {  // member 0, behind an arrive point: the partials of the round before are complete
+                    const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
+#ifdef AHV_DIAG_STAGE
+                    const float sc = __uint_as_float(__float_as_uint(pp[0]) ^ __float_as_uint(pp[1]) ^ __float_as_uint(pp[2]) ^ __float_as_uint(pp[3]));
+#else
+                    const float sc = ((pp[3] + pp[2]) + (pp[1] + pp[0])) * (1.0f / 64.0f);  // wave_sum_dpp's last two steps
+#endif
+                    if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h_prev] = sc;
+                    const key_t key = pack_key(sc, (unsigned)(n_offset_s + h_prev));
+                    best = key > best ? key : best;
+                };
+                for (; ht < N_s; ht += tstep) {
+                    float Rm[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rt), i));
+                    hyp_rotation(Rm, st1);
+                    if (ht + tstep < N_s) Rt = Rb[(ht + tstep) * 9 + rl];
+                    GatherHyp gh;
+                    gather_hyp(gh, Rm, glane);
+                    team_gather(buf, srcT, gh, gdst, member, &lds_team.done[team], 4u * team_rounds);
+                    wave_lds_fence();
+                    f32x4 u[2], v[2];
+                    team_round(u, lds_w1, lds_q + 4 * team * kQuarterFloats, lds_team, team, member, team_rounds, lane);
+                    if (member == 0 && h_prev >= 0) team_emit();
+                    tg_wait();
+                    team_head(v, u, f);
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(lds_src + ((2 * member) * 64 + lane) * kSrcStride + 16);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(lds_src + ((2 * member + 1) * 64 + lane) * kSrcStride + 16);
+                    float tot = team_tile_score<kFp32LowHalf>(v, g0, g1, lane);
+#ifdef AHV_DIAG_STAGE
+                    if (AHV_DIAG_STAGE == 1) tot = __uint_as_float(diag_wave_xor(diag_bits4(u[0]) ^ (diag_bits4(u[1]) * 11u)));
+                    if (AHV_DIAG_STAGE == 2) tot = __uint_as_float(diag_wave_xor(diag_bits4(v[0]) ^ (diag_bits4(v[1]) * 11u)));
+#endif
+                    if (lane == 63) lds_team.part[team][team_rounds & 1u][member] = tot;
+                    ++team_rounds;
+                    h_prev = ht;
+                }
+                // flush: one more meeting point, then member 0 emits the last round's score
+                team_signal(&lds_team.arrive[team], lane);
+                team_wait(&lds_team.arrive[team], 4u * (team_rounds + 1u));
+                if (member == 0) team_emit();
+                team_signal(&lds_team.done[team], lane);  // keeps arrive and done in step: one of each per meeting point
+                ++team_rounds;
+                team_wait(&lds_team.done[team], 4u * team_rounds);  // (the main rounds below store into the image unasked)
+            }
+        };
+        if (exact) {
+            // A NaN / inf among this sample's voxels or the head weights: every hypothesis of the workgroup's share, main
+            // rounds and remainder alike, one per wave through the exact path (ahv_exact.h) -- grid_sample's per-corner
+            // zeros padding and F.relu's NaN propagation restated literally.  Finite samples never get here.  A CALL, not
+            // inlined: inlined, the slow path's live ranges pushed the allocator into spilling inside the hot loop (which
+            // sits at 256 registers); behind a call boundary it cannot touch the hot loop's allocation.
+            if constexpr (TGT) tg_wait();
+            const long h0 = (long)wave * gridDim.x + residue;
+            float* sc_b = scores_s != nullptr ? scores_s + (long)b * N_s : nullptr;
+            if constexpr (C2F) {
+                ExactCompose ec;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ec.r[i] = Rstar[i];
+                ec.on = st1;
+                best = score_share_exact<SPLIT>(lds_src, lds_w1, buf, W1, W2, b2, Rb, ec, N_s, h0, hstep, sc_b, n_offset_s, best);
+            } else {
+                best = score_share_exact<SPLIT>(lds_src, lds_w1, buf, W1, W2, b2, Rb, NoCompose{}, N_s, h0, hstep, sc_b, n_offset_s, best);
+            }
+        } else {
+#ifndef AHV_DIAG_TEAMS_LAST
+        if constexpr (!SPLIT) score_remainder_by_teams();
+#endif
         // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): a partial last round of the persistent
         // grid spreads over ALL CUs with few waves each instead of filling some CUs completely and leaving the rest idle.
         // The deal inside a workgroup is STATIC.  The older wave of a SIMD issues first and finishes its share ~110 us before
@@ -353,7 +612,6 @@ __device__ __forceinline__ void score_hypotheses_body(
         // broadcast with v_readlane at the top of the next iteration.  Not as scalar loads: SMEM shares lgkmcnt
         // with the LDS and returns out of order, so the first LDS wait behind an s_load has to wait for the s_load
         // too -- a first-touch read of R from HBM (~2 us) in front of every hypothesis' first gather step.
-        const int rl = lane < 9 ? lane : 8;
         float Rn = h < n_main_s ? Rb[h * 9 + rl] : 0.0f;  // nothing of R is touched when this wave has no hypothesis (N = 0: R may be null)
 #ifdef AHV_STAMPS
         unsigned long long tsum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -445,6 +703,22 @@ __device__ __forceinline__ void score_hypotheses_body(
                     for (int m2 = 0; m2 < 2; ++m2)
                         tg[t][m2] = *reinterpret_cast<const f32x4*>(lds_src + ((2 * t + m2) * 64 + lane) * kSrcStride + 16);
                 s = hyp_score_rs<kFp32LowHalf>(v, tg, lane);
+#ifdef AHV_DIAG_STAGE
+                {
+                    unsigned x = 0;
+                    if (AHV_DIAG_STAGE == 1) for (int t = 0; t < 4; ++t) x ^= diag_bits4(acc[0][t]) ^ (diag_bits4(acc[1][t]) * 11u);
+                    if (AHV_DIAG_STAGE == 2) for (int t = 0; t < 4; ++t) x ^= diag_bits4(v[0][t]) ^ (diag_bits4(v[1][t]) * 11u);
+                    if (AHV_DIAG_STAGE >= 3) {
+                        float ss[4], dt[4];
+                        for (int t = 0; t < 4; ++t) hyp_tile_sums<kFp32LowHalf>(ss[t], dt[t], v[0][t], v[1][t], tg[t][0], tg[t][1]);
+                        const float s1 = swap_add16(swap_add32(ss[0], ss[2]), swap_add32(ss[1], ss[3]));
+                        const float d1 = swap_add16(swap_add32(dt[0], dt[2]), swap_add32(dt[1], dt[3]));
+                        const float c = d1 * __builtin_amdgcn_rsqf(fmaxf(s1, 1e-24f));
+                        x = AHV_DIAG_STAGE == 3 ? (__float_as_uint(s1) ^ (__float_as_uint(d1) * 3u)) : __float_as_uint(c);
+                    }
+                    s = __uint_as_float(diag_wave_xor(x));
+                }
+#endif
             }
             if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h] = s;
             const key_t key = pack_key(s, (unsigned)(n_offset_s + h));
@@ -455,82 +729,27 @@ __device__ __forceinline__ void score_hypotheses_body(
             tsum[10] += 1;
 #endif
         }
-        if constexpr (!SPLIT) {
-            // The remainder [n_main, N): one hypothesis per TEAM (ahv_team.h).  Team slot g = team * gridDim.x + residue, so
-            // the remainder spreads over all workgroups first and over their second team next.  Every member runs the same
-            // rounds; member 0 emits the score of round r after the arrive point of round r + 1 (or of the flush below),
-            // where the four partial means of round r are known to be in place.
-            const long tstep = 2l * gridDim.x;
-            long ht = n_main_s + (long)team * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
-            if (ht < N_s) {
-                long h_prev = -1;
-                float Rt = Rb[ht * 9 + rl];  // (not requested ahead of the main loop: a register across it costs more than this wait)
-                for (; ht < N_s; ht += tstep) {
-                    float Rm[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) Rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Rt), i));
-                    hyp_rotation(Rm, st1);
-                    if (ht + tstep < N_s) Rt = Rb[(ht + tstep) * 9 + rl];
-                    GatherHyp gh;
-                    gather_hyp(gh, Rm, glane);
-                    HatState st;
-                    hat_prologue_rt(st, srcT, gh, (float)member);
-                    team_wait(&lds_team.done[team], 4u * team_rounds);  // the image is free: last round's partials have been read
-                    hat_body(st, buf, gdst);
-                    wave_lds_fence();
-                    TeamAcc ta;
-                    gemm1_quarter_team(ta, lds_w1, buf, lane, member);
-                    wave_lds_fence();
-                    f32x4 u[2], v[2];
-                    team_exchange(u, ta, lds_q + 4 * team * kQuarterFloats, lds_team, team, member, team_rounds, lane);
-                    if (member == 0 && h_prev >= 0) {  // behind the arrive point of this round: last round's partials are complete
-                        const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
-                        const float sc = ((pp[0] + pp[1]) + (pp[2] + pp[3])) * (1.0f / 64.0f);
-                        if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h_prev] = sc;
-                        const key_t key = pack_key(sc, (unsigned)(n_offset_s + h_prev));
-                        best = key > best ? key : best;
-                    }
-                    tg_wait();
-                    const float ss = team_head(v, u, f);
-                    float dt = 0.0f;
-#pragma unroll
-                    for (int m2 = 0; m2 < 2; ++m2) {
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(lds_src + ((2 * member + m2) * 64 + lane) * kSrcStride + 16);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dt = fmaf(v[m2][r], g[r], dt);
-                    }
-                    dt += __shfl_xor(dt, 16, 64);
-                    dt += __shfl_xor(dt, 32, 64);
-                    // the four lane rows hold the same 16 columns: row 0 alone enters the sum over positions
-                    const float c = lane < 16 ? dt * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)) : 0.0f;
-                    const float tot = wave_sum_dpp(c);
-                    if (lane == 63) lds_team.part[team][team_rounds & 1u][member] = tot;
-                    ++team_rounds;
-                    h_prev = ht;
-                }
-                // flush: one more meeting point, then member 0 emits the last round's score
-                team_signal(&lds_team.arrive[team], lane);
-                team_wait(&lds_team.arrive[team], 4u * (team_rounds + 1u));
-                if (member == 0) {
-                    const float* pp = lds_team.part[team][(team_rounds + 1u) & 1u];
-                    const float sc = ((pp[0] + pp[1]) + (pp[2] + pp[3])) * (1.0f / 64.0f);
-                    if (scores_s != nullptr && lane == 0) scores_s[(long)b * N_s + h_prev] = sc;
-                    const key_t key = pack_key(sc, (unsigned)(n_offset_s + h_prev));
-                    best = key > best ? key : best;
-                }
-                team_signal(&lds_team.done[team], lane);  // keeps arrive and done in step: one of each per meeting point
-                ++team_rounds;
-            }
-        }
+#ifdef AHV_DIAG_TEAMS_LAST  // diagnostic builds (tools/kbench): the remainder behind the main rounds, as in round 4
+        if constexpr (!SPLIT) score_remainder_by_teams();
+#endif
 #ifdef AHV_STAMPS
         if (lane == 0) {
             const int gw = (blockIdx.x * 8 + wave) & 2047;
             for (int i = 0; i < 11; ++i) g_stamps[gw * 16 + i] = tsum[i];
         }
 #endif
+        }  // finite sample
         if (key_s != nullptr && lane == 0 && best != kKeyEmpty) atomicMax(key_s + b, best);
       }  // stage
         ++samples_done;
+        if (!SPLIT) {
+            // The next sample's loads travel while the workgroup's last waves finish this one.  UNCONDITIONAL (the last sample
+            // re-reads itself): a conditional definition would keep the old values alive across the hypothesis loop.
+            const int bn = b + (int)gridDim.y < B ? b + (int)gridDim.y : b;
+            const int tid_e = wave * 64 + opaque(lane);  // (a fresh copy: tid_s must not stay alive across the hypothesis loop)
+            src_regs_load(sv, vol_src + (long)bn * (16 * 512), tid_e);
+            tgt_regs_load<TGT>(tv, tgt, bn, tid_e);
+        }
         if constexpr (C2F) {
             // The workgroup that finishes the sample last decodes both keys: what select_rotation_kernel did, twice.
             __syncthreads();
@@ -623,16 +842,17 @@ __global__ void unpack_best_kernel(const key_t* __restrict__ best_key, int B, fl
 namespace ahv {
 
 // How a launch covers N hypotheses with gx workgroups of 8 waves (per sample).  Hypotheses [0, n_main) go to single
-// waves, round after round of 8 * gx; the remainder may go to teams of four waves (ahv_team.h).  Measured (tools/kbench,
-// profiles/r04d_team_tail.txt; kernel time in us, teams / single waves): a remainder left to single waves is cheap -- the
-// oldest wave of a SIMD issues first, so the wave that owns one hypothesis more runs AHEAD of its partner and the extra
-// hypothesis costs the CU 1/24 of its time, not a lone last round -- while a team round at the end is latency the CU can
-// only hide behind waves that are still in their main rounds, i.e. once the waves of a workgroup have drifted apart:
+// waves, round after round of 8 * gx; a remainder of at most two per workgroup goes to teams of four waves (ahv_team.h),
+// one hypothesis per team, scored AHEAD of the main rounds.  A team's score is the lone wave's bit for bit, so the rule is
+// pure scheduling -- no result depends on N or on how a set is sharded.
+// Round 4 ran the team rounds BEHIND the main rounds (tools/kbench, profiles/r04d_team_tail.txt; kernel time in us,
+// teams / single waves): there a team round is latency on an emptying CU and only paid behind >= 4 full rounds,
 //     N = 2 154 (1 round + 106)  53.6 / 56.8      N = 12 500 (6 rounds + 212)  181.5 / 185.7
 //     N = 6 250 (3 rounds + 106) 103.8 / 103.5    N = 25 000 (12 rounds + 424) 349.9 / 353.7
 //     N = 6 400 (3 rounds + 256) 112.4 / 104.3
-// Hence: teams take a remainder of at most two per workgroup behind at least four full rounds, and launches that are
-// all remainder (N <= 2 gx: a team's ~10 us against the ~17 us a lone wave needs for a whole hypothesis).
+// while a remainder left to single waves costs the wave that owns it a whole extra hypothesis at the end of a short launch.
+// At the head of a launch the other team of the workgroup is busy too (its own remainder hypothesis, the target features
+// of ahv_verify_pair_f32, or its first main-round hypotheses): profiles/r05_team_head.txt.
 ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool teams)
 {
     ScorePlan p;
@@ -648,7 +868,7 @@ ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool tea
     if (gx < 1) gx = 1;
     p.gx = (int)gx;
     const int64_t slots = 8 * gx, full = N / slots, rem = N - full * slots;
-    p.n_main = (teams && rem > 0 && rem <= 2 * gx && (full == 0 || full >= 4)) ? full * slots : N;
+    p.n_main = (teams && rem > 0 && rem <= 2 * gx) ? full * slots : N;
     return p;
 }
 
@@ -684,7 +904,7 @@ hipError_t launch_coarse_to_fine(const CoarseToFineLaunch& a, hipStream_t stream
     const ScorePlan p = plan_score_launch(c.B, c.N, c.num_cu, c.spare_cu, teams);
     // stage 1 runs on the SAME grid: its remainder rule with stage 0's gx
     const int64_t slots = 8 * (int64_t)p.gx, full2 = a.N2 / slots, rem2 = a.N2 - full2 * slots;
-    const int64_t n_main2 = (teams && rem2 > 0 && rem2 <= 2 * (int64_t)p.gx && (full2 == 0 || full2 >= 4)) ? full2 * slots : a.N2;
+    const int64_t n_main2 = (teams && rem2 > 0 && rem2 <= 2 * (int64_t)p.gx) ? full2 * slots : a.N2;
     // every workgroup must be resident for the meeting point: at most one per CU (159.5 KiB of LDS each)
     if ((int64_t)p.gx * p.gy > c.num_cu) return hipErrorInvalidConfiguration;
     C2fArgs cf;

@@ -87,15 +87,20 @@ __device__ __forceinline__ void stage_w1_split(f16x8* table, const float* __rest
 }
 
 // Source volume -> LDS, prescaled per sample; returns the exponent used (512 threads, 16 values each).
-__device__ __forceinline__ int stage_src_volume_scaled(float* srcT, const float* __restrict__ vol, float* scratch, int tid)
+// `bad` (per thread): one of this thread's voxels is NaN / inf.  Such a sample is not scaled (the maximum is taken to be
+// inf -- v_max would DROP a NaN) and leaves the split arithmetic for the exact fp32 path (ahv_exact.h), which reads this image.
+__device__ __forceinline__ int stage_src_volume_scaled(float* srcT, const float* __restrict__ vol, float* scratch, int tid, bool& bad)
 {
     float x[16];
     float m = 0.0f;
+    bad = false;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         x[k] = vol[tid + 512 * k];
         m = fmaxf(m, fabsf(x[k]));
+        bad = bad || __builtin_amdgcn_classf(x[k], 0x207);  // sNaN | qNaN | -inf | +inf
     }
+    if (bad) m = __builtin_inff();
     const int e = split_prescale_exp(block_absmax(m, scratch, tid));
     const float scale = ldexpf(1.0f, e);
 #pragma unroll

@@ -223,7 +223,19 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
                                         split_f16, clock_stamps, no_teams=no_teams, spare_cus=spare_cus)
 
 
-@torch.no_grad()
+def score_plan(B: int, N: int, no_teams: bool = False, split_f16: bool = False, spare_cus: int = 0):
+    """How a launch of B samples x N hypotheses is laid out on the current device (``ahv_diag_score_plan``, pure host
+    arithmetic): ``(gx, gy, n_main)`` -- the persistent grid and how many hypotheses of each sample go to single waves; the
+    rest, ``[n_main, N)``, go to teams of four.  Scores do not depend on it (a team's score is a lone wave's bit for bit)."""
+    import ctypes
+    flags = ((_lib.AHV_SCORE_NO_TEAMS if no_teams else 0) | (_lib.AHV_SCORE_SPLIT_F16 if split_f16 else 0) |
+             (int(spare_cus) << _lib.AHV_SCORE_SPARE_CUS_SHIFT))
+    gx, gy, n_main = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    _lib.check(_lib.load().ahv_diag_score_plan(B, N, flags, ctypes.byref(gx), ctypes.byref(gy), ctypes.byref(n_main)),
+               "ahv_diag_score_plan")
+    return gx.value, gy.value, n_main.value
+
+
 def verify_pair(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor,
                 b2: torch.Tensor, n_offset: int = 0, want_scores: bool = True, best_key: torch.Tensor | None = None,
                 reset_best: bool | None = None, split_f16: bool | None = None, want_feat_tgt: bool = False,
@@ -233,17 +245,20 @@ def verify_pair(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, W
     ``score_hypotheses`` with the target VOLUME ``vol_tgt (B,16,8,8,8)`` in place of ``feat_tgt``.  Returns
     ``(scores (B,N) or None, best_key (B,) int64)`` and, with ``want_feat_tgt``, the target features ``(B,32,64)`` as
     third element (always materialised for the split-f16 kernel, which runs forward_3d2d as a launch of its own).
-    Inference only (no autograd edge)."""
+    Inference only (no autograd edge): with autograd recording and an input that requires grad it REFUSES (the check runs
+    before the no_grad block -- as a decorator the block hid the recording state from the check, round 4) -- use
+    ``forward_3d2d`` + ``score_hypotheses``, which carry the HIP backward."""
     _refuse_grad("verify_pair", vol_src, vol_tgt, W1, W2, b2)
     if vol_tgt.dim() != 5 or tuple(vol_tgt.shape) != tuple(vol_src.shape):
         raise RuntimeError("vol_tgt must have vol_src's shape (B,16,8,8,8), got %s" % (tuple(vol_tgt.shape),))
     split = bool(_SPLIT_F16.get() if split_f16 is None else split_f16)
-    feat = None
-    if want_feat_tgt or split:
-        feat = torch.empty((vol_src.shape[0], 32, 64), dtype=torch.float32, device=vol_src.device)
-    scores, key = _score_hypotheses_nograd(vol_src, vol_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best,
-                                           split, clock_stamps, no_teams=no_teams, spare_cus=spare_cus, tgt_is_volume=True,
-                                           feat_tgt_out=feat)
+    with torch.no_grad():
+        feat = None
+        if want_feat_tgt or split:
+            feat = torch.empty((vol_src.shape[0], 32, 64), dtype=torch.float32, device=vol_src.device)
+        scores, key = _score_hypotheses_nograd(vol_src, vol_tgt, R, W1, W2, b2, n_offset, want_scores, best_key, reset_best,
+                                               split, clock_stamps, no_teams=no_teams, spare_cus=spare_cus,
+                                               tgt_is_volume=True, feat_tgt_out=feat)
     return (scores, key, feat) if want_feat_tgt else (scores, key)
 
 
@@ -484,7 +499,6 @@ class CoarseToFineState:
         return bool(self.sync[-1].item() != 0)
 
 
-@torch.no_grad()
 def coarse_to_fine(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, D: torch.Tensor, W1: torch.Tensor,
                    W2: torch.Tensor, b2: torch.Tensor, state: CoarseToFineState | None = None, want_scores: bool = False,
                    want_feat_tgt: bool = False, no_teams: bool = False, spare_cus: int = 0, out: dict | None = None) -> dict:
@@ -494,8 +508,14 @@ def coarse_to_fine(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor
     ``R_pred (B,3,3)``, ``coarse_score, coarse_idx`` and, on request, ``coarse_scores (B,N)``, ``fine_scores (B,N2)``,
     ``feat_tgt (B,32,64)``.  ``out``: a dict from an earlier call whose tensors are written again (static buffers for
     graph capture).  With the hypothesis sets sharded over ranks use ``refine.CoarseToFine`` (five launches, two
-    all-reduces).  Inference only."""
+    all-reduces).  Inference only: refuses inputs that require grad while autograd is recording."""
     _refuse_grad("coarse_to_fine", vol_src, vol_tgt, W1, W2, b2)
+    with torch.no_grad():
+        return _coarse_to_fine_nograd(vol_src, vol_tgt, R, D, W1, W2, b2, state, want_scores, want_feat_tgt, no_teams,
+                                      spare_cus, out)
+
+
+def _coarse_to_fine_nograd(vol_src, vol_tgt, R, D, W1, W2, b2, state, want_scores, want_feat_tgt, no_teams, spare_cus, out):
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL or tuple(vol_tgt.shape) != tuple(vol_src.shape):
         raise RuntimeError("vol_src and vol_tgt must be (B,16,8,8,8), got %s and %s" % (tuple(vol_src.shape), tuple(vol_tgt.shape)))
     B = vol_src.shape[0]

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- rotation hypotheses scored per second (BASELINE.json metric) on MI355X.
 
-One "step" = the reference's per-pair hot loop (test_co3d.py:137-146) for ONE synthetic image
-pair with N_hyp = 50 000 hypotheses on each GPU (BASELINE.json configs[1]):
+One "step" = the reference's per-pair hot loop (test_co3d.py:137-146) for ONE synthetic image pair against the SAME
+N_hyp = 50 000 Haar hypotheses whatever the number of GPUs (BASELINE.json configs[1]; the metric is quoted "at 1/2/4/8
+MI355X": strong scaling -- the hypothesis axis is cut into contiguous shards, rank r scores [lo_r, hi_r) with n_offset = lo_r):
     forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max   ONE launch, ahv_verify_pair_f32
                                                                           (test_co3d.py:137-145)
-    [N>1: all-reduce(MAX) of the packed int64 key over RCCL, asynchronous, finalized two steps later]
-    decode the key, gather R_pred = proposals[idx], hand the key back empty   ONE launch   (test_co3d.py:145-146)
-Inputs are resident in HBM before the timed region.  N > 1 shards the hypothesis axis: every
-rank scores its own 50 000 (weak scaling: `value`), the only exchange is the 8-byte key all-reduce.  The same run
-also times a FIXED total split over the ranks (`strong_scaling`: 50 000 hypotheses at B = 1, and BASELINE.json
-configs[3], B = 32 x 50 000).
+    [N > 1: all-reduce(MAX) of the packed int64 keys over RCCL -- the keys of 8 steps per collective, in stream order]
+    decode the keys, gather R_pred = proposals[idx], hand the keys back empty   ONE launch per collective (test_co3d.py:145-146)
+Inputs are resident in HBM before the timed region.  `value` = 50 000 x steps / time: the whole job's hypotheses per
+second ("scaling": "strong").  The same run also times, as named secondary records: the per-step-collective cadence
+(one all-reduce + select per step), weak scaling (50 000 hypotheses PER RANK), BASELINE.json configs[3] (B = 32 x 50 000
+split over the ranks), a two-stream variant of the step loop (independent pairs overlap one step's drain with the next one's
+ramp) and, at one rank, the shard timings that say what an N-GPU run can reach (`predicted_strong_scaling`).
 
 Launching: `python3 bench.py --gpus N` starts its own N worker processes (one per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE anything touches a GPU and relays rank 0's JSON
@@ -56,9 +58,9 @@ def parse_args():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="minimum length of the untimed, time-based pre-warm (the same step, looped until the chip's "
                          "clock has settled: >= this many ms AND three consecutive kernel times within 1 %%; 0 disables)")
-    ap.add_argument("--skip-strong-scaling", action="store_true",
-                    help="leave out the strong_scaling legs (profiling runs: they launch the same kernel at B = 32, which "
-                         "would mix into rocprofv3's per-kernel averages)")
+    ap.add_argument("--skip-secondary", "--skip-strong-scaling", dest="skip_secondary", action="store_true",
+                    help="leave out the secondary records (profiling runs: they launch the same kernel at other shapes, "
+                         "which would mix into rocprofv3's per-kernel averages)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -116,7 +118,7 @@ def synth_inputs(ahv, dev, rank):
     W1 = (torch.rand(32, 384, generator=g) * 2 - 1) / np.sqrt(384.0)
     W2 = (torch.rand(32, 32, generator=g) * 2 - 1) / np.sqrt(32.0)
     b2 = (torch.rand(32, generator=g) * 2 - 1) / np.sqrt(32.0)
-    R = torch.from_numpy(ahv.rotations.haar_rotations_np(N_HYP, seed=1000 + rank))
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(N_HYP, seed=1000))  # ONE set: every rank scores its shard of it
     return [t.to(dev).contiguous() for t in (vol_src, vol_tgt, W1, W2, b2, R)]
 
 
@@ -218,75 +220,90 @@ def cpu_baseline(vol_src, vol_tgt, W1, W2, b2, R):
     return res, scores
 
 
+def kernel_source_sha() -> str:
+    """SHA-256 over the sources the fused scorer is compiled from: profiles/traffic.json records the value its PMC passes
+    were taken at, and a `traffic` figure from another kernel is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("ahv_score.hip", "ahv_device.h", "ahv_dual.h", "ahv_team.h", "ahv_exact.h", "ahv_split.h"):
+        with open(os.path.join(REPO, "3dahv_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 class VerifyLoop:
     """One rank's verify steps on a fixed workload (the reference's per-pair hot loop, test_co3d.py:137-146):
         step i   = ONE fused launch: forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max into its key slot
         finalize = ONE launch per group of `group` steps: decode the keys, gather R_pred = proposals[idx], hand the keys
                    back EMPTY (single process: group = 1, i.e. one select per step)
-    With a process group the keys of `group` consecutive steps travel in ONE all-reduce(MAX) of group * B int64 words (the
-    bucketing every data-parallel exchange uses: what a collective costs beside a 0.7-ms kernel is its fixed part -- the
-    event packets torch puts around it, 29 us measured with a one-rank RCCL group, profiles/r04a_* -- not its 8 bytes),
-    either asynchronously on RCCL's stream and consumed `lag` groups later, or (`sync`) in stream order."""
-    RING = 4
+    With a process group the keys of `group` consecutive steps travel in ONE all-reduce(MAX) of group * B int64 words, issued
+    in stream order (what a collective costs beside a 0.1 ... 0.7-ms kernel is its fixed part -- the event packets torch
+    puts around it, 17 ... 36 us with a one-rank RCCL group, profiles/r04ab_process_group_variants.jsonl -- not its bytes).
+    `lanes` > 1: the groups alternate between that many streams, each with its own key buffer and (under a process group)
+    its own communicator, so that nothing orders one lane behind the other: independent pairs then overlap one step's
+    drain -- the wait for the slowest workgroup, the launch gap, the next prologue -- with the next step's hypotheses."""
 
-    def __init__(self, ops, dist, dev, vol_src, vol_tgt, R_local, head, n_offset, use_pg, group, lag, sync, spare_cus, split):
+    def __init__(self, ops, dist, dev, vol_src, vol_tgt, R_local, head, n_offset, use_pg, group, split, lanes=1):
         import torch
         self.ops, self.dist, self.use_pg = ops, dist, use_pg
-        self.group, self.sync = max(1, group), sync
-        self.lag = lag if (use_pg and not sync) else 0
-        assert 0 <= self.lag < self.RING
+        self.group = max(1, group)
         self.vs, self.vt, self.R, self.head, self.n_offset = vol_src, vol_tgt, R_local, head, n_offset
-        self.spare, self.split = spare_cus, split
+        self.split = split
         self.B = vol_src.shape[0]
-        self.keys = torch.full((self.RING, self.group, self.B), -(1 << 63), dtype=torch.int64, device=dev)
-        self.pending, self.out, self.done = {}, {}, -1
+        self.lanes = []
+        for k in range(max(1, lanes)):
+            lane = {"keys": torch.full((self.group, self.B), -(1 << 63), dtype=torch.int64, device=dev),
+                    "stream": None, "pg": None, "out": None}
+            if lanes > 1:
+                lane["stream"] = torch.cuda.Stream(device=dev)
+                lane["stream"].wait_stream(torch.cuda.current_stream(dev))  # the inputs above are ready for it
+                if use_pg and k > 0:
+                    lane["pg"] = dist.new_group(backend=dist.get_backend())  # its own communicator: no order between lanes
+            self.lanes.append(lane)
+        self.out = {}
 
-    def finalize(self, g):
-        """Group g: wait for its collective (stream-level, the host does not block), then ONE select for all its steps."""
-        keys = self.keys[g % self.RING]
-        work = self.pending.pop(g, None)
-        if work is not None:
-            work.wait()
+    def _finalize(self, lane):
+        """In the lane's stream order: (all-reduce of the group's keys,) ONE select for all its steps."""
+        keys = lane["keys"]
+        if self.use_pg:
+            self.dist.all_reduce(keys, op=self.dist.ReduceOp.MAX, group=lane["pg"])
         # with sharding the owner rank holds the winning row, the others get zeros
         best, idx, R_pred = self.ops.select_rotation(keys.view(-1), self.R, n_offset=self.n_offset, reset_key=True)
-        B = self.B  # results of the group's LAST step (empty slots of a partial group decode to -inf / -1 in front of them)
-        self.out["group_best"], self.out["group_idx"] = best.view(self.group, B), idx.view(self.group, B)
-        self.out["group_R_pred"] = R_pred.view(self.group, B, 3, 3)
-        self.done = g
-
-    def _result_of(self, step):
-        j = step % self.group
-        return self.out["group_best"][j], self.out["group_idx"][j], self.out["group_R_pred"][j]
-
-    def step(self, i, ev=None, stamps=None, last=False):
-        g, j = i // self.group, i % self.group
-        key = self.keys[g % self.RING, j]  # EMPTY: reset by the select that consumed it
-        if ev is not None:
-            ev[0].record()
-        # `stamps` given: the same kernel also writes every workgroup's s_memtime / s_memrealtime pair (shader clock)
-        self.ops.verify_pair(self.vs, self.vt, self.R, *self.head, n_offset=self.n_offset, want_scores=False, best_key=key,
-                             reset_best=False, split_f16=self.split, clock_stamps=stamps, spare_cus=self.spare)
-        if ev is not None:
-            ev[1].record()
-        if j == self.group - 1 or last:  # the group is complete (or the run ends inside it)
-            if self.use_pg:
-                w = self.dist.all_reduce(self.keys[g % self.RING], op=self.dist.ReduceOp.MAX, async_op=not self.sync)
-                if not self.sync:
-                    self.pending[g] = w
-            if g - self.lag >= 0 and g - self.lag > self.done:
-                self.finalize(g - self.lag)
+        B = self.B  # (empty slots of a partial group decode to -inf / -1)
+        lane["out"] = (best.view(self.group, B), idx.view(self.group, B), R_pred.view(self.group, B, 3, 3))
 
     def run(self, steps, events=None, stamps=None):
-        """`steps` steps, every one finalized on return (the stream is NOT synchronised).  `events`: {step: event pair} for
-        the launches to bracket with HIP events (a SAMPLE: an event record idles the queue for ~6 us, tools/summarize_timeline.py)."""
-        self.done = -1
+        """`steps` steps, every one finalized on return (the streams are NOT synchronised).  `events`: {step: event pair} for
+        the launches to bracket with HIP events on the launch's own stream (a SAMPLE: a record idles the queue ~6 us)."""
+        import torch
         events = events or {}
+        multi = len(self.lanes) > 1
+        main = torch.cuda.current_stream() if multi else None
+        lane = self.lanes[0]
         for i in range(steps):
-            self.step(i, events.get(i), None if stamps is None else stamps[i], last=(i == steps - 1))
-        last_group = (steps - 1) // self.group
-        for g in range(max(self.done + 1, 0), last_group + 1):
-            self.finalize(g)
-        self.out["best"], self.out["idx"], self.out["R_pred"] = self._result_of(steps - 1)
+            g, j = divmod(i, self.group)
+            if j == 0:
+                lane = self.lanes[g % len(self.lanes)]
+                if multi:
+                    torch.cuda.set_stream(lane["stream"])
+            ev = events.get(i)
+            if ev is not None:
+                ev[0].record()
+            # `stamps` given: the same kernel also writes every workgroup's s_memtime / s_memrealtime pair (shader clock)
+            self.ops.verify_pair(self.vs, self.vt, self.R, *self.head, n_offset=self.n_offset, want_scores=False,
+                                 best_key=lane["keys"][j], reset_best=False, split_f16=self.split,
+                                 clock_stamps=None if stamps is None else stamps[i])
+            if ev is not None:
+                ev[1].record()
+            if j == self.group - 1 or i == steps - 1:  # the group is complete (or the run ends inside it)
+                self._finalize(lane)
+        if multi:
+            torch.cuda.set_stream(main)
+            for ln in self.lanes:
+                main.wait_stream(ln["stream"])
+        j = (steps - 1) % self.group
+        best, idx, R_pred = lane["out"]
+        self.out = {"best": best[j], "idx": idx[j], "R_pred": R_pred[j]}
 
 
 def worker(args):
@@ -331,19 +348,16 @@ def worker(args):
     ops, adist = ahv.ops, ahv.dist
     lib = ahv._lib.load()  # fails loudly without the HIP library
     split = bool(args.split_f16)
-    # Under a process group the keys of `group` steps share one all-reduce, issued in stream order (default) or
-    # asynchronously on RCCL's stream and consumed `lag` groups later (AHV_BENCH_COLLECTIVE=async: every cross-stream event
-    # wait costs the compute queue ~30 us here, profiles/r04_forced_pg_timeline.txt); the scorer can leave `spare` CUs
-    # without a workgroup for a concurrent kernel (measured: costs 1.4 % at 2 and buys nothing, so 0).  DESIGN.md section 6.
+    # Under a process group the keys of `group` steps share one all-reduce, issued in stream order (DESIGN.md section 6:
+    # what a collective costs is the event packets around it, not its bytes; the per-step cadence is timed beside it).
     group = int(os.environ.get("AHV_BENCH_STEPS_PER_COLLECTIVE", "8" if use_pg else "1"))
-    lag = int(os.environ.get("AHV_BENCH_FINALIZE_LAG", "1"))
-    sync = os.environ.get("AHV_BENCH_COLLECTIVE", "sync") == "sync"
-    spare = int(os.environ.get("AHV_BENCH_SPARE_CUS", "0"))
 
-    vol_src, vol_tgt, W1, W2, b2, R = synth_inputs(ahv, dev, rank)
+    vol_src, vol_tgt, W1, W2, b2, R_all = synth_inputs(ahv, dev, rank)
     head = (W1, W2, b2)
-    n_offset = rank * N_HYP
-    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, lag, sync, spare, split)
+    # strong scaling: ONE set of 50 000 hypotheses, this rank's contiguous shard of it
+    lo, hi = adist.shard_range(N_HYP, rank, world)
+    R, n_offset, n_local = R_all[lo:hi].contiguous(), lo, hi - lo
+    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, split)
     ncu = lib.ahv_device_cu_count()
 
     def barrier():
@@ -448,73 +462,125 @@ def worker(args):
             if len(row):
                 loop_ms.append(float(row[:, 3].max() - row[:, 1].min()) * 1e-5)
 
-        # correctness of what was timed: the key equals torch.max over the materialised scores (all ranks)
-        scores, key = ops.verify_pair(vol_src, vol_tgt, R, *head, n_offset=n_offset, split_f16=split, spare_cus=loop.spare)
+        # correctness of what was timed: the merged key equals torch.max over the materialised scores of ALL ranks, and
+        # (sharded runs) the winner of the UNSHARDED set scored on this rank alone -- exactly: a score does not depend on
+        # how the set is cut (a team's score is a lone wave's bit for bit, csrc/ahv_team.h)
+        scores, key = ops.verify_pair(vol_src, vol_tgt, R, *head, n_offset=n_offset, split_f16=split)
         gbest = global_best(scores, n_offset)[0]
         assert int(out["idx"].item()) == int(gbest[1].item()), (out["idx"], gbest)
         assert float(out["best"].item()) == float(gbest[0].item())
+        if world > 1:
+            s_all, k_all = ops.verify_pair(vol_src, vol_tgt, R_all, *head, split_f16=split)
+            assert torch.equal(s_all[:, lo:hi], scores)
+            v_all, i_all = torch.max(s_all, dim=1)
+            assert int(out["idx"].item()) == int(i_all.item()) and float(out["best"].item()) == float(v_all.item())
 
-        # ---- strong scaling, same run: a FIXED total split over the ranks (BASELINE.json metric "at 1/2/4/8"; configs[3])
-        def strong(vs, vt, R_all, steps, warmup):
-            n_total = R_all.shape[0]
-            lo, hi = adist.shard_range(n_total, rank, world)
-            lp = VerifyLoop(ops, dist, dev, vs, vt, R_all[lo:hi].contiguous(), head, lo, use_pg, group, lag, sync, spare, split)
+        # ---- secondary records, same run, same timing (barriers, max over ranks)
+        def leg(vs, vt, R_set, steps, warmup, grp=None, lanes=1, shard=True, offset=None):
+            """`steps` verify steps of (vs, vt) against R_set -- sharded over the ranks (shard=True: a FIXED total) or whole
+            on every rank -- timed like the headline."""
+            n_total = R_set.shape[0]
+            a, b = adist.shard_range(n_total, rank, world) if shard else (0, n_total)
+            off = a if offset is None else offset
+            lp = VerifyLoop(ops, dist, dev, vs, vt, R_set[a:b].contiguous(), head, off, use_pg, group if grp is None else grp,
+                            split, lanes=lanes)
             t = timed(lp, steps, warmup)
-            # the merged winner == the winner of the unsharded set scored on this rank alone
-            s_all, _ = ops.verify_pair(vs, vt, R_all, *head, split_f16=split, no_teams=True)
-            v, ix = torch.max(s_all, dim=1)
-            assert torch.equal(lp.out["idx"], ix), (lp.out["idx"], ix)
-            assert (lp.out["best"] - v).abs().max().item() <= 5e-6  # teams may score a shard's remainder: equal to rounding
             B = vs.shape[0]
-            return {"n_hyp_total": n_total, "B": B, "n_hyp_per_rank": hi - lo, "steps": steps, "warmup": warmup,
-                    "ms_per_step": t / steps * 1e3, "hypotheses_per_s": B * n_total * steps / t,
-                    "pairs_per_s": B * steps / t}
+            total = n_total if shard else n_total * world
+            return lp, {"n_hyp_total": total, "B": B, "n_hyp_per_rank": b - a, "steps": steps, "warmup": warmup,
+                        "steps_per_collective": lp.group if use_pg else None, "lanes": lanes,
+                        "ms_per_step": t / steps * 1e3, "hypotheses_per_s": B * total * steps / t, "pairs_per_s": B * steps / t}
 
-        R_all = torch.from_numpy(ahv.rotations.haar_rotations_np(N_HYP, seed=1000)).to(dev)
+        sec_steps = max(24, min(args.steps, 96))
         g = torch.Generator().manual_seed(5)
         vs32 = (torch.randn(32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
         vt32 = (torch.randn(32, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
-        strong_scaling = None if args.skip_strong_scaling else {
-            "note": "a fixed total split over the ranks (value / ms_per_step above are WEAK scaling: 50 000 hypotheses per "
-                    "rank); same step, same collectives, timed between barriers, max over ranks",
-            # 48 untimed steps first (33 ms of the same kernel): the checks in front of this leg let the clock sag
-            "n50k_b1": strong(vol_src, vol_tgt, R_all, max(20, min(args.steps, 100)), 48),
-            "configs3_b32_n50k": strong(vs32, vt32, R_all, 5, 2),
-        }
+        secondary = None
+        if not args.skip_secondary:
+            secondary = {"note": "same step, same collectives, timed between barriers, max over ranks; 48 untimed steps in "
+                                 "front of each leg (the checks before it let the clock sag)"}
+            # the per-step cadence: ONE all-reduce + ONE select per verify step (test_co3d.py:145-146 as written)
+            lp1, secondary["n50k_b1_collective_per_step"] = leg(vol_src, vol_tgt, R_all, sec_steps, 48, grp=1)
+            assert int(lp1.out["idx"].item()) == int(out["idx"].item())
+            # weak scaling: 50 000 hypotheses PER RANK (rounds 1-4's headline), each rank its own set
+            R_own = torch.from_numpy(ahv.rotations.haar_rotations_np(N_HYP, seed=1000 + rank)).to(dev)
+            _, secondary["weak_n50k_per_rank_b1"] = leg(vol_src, vol_tgt, R_own, sec_steps, 48, shard=False, offset=rank * N_HYP)
+            # BASELINE.json configs[3]: B = 32 pairs x 50 000 shared hypotheses split over the ranks
+            lp3, secondary["configs3_b32_n50k"] = leg(vs32, vt32, R_all, 5, 2)
+            s32, _ = ops.verify_pair(vs32, vt32, R_all, *head, split_f16=split)
+            assert torch.equal(lp3.out["idx"], torch.max(s32, dim=1)[1])
+            del s32
+            # two lanes: independent pairs on two streams (under a process group: two communicators) -- what a loop over
+            # many pairs gets when one step's drain overlaps the next step's ramp.  Single process by default; with a
+            # process group only on request (AHV_BENCH_TWO_LANES_PG=1): never a new code path in somebody else's 8-GPU run.
+            if not use_pg or os.environ.get("AHV_BENCH_TWO_LANES_PG", "0") == "1":
+                lp2, secondary["n50k_b1_two_lanes"] = leg(vol_src, vol_tgt, R_all, 2 * sec_steps, 48, grp=max(group, 4), lanes=2)
+                assert int(lp2.out["idx"].item()) == int(out["idx"].item())
+            if world == 1:
+                # what a strong-scaling run can reach, from this GPU alone: the shard a rank of an n-GPU run scores per
+                # step (contiguous 1/n of the same set, n_offset, the multi-rank cadence of 8 steps per select, no
+                # collective), one lane and two
+                pred = {"note": "t(50 000) / (n * t(50 000 / n)) on ONE GPU, 8 steps per select, no collective: the efficiency an "
+                                "n-GPU strong-scaling run can reach before link latency"}
+                t_ref = {}
+                for lanes in (1, 2):
+                    _, r = leg(vol_src, vol_tgt, R_all, sec_steps if lanes == 1 else 2 * sec_steps, 48, grp=8, lanes=lanes)
+                    t_ref[lanes] = r["ms_per_step"]
+                for n in (2, 4, 8):
+                    a, b = adist.shard_range(N_HYP, n - 1, n)   # the last rank's shard (offsets included)
+                    row = {"n_hyp_per_rank": b - a}
+                    for lanes in (1, 2):
+                        _, r = leg(vol_src, vol_tgt, R_all[a:b], 2 * sec_steps, 48, grp=8, lanes=lanes, offset=a)
+                        row["ms_per_step" + ("" if lanes == 1 else "_two_lanes")] = r["ms_per_step"]
+                        row["efficiency" + ("" if lanes == 1 else "_two_lanes")] = t_ref[lanes] / (n * r["ms_per_step"])
+                    pred["n_gpus_%d" % n] = row
+                pred["ms_per_step_n50k"] = t_ref[1]
+                pred["ms_per_step_n50k_two_lanes"] = t_ref[2]
+                secondary["predicted_strong_scaling"] = pred
         feat_tgt = ops.forward_3d2d(vol_tgt, W1, W2, b2)  # for the split-f16 side report below
     gc.enable()
 
     if rank == 0:
-        total_hyp = N_HYP * world * args.steps
-        value = total_hyp / dt
-        achieved = FLOPS_PER_HYP * N_HYP / (kern_ms * 1e-3) / 1e12
-        # HBM bytes per launch: NOT measured in this run (PMC passes need rocprofv3); replayed from the committed
-        # summary of tools/profile_bench.sh on the same command, with its source named.
+        value = N_HYP * args.steps / dt                      # the whole job: ONE set of 50 000 hypotheses per step
+        achieved = FLOPS_PER_HYP * n_local / (kern_ms * 1e-3) / 1e12   # the timed kernel scores this rank's shard
+        # HBM bytes per launch: NOT measured in this run (PMC passes need rocprofv3) -- the committed figure of
+        # tools/profile_bench.sh on the same command, reported only while it describes THIS kernel and THIS launch shape:
+        # the hash of the scorer's sources must equal the one recorded with the counters (else null + the reason), the
+        # launch must be the 50 000-hypothesis one the counters were taken on, and the figure must cover at least what
+        # the launch has to read (a WRITE_SIZE / FETCH_SIZE mix-up or a unit slip would fall below it).
         traffic, traffic_src = None, None
         tpath = os.path.join(REPO, TRAFFIC_JSON)
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj.get("fused_hbm_bytes_per_launch")
-            traffic_src = "%s (rocprofv3 --pmc passes of %s; not measured in this run)" % (
-                TRAFFIC_JSON, tj.get("source", "an earlier bench.py run"))
+            sha = kernel_source_sha()
+            if tj.get("kernel_src_sha") != sha:
+                traffic_src = {"stale": "the scorer's sources changed since the PMC passes of %s (sha %s..., now %s...): "
+                                        "re-run tools/profile_bench.sh" % (tj.get("source"), str(tj.get("kernel_src_sha"))[:12], sha[:12])}
+            elif n_local != N_HYP:
+                traffic_src = {"not_applicable": "counters were taken on the 50 000-hypothesis launch; this rank scores %d" % n_local}
+            else:
+                traffic = tj.get("fused_hbm_bytes_per_launch")
+                assert traffic >= HBM_BYTES_PER_HYP * N_HYP, "traffic.json below the algorithmic bytes: wrong counter or unit"
+                traffic_src = {"bytes": traffic, "source": tj.get("source"), "source_commit": tj.get("source_commit"),
+                               "kernel_src_sha": sha, "formula": tj.get("formula"),
+                               "note": "rocprofv3 --pmc passes of the same command; not measured in this run"}
         kname = "score_hypotheses_dual_kernel<false, true>"
         res = {
             "metric": "rotation hypotheses scored/sec (B=1)", "value": value, "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", **pre,
-            "config": {"workload": "CO3D pair (BASELINE.json configs[1]): B=1, N_hyp=50000 Haar rotations per GPU, "
-                                   "source volume 16x8x8x8 (P=512 voxel sites x 16 ch), head 384->32->32, 64 positions",
-                       "n_hyp_per_gpu": N_HYP, "n_hyp_total": N_HYP * world,
+            "config": {"workload": "CO3D pair (BASELINE.json configs[1]): B=1, ONE set of N_hyp=50000 Haar rotations split "
+                                   "over the GPUs (contiguous shards, n_offset), source volume 16x8x8x8 (P=512 voxel sites x "
+                                   "16 ch), head 384->32->32, 64 positions",
+                       "n_hyp_per_gpu": n_local, "n_hyp_total": N_HYP,
                        "parallelism": "hypothesis axis sharded x%d, 8-byte key all-reduce(max)" % world,
                        "backend": "single process" if not use_pg else ("rccl" if args.backend == "nccl" else args.backend),
                        "step": "ONE fused launch (forward_3d2d(tgt) + rotate + forward_3d2d + score + arg-max: "
                                "ahv_verify_pair_f32)%s + ONE select launch per %d step(s) (decode + gather R_pred + key reset)" % (
-                                   " + ONE all-reduce(MAX) of the int64 keys of %d steps (%s), %d CU(s) left free" % (
-                                       loop.group, "in stream order" if loop.sync else
-                                       "asynchronous, consumed %d group(s) later" % loop.lag, loop.spare) if use_pg else "",
-                                   loop.group),
+                                   " + ONE all-reduce(MAX) of the int64 keys of %d steps, in stream order" % loop.group
+                                   if use_pg else "", loop.group),
                        "steps_per_collective": loop.group if use_pg else None},
             # what the timed region computed (asserted above against torch.max over the materialised scores of
             # all ranks): lets a forced-process-group run be compared with a single-process run
@@ -530,18 +596,18 @@ def worker(args):
                          "hypothesis_loop_ms_all_launches_median": float(np.median(loop_ms)) if loop_ms else None,
                          "hypothesis_loop_ms_is": "in-kernel s_memrealtime stamps of ALL %d timed launches: first workgroup "
                                                   "entering its hypothesis loop -> last leaving it" % args.steps,
-                         "frac_at_median": FLOPS_PER_HYP * N_HYP / (float(np.median(kern_list)) * 1e-3) / 1e12
+                         "frac_at_median": FLOPS_PER_HYP * n_local / (float(np.median(kern_list)) * 1e-3) / 1e12
                                            / PEAK_F32_MFMA_TFLOPS,
-                         "algorithmic_flops_per_launch": FLOPS_PER_HYP * N_HYP,
-                         "algorithmic_flops_note": "50 000 hypotheses x 1 839 104; the in-launch target features (one more "
-                                                   "forward_3d2d per workgroup, ~0.5 %% extra work) are NOT counted",
-                         "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * N_HYP,
+                         "algorithmic_flops_per_launch": FLOPS_PER_HYP * n_local,
+                         "algorithmic_flops_note": "%d hypotheses (this rank's shard) x 1 839 104; the in-launch target "
+                                                   "features (one more forward_3d2d per workgroup) are NOT counted" % n_local,
+                         "algorithmic_hbm_bytes_per_launch": HBM_BYTES_PER_HYP * n_local,
                          "shader_clock_ghz": clock_ghz,
                          "shader_clock_source": "s_memtime / s_memrealtime stamps of the TIMED launches (all %d, all "
                                                 "workgroups, median)" % args.steps,
                          "frac_at_delivered_clock": (achieved / (PEAK_F32_MFMA_TFLOPS * clock_ghz / MAX_CLOCK_GHZ)
                                                      if clock_ghz else None)},
-            "strong_scaling": strong_scaling,
+            "secondary": secondary,
         }
         if split:  # opt-in kernel: priced against the f16 matrix peak (16 x the fp32 one)
             res["dtype"] = "f16 hi/lo split products, f32 accumulate"
@@ -556,7 +622,7 @@ def worker(args):
             with torch.no_grad():
                 s4, k4 = ops.score_hypotheses(vol_src, feat_tgt, R, W1, W2, b2, split_f16=True)
 
-                k0 = loop.keys[0, 0]
+                k0 = loop.lanes[0]["keys"][0]
 
                 def split_launch(ev=None):
                     if ev is not None:

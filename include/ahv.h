@@ -81,19 +81,15 @@ extern "C" {
                                  * hence opt-in.  The blend, normalisation and score stay fp32.  2.1x faster.  The
                                  * selector is per call: there is no process-wide kernel switch. */
 
-#define AHV_SCORE_NO_TEAMS 4u   /* every hypothesis by ONE wave.  Default: the remainder of a launch that would fill less than
-                                 * a quarter of the device's wave slots is scored by teams of four waves (a quarter of the
-                                 * volume each): ~4x lower latency for those hypotheses, and sums associated differently, so
-                                 * that a hypothesis' score may differ in the last bit or two (~1e-7) from what a lone wave
-                                 * computes -- i.e. depend, to rounding, on N and on the hypothesis' position in the set.
-                                 * With this flag a score is a function of (volumes, weights, R_n) alone, bit for bit. */
-#define AHV_SCORE_SPARE_CUS_SHIFT 8
-#define AHV_SCORE_SPARE_CUS_MASK 0xFF00u
-#define AHV_SCORE_SPARE_CUS(k) (((unsigned)(k) << AHV_SCORE_SPARE_CUS_SHIFT) & AHV_SCORE_SPARE_CUS_MASK)
-                                /* leave k compute units without a workgroup of the persistent grid (default 0: one
-                                 * workgroup per CU, 159.5 KiB of LDS each, so NOTHING else fits on the device while the
-                                 * scorer runs).  A caller that overlaps a small kernel of another stream with the scorer --
-                                 * the RCCL all-reduce of the previous step's key -- reserves a CU or two for it here. */
+#define AHV_SCORE_NO_TEAMS 4u   /* every hypothesis by ONE wave.  Default: a remainder of the launch (at most two hypotheses
+                                 * per workgroup beyond its full rounds of eight) is scored by teams of four waves, a quarter
+                                 * of the volume each, ahead of the main rounds (csrc/ahv_team.h).  A team runs the lone
+                                 * wave's accumulation chains tile by tile and associates the score's sums the same way: its
+                                 * score is the lone wave's BIT FOR BIT.  The flag is therefore a scheduling knob only -- with
+                                 * or without it a score is a function of (volumes, weights, R_n) alone, independent of N, of
+                                 * n_offset and of how a set is sharded (tests/test_gpu_parity.py::
+                                 * test_team_scores_are_bit_identical; ABI <= 2.1 exchanged partial sums: 1e-7 apart). */
+/* (bits 8-15: AHV_SCORE_SPARE_CUS(k), a measurement knob declared in ahv_diag.h) */
 
 /* flags of ahv_select_rotation_f32 */
 #define AHV_SELECT_RESET_KEY 1u /* hand best_key[0..B) back as AHV_KEY_EMPTY after decoding it: the next verify step
@@ -136,26 +132,12 @@ int ahv_device_cu_count(void);
  *            with a signed atomic max.  Decode with ahv_unpack_best / ahv_select_rotation_f32.
  *            Requires n_offset + N <= 2^32.
  *  flags     bit-or of AHV_SCORE_RESET_BEST (else: merge into the existing keys, e.g. chunked N),
- *            AHV_SCORE_SPLIT_F16 (else: the all-fp32 kernel), AHV_SCORE_NO_TEAMS, AHV_SCORE_SPARE_CUS(k)
+ *            AHV_SCORE_SPLIT_F16 (else: the all-fp32 kernel), AHV_SCORE_NO_TEAMS
  */
 int ahv_score_hypotheses_f32(const float* vol_src, const float* feat_tgt, const float* R,
                              int64_t r_batch_stride, int64_t n_offset, const float* W1,
                              const float* W2, const float* b2, int B, int64_t N, float* scores,
                              int64_t* best_key, unsigned flags, void* stream);
-
-/*
- * Diagnostics (measurement only; not part of the reference's interface): the same launch as
- * ahv_score_hypotheses_f32, and additionally every workgroup w of the persistent grid writes
- *   clock_stamps[4w + 0..3] = { s_memtime, s_memrealtime (100 MHz) before its hypothesis loop, the same two after }
- * so that the shader clock the chip actually held during THIS kernel is
- *   (stamps[2] - stamps[0]) / (stamps[3] - stamps[1]) * 100 MHz   (median over workgroups).
- * clock_stamps: device memory, 4 * ahv_device_cu_count() words, zeroed by the caller (the grid never exceeds
- * one workgroup per CU; entries of unused slots stay zero).  bench.py reports roofline.shader_clock_ghz from it.
- */
-int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt, const float* R,
-                                     int64_t r_batch_stride, int64_t n_offset, const float* W1,
-                                     const float* W2, const float* b2, int B, int64_t N, float* scores,
-                                     int64_t* best_key, unsigned flags, uint64_t* clock_stamps, void* stream);
 
 /*
  * One-launch verify step: everything the reference does per image pair between the encoder and the arg-max,
@@ -168,7 +150,7 @@ int ahv_score_hypotheses_clocked_f32(const float* vol_src, const float* feat_tgt
  *  feat_tgt_out  [B][32][64] or NULL: if given, forward_3d2d(vol_tgt) as the launch computed it (validation_step's
  *                gt_sim reuses it, modules/model.py:137-143).  REQUIRED with AHV_SCORE_SPLIT_F16, whose kernel
  *                takes ready-made features: that case runs forward_3d2d into it and then the scorer (two launches).
- *  clock_stamps  NULL, or as in ahv_score_hypotheses_clocked_f32 (diagnostics)
+ *  clock_stamps  NULL, or as in ahv_score_hypotheses_clocked_f32 (ahv_diag.h; measurement only)
  * With N = 0 and feat_tgt_out given only the target features are produced.  The in-launch features are summed in
  * another order than ahv_forward_3d2d_f32's (both fp32, both within 1e-6 of the reference).
  */

@@ -109,14 +109,17 @@ void ahv_oracle_rotate_volume_f32(const float* vol, int64_t vol_batch_stride, co
                                 const float wy = dy ? ty : 1.0f - ty;
                                 const float wz = dz ? tz : 1.0f - tz;
                                 const int in = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
-                                /* zeros padding is per corner */
-                                wgt[k] = in ? wx * wy * wz : 0.0f;
-                                off[k] = in ? ((int64_t)zz * H + yy) * W + xx : 0;
+                                /* zeros padding is per corner: ATen SKIPS a corner that is out of bounds (it does not
+                                 * multiply a voxel by 0 -- that would turn a non-finite voxel into NaN); an in-bounds
+                                 * corner is accumulated even when its weight is exactly 0 */
+                                wgt[k] = wx * wy * wz;
+                                off[k] = in ? ((int64_t)zz * H + yy) * W + xx : -1;
                             }
                     for (int c = 0; c < C; ++c) {
                         const float* vc = v + c * plane;
                         float acc = 0.0f;
-                        for (k = 0; k < 8; ++k) acc += wgt[k] * vc[off[k]];
+                        for (k = 0; k < 8; ++k)
+                            if (off[k] >= 0) acc += wgt[k] * vc[off[k]];
                         o[c * plane + obase] = acc;
                     }
                 }
@@ -156,7 +159,7 @@ void ahv_oracle_forward_3d2d_f32(const float* vol, const float* W1, const float*
                             acc += w[128 + c * 8 + k] * vy;
                             acc += w[256 + c * 8 + k] * vz;
                         }
-                    u[o] = acc > 0.0f ? acc : 0.0f;
+                    u[o] = acc < 0.0f ? 0.0f : acc; /* F.relu: a NaN stays a NaN (acc > 0 ? acc : 0 would drop it) */
                 }
                 float ss = 0.0f;
                 for (int o = 0; o < AHV_O; ++o) {

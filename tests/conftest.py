@@ -42,3 +42,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def g128():
     return load_golden("score_n128")
+
+
+def nonfinite_cases(g128):
+    """G10 `nonfinite` (tools/gen_golden.py gen_nonfinite: the reference's hot loop on inputs with ONE non-finite element):
+    yields (name, inputs dict with vol_src / vol_tgt / W1 / W2 / b2, R, reference scores (1, N), best idx)."""
+    g = load_golden("nonfinite")
+    for k, name in enumerate(g["names"]):
+        inp = {key: np.array(g128[key]) for key in ("vol_src", "vol_tgt", "W1", "W2", "b2")}
+        which = {"src": "vol_src", "tgt": "vol_tgt"}.get(str(g["tensor"][k]), str(g["tensor"][k]))
+        idx = tuple(int(i) for i in g["index"][k] if i >= 0)
+        inp[which].view(np.uint32)[idx] = g["bits"][k]
+        yield str(name), inp, g["R"], g["scores"][k], int(g["best_idx"][k][0])

@@ -15,21 +15,24 @@ def lib(ahv):
     return ahv._lib.load()
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, "include", "ahv.h")).read()
+def declared_symbols(header="ahv.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ahv_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported(lib, ahv):
-    syms = declared_symbols()
-    assert len(syms) >= 9
-    for s in syms:
-        assert hasattr(lib, s), "libahv_hip.so lacks %s declared in include/ahv.h" % s
-    assert sorted(ahv._lib.SIGNATURES) == syms  # the ctypes table mirrors the header one to one
+    syms = declared_symbols()                 # the drop-in boundary
+    diag = declared_symbols("ahv_diag.h")     # measurement / developer entry points: a header of their own
+    assert len(syms) >= 9 and not set(syms) & set(diag)
+    assert all("clocked" not in s and "diag" not in s for s in syms)
+    for s in syms + diag:
+        assert hasattr(lib, s), "libahv_hip.so lacks %s declared in include/" % s
+    assert sorted(ahv._lib.SIGNATURES) == syms  # the ctypes tables mirror the headers one to one
+    assert sorted(ahv._lib.DIAG_SIGNATURES) == diag
     out = subprocess.check_output(["nm", "-D", "--defined-only", ahv._lib.LIB_PATH], text=True)
     exported = sorted(set(re.findall(r" T (ahv_[a-z0-9_]+)", out)))
-    assert exported == syms  # nothing undeclared leaks out of the ABI
+    assert exported == sorted(syms + diag)  # nothing undeclared leaks out of the ABI
 
 
 def test_abi_version_and_error_string(lib):

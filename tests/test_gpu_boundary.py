@@ -130,9 +130,45 @@ def test_plain_ops_never_drop_a_gradient(ahv, dev):
         ahv.ops.score_features(torch.zeros(1, 2, 32, 64, device=dev, requires_grad=True), torch.zeros(1, 32, 64, device=dev))
     with pytest.raises(RuntimeError, match="GPU only"):
         ahv.ops.unpack_best(torch.zeros(1, dtype=torch.int64))
-    # nothing differentiable requested: the plain launch (single waves like the autograd path: same bits)
-    _, key2 = ahv.ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False, no_teams=True)
+    # nothing differentiable requested: the plain launch (teams or single waves: same bits)
+    _, key2 = ahv.ops.score_hypotheses(vs, ft, R, W1, W2, b2, want_scores=False)
     assert torch.equal(key2, key)
+
+
+def test_one_launch_steps_refuse_or_route_a_gradient(ahv, dev):
+    """verify_pair / coarse_to_fine have no autograd edge and must SAY so (the refusal sat inside a
+    no_grad decorator, where it could never fire); Feature_Aligner.score_hypotheses -- which routes to verify_pair for
+    inference -- takes the differentiable pair of ops when something requires grad."""
+    g = load_golden("score_n128")
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).to(dev)
+    vs, vt, R = T("vol_src"), T("vol_tgt"), T("R")[:16]
+    W1, W2, b2 = T("W1"), T("W2"), T("b2")
+    for bad in ("vs", "W1"):
+        a = vs.clone().requires_grad_(bad == "vs")
+        w = W1.clone().requires_grad_(bad == "W1")
+        with pytest.raises(RuntimeError, match="autograd"):
+            ahv.ops.verify_pair(a, vt, R, w, W2, b2)
+        with pytest.raises(RuntimeError, match="autograd"):
+            ahv.ops.coarse_to_fine(a, vt, R, R[:4], w, W2, b2)
+        with torch.no_grad():                       # explicitly not recording: the plain launch
+            s, _ = ahv.ops.verify_pair(a, vt, R, w, W2, b2)
+        assert not s.requires_grad
+    # the module-level entry point: trainable head, volumes under grad -> scores with the HIP backward behind them
+    torch.manual_seed(0)
+    m = ahv.aligner.Feature_Aligner(768, 256, 32, 4, 4).to(dev)
+    with torch.no_grad():
+        m.feature_embedding_2d[0].weight.copy_(W1.reshape(32, 384, 1, 1))
+        m.feature_embedding_2d[2].weight.copy_(W2.reshape(32, 32, 1, 1))
+        m.feature_embedding_2d[2].bias.copy_(b2)
+    a = vs.clone().requires_grad_(True)
+    scores, key = m.score_hypotheses(a, vt, R)
+    assert scores.requires_grad and not key.requires_grad
+    scores.sum().backward()
+    assert a.grad.abs().max().item() > 0 and m.feature_embedding_2d[0].weight.grad.abs().max().item() > 0
+    with torch.no_grad():
+        s_inf, k_inf = m.score_hypotheses(vs, vt, R)
+    assert (s_inf - scores.detach()).abs().max().item() < 1e-6 and torch.equal(
+        ahv.ops.unpack_best(k_inf)[1], ahv.ops.unpack_best(key)[1])
 
 
 def test_packed_encoder_weights_follow_inplace_updates(ahv, dev):

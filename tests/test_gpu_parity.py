@@ -270,16 +270,17 @@ def test_fused_tie_break_lowest_index(ops, G, dev, ahv):
 
 
 def test_fused_sharded_offsets_merge(ops, G, dev, ahv):
-    """N split into shards with n_offset (what each rank does); max over packed keys = global arg-max.
-    AHV_SCORE_NO_TEAMS: scores that do not depend on N bit for bit (the default lets teams of four waves score the
-    remainder of a launch, equal to rounding: tests/test_gpu_verify.py)."""
+    """N split into shards with n_offset (what each rank does); max over packed keys = global arg-max, scores and keys
+    bit for bit -- with the DEFAULT launches: 10 000 unsharded is 4 full rounds + 1 808 by single waves, a 2 500 shard is
+    one round + 452 by teams, and a team's score is a lone wave's (ahv_team.h)."""
     R = to_dev(ahv.rotations.haar_rotations_np(10000, 11), dev)
     ft = ops.forward_3d2d(G["vol_tgt"], G["W1"], G["W2"], G["b2"])
-    s_full, k_full = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], no_teams=True)
+    assert ops.score_plan(1, 10000)[2] == 10000 and ops.score_plan(1, 2500)[2] == 2048
+    s_full, k_full = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
     keys, parts = [], []
     for r in range(4):
         lo, hi = r * 2500, (r + 1) * 2500
-        s, k = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo, no_teams=True)
+        s, k = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo)
         keys.append(k)
         parts.append(s)
     assert torch.equal(torch.cat(parts, dim=1), s_full)  # per-hypothesis results do not depend on the shard
@@ -291,18 +292,62 @@ def test_fused_sharded_offsets_merge(ops, G, dev, ahv):
     for r in range(4):
         lo, hi = r * 2500, (r + 1) * 2500
         _, key = ops.score_hypotheses(G["vol_src"], ft, R[lo:hi], G["W1"], G["W2"], G["b2"], n_offset=lo,
-                                      want_scores=False, best_key=key, no_teams=True)
+                                      want_scores=False, best_key=key)
     assert torch.equal(key, k_full)
-    # the default (teams may take a shard's remainder): same winner, scores equal to rounding
-    s_t, k_t = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
-    assert (s_t - s_full).abs().max().item() <= 1e-6 and torch.equal(ops.unpack_best(k_t)[1], ops.unpack_best(k_full)[1])
+    s_1, k_1 = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], no_teams=True)
+    assert torch.equal(s_1, s_full) and torch.equal(k_1, k_full)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 33, 64, 257, 511, 512, 2048 + 106, 2048 + 512, 3 * 2048 + 106, 6 * 2048 + 212,
+                               12 * 2048 + 424])
+def test_team_scores_are_bit_identical(ops, G, dev, ahv, n):
+    """Whether a hypothesis is scored by one wave or by a team of four (ahv_team.h: the remainder of a launch) is a
+    scheduling decision: a team runs the lone wave's accumulation chains tile by tile and associates the score's sums the
+    same way, so scores and keys are equal BIT FOR BIT -- through both entry points, with shared and per-sample rotations,
+    with an offset.  (Rounds 1-4: teams exchanged partial sums, 1e-7 apart, and a sharded run could pick another arg-max
+    than the unsharded one inside a rounding-level near-tie.)"""
+    R = to_dev(ahv.rotations.haar_rotations_np(n, 100 + n), dev)
+    W = (G["W1"], G["W2"], G["b2"])
+    ft = ops.forward_3d2d(G["vol_tgt"], *W)
+    s1, k1 = ops.score_hypotheses(G["vol_src"], ft, R, *W, no_teams=True, n_offset=7)
+    s2, k2 = ops.score_hypotheses(G["vol_src"], ft, R, *W, n_offset=7)
+    assert torch.equal(s1, s2) and torch.equal(k1, k2)
+    v1, kv1 = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, *W, no_teams=True)
+    v2, kv2 = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, *W)
+    assert torch.equal(v1, v2) and torch.equal(kv1, kv2)
+    if n <= 2048 + 512:   # a batch of three with per-sample rotation sets (A5: r_batch_stride = 9 N)
+        g = torch.Generator(device="cpu").manual_seed(n)
+        vs = (torch.randn(3, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
+        vt = (torch.randn(3, 16, 8, 8, 8, generator=g) * 1.15).to(dev)
+        Rb = to_dev(ahv.rotations.haar_rotations_np(3 * n, 200 + n).reshape(3, n, 3, 3), dev)
+        b1, kb1 = ops.verify_pair(vs, vt, Rb, *W, no_teams=True)
+        b2, kb2 = ops.verify_pair(vs, vt, Rb, *W)
+        assert torch.equal(b1, b2) and torch.equal(kb1, kb2)
+
+
+def test_team_scores_bit_identical_on_edge_rotations(ops, G, dev):
+    """The same on the 33 edge rotations of G3 (identity, cube rotations, 45 degrees, non-orthonormal, scaled) and on
+    rotations with NaN / inf entries: a launch of 33 + 6 hypotheses is all teams by default."""
+    g = load_golden("edge_rotations")
+    Rn = np.concatenate([g["R"], np.repeat(np.eye(3, dtype=np.float32)[None], 6, 0)])
+    Rn[33, 1, 1] = np.nan
+    Rn[34, 0, 2] = np.inf
+    Rn[35, 2, 2] = -np.inf
+    Rn[36] = 1e30
+    Rn[37] = 0.0
+    Rn[38, 2, 0] = np.inf
+    R = to_dev(Rn, dev)
+    W = (G["W1"], G["W2"], G["b2"])
+    s1, k1 = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, *W, no_teams=True)
+    s2, k2 = ops.verify_pair(G["vol_src"], G["vol_tgt"], R, *W)
+    assert torch.equal(s1, s2) and torch.equal(k1, k2)
 
 
 def test_configs3_full_size(ops, dev, ahv, oracle):
     """BASELINE.json configs[3] at its full size on one GPU: B = 32 pairs x N = 50 000 shared hypotheses, the
     hypothesis axis cut into 8 contiguous shards with n_offset (what the 8 ranks do).  merge_keys over the shard
-    keys == the unsharded key bit for bit; shard scores == the unsharded scores bit for bit; a 512-hypothesis slice
-    of shard 3 vs the oracle."""
+    keys == the unsharded key bit for bit; shard scores == the unsharded scores bit for bit (default launches: the
+    shards' remainders go to teams, the unsharded launch has none); a 512-hypothesis slice of shard 3 vs the oracle."""
     B, N, G8 = 32, 50000, 8
     g = load_golden("score_n128")
     rng = np.random.default_rng(33)
@@ -312,13 +357,13 @@ def test_configs3_full_size(ops, dev, ahv, oracle):
     W = [to_dev(g[k], dev) for k in ("W1", "W2", "b2")]
     vsd, vtd, R = to_dev(vs, dev), to_dev(vt, dev), to_dev(Rn, dev)
     ft = ops.forward_3d2d(vtd, *W)
-    s_full, k_full = ops.score_hypotheses(vsd, ft, R, *W, no_teams=True)
+    s_full, k_full = ops.score_hypotheses(vsd, ft, R, *W)
     assert s_full.shape == (B, N)
     keys = []
     for r in range(G8):
         lo, hi = ahv.dist.shard_range(N, r, G8)
         assert hi - lo == N // G8
-        s, k = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, no_teams=True)
+        s, k = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo)
         assert torch.equal(s, s_full[:, lo:hi])            # per-hypothesis results do not depend on the shard
         keys.append(k)
         if r == 3:
@@ -333,12 +378,14 @@ def test_configs3_full_size(ops, dev, ahv, oracle):
     key = None
     for r in range(G8):
         lo, hi = ahv.dist.shard_range(N, r, G8)
-        _, key = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, want_scores=False, best_key=key, no_teams=True)
+        _, key = ops.score_hypotheses(vsd, ft, R[lo:hi], *W, n_offset=lo, want_scores=False, best_key=key)
     assert torch.equal(key, k_full)
-    # what bench.py's strong-scaling record runs: the one-launch step per shard, teams allowed -- same winners
+    # what bench.py's multi-rank line runs: the one-launch step per shard -- merged keys == the unsharded one-launch key
     keys_t = [ops.verify_pair(vsd, vtd, R[lo:hi], *W, n_offset=lo, want_scores=False)[1]
               for lo, hi in (ahv.dist.shard_range(N, r, G8) for r in range(G8))]
-    assert torch.equal(ops.unpack_best(ahv.dist.merge_keys(torch.stack(keys_t)))[1], ri)
+    k_one = ops.verify_pair(vsd, vtd, R, *W, want_scores=False)[1]
+    assert torch.equal(ahv.dist.merge_keys(torch.stack(keys_t)), k_one)
+    assert torch.equal(ops.unpack_best(k_one)[1], ri)
 
 
 def test_fused_properties_full_size(ops, G, dev, ahv):
@@ -354,9 +401,9 @@ def test_fused_properties_full_size(ops, G, dev, ahv):
         assert torch.all(s.abs() <= 1.0 + 1e-5)                           # mean cosine similarity
         perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
         s_1, _ = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"], no_teams=True)
-        s_p, _ = ops.score_hypotheses(G["vol_src"], ft, R[perm].contiguous(), G["W1"], G["W2"], G["b2"], no_teams=True)
-        assert torch.equal(s_p[0], s_1[0, perm])                          # order independence, bit for bit (single waves)
-        assert (s - s_1).abs().max().item() <= 1e-6                       # teams for the remainder: equal to rounding
+        s_p, _ = ops.score_hypotheses(G["vol_src"], ft, R[perm].contiguous(), G["W1"], G["W2"], G["b2"])
+        assert torch.equal(s_p[0], s[0, perm])                            # order independence, bit for bit
+        assert torch.equal(s, s_1)                                        # teams or single waves: the same bits
         s_again, k_again = ops.score_hypotheses(G["vol_src"], ft, R, G["W1"], G["W2"], G["b2"])
         assert torch.equal(s_again, s) and torch.equal(k_again, k)        # deterministic
     # identity hypothesis == un-rotated source features scored against the target

@@ -25,10 +25,10 @@ def _hipcc():
     return exe
 
 
-def _isa(src, tmp_path, slp=False):
-    out = str(tmp_path / (os.path.basename(src) + ".s"))
+def _isa(src, tmp_path, slp=False, defines=()):
+    out = str(tmp_path / (os.path.basename(src) + "".join(defines) + ".s"))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-I" + CSRC,
-           "-I" + os.path.join(REPO, "include"), src, "-o", out]
+           "-I" + os.path.join(REPO, "include"), src, "-o", out] + ["-D" + d for d in defines]
     if not slp:
         cmd.insert(4, "-fno-slp-vectorize")  # as in the Makefile for this file
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
@@ -66,19 +66,33 @@ def test_xdl_kernel_has_no_cross_half_packed_f32(tmp_path):
     # and the fp32 kernels of the same file (target features given / built in the launch) have no XDL MFMA
     fp32 = [b for n, b in fns.items() if "score_hypotheses_dual_kernelILb0" in n or "coarse_to_fine_kernel" in n]
     assert len(fp32) == 3 and not any(XDL.search(b) for b in fp32)
+    # the exact (non-finite) path the XDL kernel CALLS (ahv_exact.h, score_share_exact<true>): fp32 MFMAs only, and no
+    # cross-half packed form either (every wave of the workgroup is in it at once, but the rule costs nothing to keep)
+    called = [b for n, b in fns.items() if "score_share_exactILb1" in n]
+    assert len(called) == 1 and not XDL.search(called[0]) and "v_mfma_f32_16x16x4_f32" in called[0]
+    assert not [l for l in called[0].splitlines() if re.search(r"\bv_pk_\w+_(f32|b32)\b", l) and "op_sel:[" in l]
 
 
 def test_scorers_use_no_scratch_memory(tmp_path):
-    """No spilled vector register and no private segment in any scorer instance (round 3's split-f16 kernel carried 7
-    spilled registers, the first one-launch verify kernel 4: per-thread staging addresses hoisted out of the sample loop
-    and parked in scratch across the hypothesis loop -- megabytes of spill stores per launch in WRITE_SIZE), and in
-    particular no scratch access inside a hypothesis loop (the innermost loop with MFMAs and > 2 000 instructions)."""
-    asm = _isa(os.path.join(CSRC, "ahv_score.hip"), tmp_path)
-    meta = re.findall(r"\.name:\s+(\S*(?:score_hypotheses_dual_kernel|coarse_to_fine_kernel)\S*)\s+\.private_segment_fixed_size:\s+(\d+).*?"
-                      r"\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", asm, flags=re.S)
+    """The scorers themselves spill nothing and need no private segment (round 3's split-f16 kernel carried 7 spilled
+    registers, the first one-launch verify kernel 4: per-thread staging addresses hoisted out of the sample loop and parked in
+    scratch across the hypothesis loop -- megabytes of spill stores per launch in WRITE_SIZE): checked on the build WITHOUT
+    the exact path (-DAHV_DIAG_NO_EXACT).  The shipped build CALLS the exact path for a sample with a NaN / inf (ahv_exact.h;
+    a call needs a stack, so a private segment exists -- measured cost on finite inputs: none, profiles/r05_exact_path_ab.txt):
+    there, the rule is that no hypothesis loop (the innermost loop with MFMAs and > 2 000 instructions) touches scratch and
+    that what the call makes the kernels save stays a handful of registers."""
+    plain = _isa(os.path.join(CSRC, "ahv_score.hip"), tmp_path, defines=("AHV_DIAG_NO_EXACT",))
+    pat = (r"\.name:\s+(\S*(?:score_hypotheses_dual_kernel|coarse_to_fine_kernel)\S*)\s+\.private_segment_fixed_size:\s+(\d+).*?"
+           r"\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)")
+    meta = re.findall(pat, plain, flags=re.S)
     assert len(meta) == 4, meta  # three instances of the scorer + the two-stage launch (the fp32 verify kernel's body)
     for name, private, vgprs, spills in meta:
         assert int(private) == 0 and int(spills) == 0 and int(vgprs) <= 256, (name, private, vgprs, spills)
+    asm = _isa(os.path.join(CSRC, "ahv_score.hip"), tmp_path)
+    meta = re.findall(pat, asm, flags=re.S)
+    assert len(meta) == 4, meta
+    for name, private, vgprs, spills in meta:
+        assert int(private) <= 256 and int(spills) <= 16 and int(vgprs) <= 256, (name, private, vgprs, spills)
         # occupancy argument of low_half (ahv_dual.h): two waves per SIMD (launch bounds), vector registers handed out in
         # granules of 8 -- with more than 248 per wave the pair owns all 512 registers of the SIMD and no wave of another
         # kernel (an XDL MFMA kernel in particular) can be resident beside an fp32 scorer
@@ -91,7 +105,7 @@ def test_scorers_use_no_scratch_memory(tmp_path):
         labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\w+):", l)] if m}
         loops = []
         for i, l in enumerate(lines):
-            m = re.search(r"s_cbranch_\w+\s+(\.LBB\w+)", l)
+            m = re.search(r"s_c?branch\w*\s+(\.LBB\w+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
                 loops.append((labels[m.group(1)], i))
         hot = [(a, b) for a, b in loops if b - a > 2000 and any("v_mfma" in x for x in lines[a:b])]

@@ -113,3 +113,22 @@ def test_torch_ref_matches_reference(g128):
     scores_c, _, idx_c = torch_ref.score_hypotheses(t("vol_src"), t("vol_tgt"), t("R"), t("W1"), t("W2"), t("b2"),
                                                     chunk=50)
     assert relerr(scores_c.numpy(), g128["scores"]) < 1e-6 and idx_c.item() == idx.item()
+
+
+def test_nonfinite_inputs_match_the_reference(oracle, g128):
+    """G10: ONE non-finite voxel / head weight.  F.grid_sample skips an out-of-range corner (a non-finite voxel next to it
+    stays out of the sample: 0 * inf would be NaN), an in-range corner is accumulated even with weight 0, and F.relu
+    propagates NaN of either sign: the oracle reproduces the reference's NaN mask exactly, its finite scores to RTOL and
+    torch.max's index (the first NaN)."""
+    from .conftest import nonfinite_cases
+    n_cases = 0
+    for name, inp, R, ref, ref_idx in nonfinite_cases(g128):
+        scores, best, idx = oracle.score_hypotheses(inp["vol_src"], inp["vol_tgt"], R, inp["W1"], inp["W2"], inp["b2"])
+        assert np.array_equal(np.isnan(scores), np.isnan(ref)), name
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(scores), fin), name
+        if fin.any():
+            assert np.max(np.abs(scores[fin] - ref[fin]) / np.abs(ref[fin]).clip(1e-2)) < 1e-4, name
+        assert idx[0] == ref_idx, name
+        n_cases += 1
+    assert n_cases == 10

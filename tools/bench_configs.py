@@ -101,6 +101,35 @@ if not only or "shard" in only:
                 ops.select_rotation(key, R, reset_key=True)
             row["us_per_step_" + name] = timeit(step, 200, warm=20) * 1e3
         row["hyp_per_s"] = N / row["us_per_step_teams"] * 1e6
+        # two lanes: groups of 8 steps alternate between two streams (each with its own key), so that one step's drain
+        # (the wait for the slowest workgroup), the launch gap and the next step's prologue overlap
+        lanes = [(torch.cuda.Stream(), key.clone()) for _ in range(2)]
+        state = {"i": 0}
+
+        def step2():
+            st, k = lanes[(state["i"] // 8) & 1]
+            state["i"] += 1
+            with torch.cuda.stream(st):
+                ops.verify_pair(vs, vt, R, W1, W2, b2, want_scores=False, best_key=k, reset_best=False)
+                ops.select_rotation(k, R, reset_key=True)
+        for st, _ in lanes:
+            st.wait_stream(torch.cuda.current_stream())
+        t0 = time.perf_counter()
+        for _ in range(64):
+            step2()
+        torch.cuda.synchronize()
+        state["i"] = 0
+        t0 = time.perf_counter()
+        for _ in range(400):
+            step2()
+        torch.cuda.synchronize()
+        row["us_per_step_two_lanes_wall"] = (time.perf_counter() - t0) / 400 * 1e6
+        state["i"] = 0
+        t0 = time.perf_counter()
+        for _ in range(400):
+            step()
+        torch.cuda.synchronize()
+        row["us_per_step_one_lane_wall"] = (time.perf_counter() - t0) / 400 * 1e6
         print(json.dumps(row))
 
 if not only or "enc" in only:

@@ -180,6 +180,63 @@ def gen_batched32(rotate_volume, Feature_Aligner, fa):
     print("G9 B=32 best idx", idx.tolist()[:8], "... min margin", (top2[:, 0] - top2[:, 1]).min().item())
 
 
+NONFINITE_CASES = (
+    # name, tensor ("src" / "tgt" / "W1" / "b2"), index, value bits (uint32: exact NaN signs travel as bits)
+    ("nan_centre", "src", (0, 5, 3, 4, 3), 0x7FC00000),
+    ("inf_face", "src", (0, 5, 0, 4, 3), 0x7F800000),
+    ("ninf_corner", "src", (0, 2, 7, 7, 0), 0xFF800000),
+    ("negnan_edge", "src", (0, 9, 0, 0, 5), 0xFFC00000),
+    ("nan_origin", "src", (0, 0, 0, 0, 0), 0x7FC00000),
+    ("inf_last", "src", (0, 15, 7, 7, 7), 0x7F800000),
+    ("tgt_nan", "tgt", (0, 3, 2, 2, 2), 0x7FC00000),
+    ("tgt_ninf", "tgt", (0, 7, 0, 0, 0), 0xFF800000),
+    ("w1_ninf", "W1", (3, 17), 0xFF800000),
+    ("b2_negnan", "b2", (5,), 0xFFC00000),
+)
+
+
+def nonfinite_rotations():
+    """64 Haar rotations + the rotations that put sample points ON and BEYOND the volume's faces: identity, two cube
+    rotations, 45 degrees about z, 2 I (87.5 % of the output outside), 0.5 I, a shear."""
+    extra = np.stack([np.eye(3), cube_rotations()[5], cube_rotations()[17], axis_rot("z", 45.0), 2.0 * np.eye(3), 0.5 * np.eye(3),
+                      np.array([[1, 0.5, 0], [0, 1, 0.25], [0.125, 0, 1]])]).astype(np.float32)
+    return np.concatenate([rot.haar_rotations_np(64, seed=10), extra]).astype(np.float32)
+
+
+def gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt):
+    """G10 `nonfinite`: the reference's hot loop on inputs with ONE non-finite element (a voxel of either volume, a head
+    weight): per case the scores (NaNs included) and torch.max's (value, index).  Pins what F.grid_sample's zeros padding
+    does with a non-finite voxel next to an out-of-range corner (the corner is skipped, not multiplied by 0), and that
+    F.relu propagates a NaN of either sign.  utils.py:129, modules/modules.py:68."""
+    import copy
+    R = torch.from_numpy(nonfinite_rotations())
+    out = {"R": R.numpy(), "names": np.array([c[0] for c in NONFINITE_CASES]),
+           "tensor": np.array([c[1] for c in NONFINITE_CASES]),
+           "index": np.array([list(c[2]) + [-1] * (5 - len(c[2])) for c in NONFINITE_CASES], dtype=np.int64),
+           "bits": np.array([c[3] for c in NONFINITE_CASES], dtype=np.uint32)}
+    scores, best, best_idx = [], [], []
+    for name, which, idx, bits in NONFINITE_CASES:
+        val = np.array([bits], dtype=np.uint32).view(np.float32)[0]
+        vs, vt, f = vol_src.clone(), vol_tgt.clone(), copy.deepcopy(fa)
+        with torch.no_grad():
+            if which == "src":
+                vs.numpy()[idx] = val
+            elif which == "tgt":
+                vt.numpy()[idx] = val
+            elif which == "W1":
+                f.feature_embedding_2d[0].weight.numpy()[idx + (0, 0)] = val
+            else:
+                f.feature_embedding_2d[2].bias.numpy()[idx] = val
+        _, _, _, sim, b, i = ref_hot_loop(rotate_volume, f, vs, vt, R)
+        scores.append(sim.numpy())
+        best.append(b.numpy())
+        best_idx.append(i.numpy())
+        print("G10 %-12s NaN scores %3d / %d, inf %d, best %s idx %d" % (
+            name, int(torch.isnan(sim).sum()), sim.numel(), int(torch.isinf(sim).sum()), b.item(), i.item()))
+    out.update(scores=np.stack(scores), best=np.stack(best), best_idx=np.stack(best_idx))
+    np.savez(os.path.join(OUT, "nonfinite.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -193,6 +250,9 @@ def main():
     fa, vol_src3, vol_tgt3 = seeded_pair(Feature_Aligner)
     W1, W2, b2 = head_weights(fa)
     vol_src, vol_tgt = vol_src3[:1], vol_tgt3[:1]
+    if "--only-g10" in sys.argv:    # round 5 addition alone
+        gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt)
+        return
     if "--only-g8-g9" in sys.argv:  # round 4 additions alone (the other fixtures regenerate bit-identically anyway)
         gen_grid_digest(rotate_volume, fa, vol_src, vol_tgt)
         gen_batched32(rotate_volume, Feature_Aligner, fa)
@@ -293,6 +353,7 @@ def main():
 
     gen_grid_digest(rotate_volume, fa, vol_src, vol_tgt)
     gen_batched32(rotate_volume, Feature_Aligner, fa)
+    gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt)
     gen_encoder_full(Feature_Aligner)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
