@@ -318,21 +318,25 @@ __global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
     const int n16 = lane & 15, kq = lane >> 4;
     const int i2 = 2 * lane, sa0 = i2 >> 6, sb = (i2 >> 3) & 7, se = i2 & 7;
     const int o0 = qoff(sa0, sb, se), o1 = qoff(sa0, sb, se + 1);
-    for (long m = (long)wave * gridDim.x + blockIdx.x; m < M; m += (long)gridDim.x * 8) {
+    const long mstep = (long)gridDim.x * 8;
+    long m = (long)wave * gridDim.x + blockIdx.x;
+    f32x2 cur[16], nxt[16];
+    if (m < M) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cur[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(vol + m * (16 * 512) + i2 + c * 512));
+    }
+    for (; m < M; m += mstep) {
         const float* V = vol + m * (16 * 512) + i2;
+        // quarter 3's prefetch is the NEXT item's quarter 0 (the last item re-reads its own): no first-touch wait per item
+        const float* Vn = vol + (m + mstep < M ? m + mstep : m) * (16 * 512) + i2;
         f32x4 acc[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x2 cur[16], nxt[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) cur[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(V + c * 512));
 #define AHV_F3_QUARTER(Q)                                                                                   \
-        if (Q < 3) {                                                                                        \
-            _Pragma("unroll") for (int c = 0; c < 16; ++c)                                                  \
-                nxt[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(V + c * 512 + (Q + 1) * 128)); \
-        }                                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 16; ++c)                                                      \
+            nxt[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>((Q < 3 ? V + (Q + 1) * 128 : Vn) + c * 512)); \
         _Pragma("unroll") for (int c = 0; c < 16; ++c) { buf[c * 128 + o0] = cur[c][0]; buf[c * 128 + o1] = cur[c][1]; } \
         wave_lds_fence();                                                                                   \
         gemm1_quarter_pipe<Q>(acc, lds_w1, buf, lane, [] {});                                               \
@@ -355,11 +359,14 @@ __global__ __launch_bounds__(512, 2) void forward_3d2d_dual_kernel(
                 for (int r = 0; r < 4; ++r) ss += v[m2][t][r] * v[m2][t][r];
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            // v / max(|v|, eps) as v * (1 / max(|v|, eps)): ONE correctly rounded division per position instead of eight per
+            // lane (an IEEE division is ~10 vector instructions, and fp32 MFMAs overlap none of them: 320 of an item's ~900);
+            // each feature within 1 ulp of the quotient
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16] = v[m2][t][r] / nrm;
+                for (int r = 0; r < 4; ++r) o[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n16] = v[m2][t][r] * inv;
         }
     }
 }

@@ -14,6 +14,13 @@
 // target features forward_3d2d(vol_tgt) built inside the launch: ahv_verify_pair_f32) and <true, false> (GEMM1 as
 // split-f16 MFMA products, opt-in through AHV_SCORE_SPLIT_F16; ahv_split.h).  The remainder of a launch that fills
 // less than a quarter of the wave slots is scored by TEAMS of four waves per hypothesis (ahv_team.h).
+#ifndef AHV_DIAG_NO_FP32_LOW_HALF  // (tools/kbench A/B build of the unprotected fp32 scorers)
+// The fp32 scorers keep every scalar they broadcast over a register pair in the LOW half too (low_half, ahv_dual.h).  Rounds 3-4
+// relied on occupancy instead (two waves of > 248 registers own the SIMD: no foreign XDL wave fits) -- true while both waves
+// run, but the older wave of a SIMD retires ~110 us before its partner, and in that tail a wave of another stream's XDL
+// kernel CAN land beside the remaining one.  75 more vector instructions per hypothesis (2 555 -> 2 630): +0.3 %.
+#define AHV_FP32_LOW_HALF
+#endif
 #include "ahv_dual.h"
 #include "ahv_split.h"
 #include "ahv_team.h"
@@ -229,9 +236,11 @@ struct NoCompose {  // the instances without a second stage pass nothing
 template <bool SPLIT, typename Compose>
 __device__ __attribute__((noinline)) key_t score_share_exact(const float* lds_src, const float* lds_w1, float* buf, const float* W1,
                                                              const float* W2, const float* b2, const float* Rb, Compose Rstar,
-                                                             long N, long h0, long hstep, float* scores_b, long n_offset, key_t best)
+                                                             long N, long h0, long hstep, float* scores_b, long n_offset, key_t best,
+                                                             int lane)
 {
-    const int lane = threadIdx.x & 63;
+    // (`lane` comes in as an argument: a callee that reads threadIdx makes every caller keep the launch's work-item-id
+    // register alive for it -- two spilled registers per lane at kernel entry, 1 MB of scratch stores per launch)
     const int rl = lane < 9 ? lane : 8;
     DualFrags f;
     load_dual_frags(f, W2, b2, lane);
@@ -592,10 +601,13 @@ __device__ __forceinline__ void score_hypotheses_body(
 #pragma unroll
                 for (int i = 0; i < 9; ++i) ec.r[i] = Rstar[i];
                 ec.on = st1;
-                best = score_share_exact<SPLIT>(lds_src, lds_w1, buf, W1, W2, b2, Rb, ec, N_s, h0, hstep, sc_b, n_offset_s, best);
+                best = score_share_exact<SPLIT>(lds_src, lds_w1, buf, W1, W2, b2, Rb, ec, N_s, h0, hstep, sc_b, n_offset_s, best, lane);
             } else {
-                best = score_share_exact<SPLIT>(lds_src, lds_w1, buf, W1, W2, b2, Rb, NoCompose{}, N_s, h0, hstep, sc_b, n_offset_s, best);
+                best = score_share_exact<SPLIT>(lds_src, lds_w1, buf, W1, W2, b2, Rb, NoCompose{}, N_s, h0, hstep, sc_b, n_offset_s, best, lane);
             }
+            // (re-read rather than kept alive across the call: kept alive, the resident W1 fragments were saved to scratch at
+            // their definition -- once per wave and launch, 5 MB of stores -- for a path finite data never takes)
+            if constexpr (SPLIT) split_load_resident(w1res, reinterpret_cast<const f16x8*>(lds_w1), lane);
         } else {
 #ifndef AHV_DIAG_TEAMS_LAST
         if constexpr (!SPLIT) score_remainder_by_teams();
@@ -758,15 +770,20 @@ __device__ __forceinline__ void score_hypotheses_body(
                 if (before == gridDim.x - 1) {
                     const key_t kc = __hip_atomic_load(best_key + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const key_t kf = __hip_atomic_load(cf.best_key2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cf.coarse_score) cf.coarse_score[b] = (kc == kKeyEmpty) ? -INFINITY : key_score(kc);
-                    if (cf.coarse_idx) cf.coarse_idx[b] = (kc == kKeyEmpty) ? -1l : key_index(kc);
-                    if (cf.fine_score) cf.fine_score[b] = (kf == kKeyEmpty) ? -INFINITY : key_score(kf);
-                    const long fi = (kf == kKeyEmpty) ? -1l : key_index(kf);
+                    // A workgroup that gave the meeting point up (something else held CUs for ~1 s) has scored stage 1 against
+                    // an incomplete coarse key: the sticky error word is set, and the results are POISONED -- NaN scores,
+                    // index -1, NaN rotation -- so that the failure cannot pass for a result even if nobody reads the word.
+                    const bool gave_up = __hip_atomic_load(cf.sync + 2 * B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    const float nanv = __builtin_nanf("");
+                    if (cf.coarse_score) cf.coarse_score[b] = gave_up ? nanv : (kc == kKeyEmpty) ? -INFINITY : key_score(kc);
+                    if (cf.coarse_idx) cf.coarse_idx[b] = (gave_up || kc == kKeyEmpty) ? -1l : key_index(kc);
+                    if (cf.fine_score) cf.fine_score[b] = gave_up ? nanv : (kf == kKeyEmpty) ? -INFINITY : key_score(kf);
+                    const long fi = (gave_up || kf == kKeyEmpty) ? -1l : key_index(kf);
                     if (cf.fine_idx) cf.fine_idx[b] = fi;
                     if (cf.R_pred) {
                         float Rm[9];
 #pragma unroll
-                        for (int i = 0; i < 9; ++i) Rm[i] = (fi >= 0 && fi < cf.N2) ? cf.D[fi * 9 + i] : 0.0f;
+                        for (int i = 0; i < 9; ++i) Rm[i] = (fi >= 0 && fi < cf.N2) ? cf.D[fi * 9 + i] : (gave_up ? nanv : 0.0f);
                         if (fi >= 0 && fi < cf.N2) hyp_rotation(Rm, true);
 #pragma unroll
                         for (int i = 0; i < 9; ++i) cf.R_pred[b * 9 + i] = Rm[i];

@@ -68,7 +68,7 @@ class _EstimatorBase(nn.Module):
         if feature_extractor is None and backbone_factory is not None:
             feature_extractor = backbone_factory()
         if feature_extractor is None:
-            feature_extractor = _try_midas_backbone()
+            feature_extractor = _try_midas_backbone(cfg)
         self.feature_extractor = feature_extractor
         self.feature_aligner = Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4)
         self.step_outputs = []
@@ -81,8 +81,9 @@ class _EstimatorBase(nn.Module):
     def feature_extraction(self, img):
         fx = self.feature_extractor
         if fx is None:
-            raise RuntimeError("no feature_extractor: pass feature_extractor= (timm / MiDaS weights are not "
-                               "available offline) or use synthetic layer_4 features via forward_features()")
+            raise RuntimeError("no feature_extractor: the reference's DPT_SwinV2_T_256 factory could not be used (%s); pass "
+                               "feature_extractor= / backbone_factory=, or feed layer_4 features to forward_features()"
+                               % (midas_unavailable_reason or "not attempted"))
         if hasattr(fx, "forward_transformer"):  # the real MiDaS DPT object
             return fx.forward_transformer(fx.pretrained, img)[3]
         return fx(img)
@@ -296,7 +297,49 @@ class EstimatorObjaverse(_EstimatorBase):
 Estimator = EstimatorCo3d  # the class test_co3d.py imports from modules.model_co3d
 
 
-def _try_midas_backbone():
-    """The reference builds ``DPT_SwinV2_T_256(pretrained=True)`` (MiDaS/hubconf.py:124-145), which needs
-    timm==0.6.12 and a weight download.  Neither exists offline: return None and let the caller inject."""
-    return None
+#: why the last ``_try_midas_backbone`` call returned None (one line; ``Estimator(cfg)`` callers can print it)
+midas_unavailable_reason = ""
+
+
+def _try_midas_backbone(cfg=None):
+    """What the reference's constructor does -- ``self.feature_extractor = DPT_SwinV2_T_256(pretrained=True)``
+    (modules/model_co3d.py:32, modules/model.py:34; factory at MiDaS/hubconf.py:124-145) -- attempted for real:
+    the MiDaS directory (``cfg["MODEL"]["MIDAS_DIR"]``, else ``$AHV_MIDAS_DIR``, else ``MiDaS/`` next to the working
+    directory, which is where the reference's scripts run from) goes on ``sys.path`` and its ``hubconf`` is imported.
+    The factory needs timm == 0.6.12 and downloads ``dpt_swin2_tiny_256.pt`` unless torch.hub already has it cached;
+    ``$AHV_MIDAS_PRETRAINED=0`` builds the architecture without weights (a checkpoint's ``feature_extractor.*`` tensors
+    then fill it, ``load_from_checkpoint``).  Any failure -- no directory, no timm, no network -- returns None with the
+    reason in ``estimator.midas_unavailable_reason``: the caller injects a backbone or feeds ``layer_4`` features."""
+    global midas_unavailable_reason
+    import importlib
+    import os
+    import sys
+    cand = []
+    if cfg is not None:
+        try:
+            cand.append(cfg["MODEL"]["MIDAS_DIR"])
+        except (KeyError, TypeError):
+            pass
+    if os.environ.get("AHV_MIDAS_DIR"):
+        cand.append(os.environ["AHV_MIDAS_DIR"])
+    cand.append(os.path.join(os.getcwd(), "MiDaS"))
+    midas_dir = next((d for d in cand if d and os.path.isfile(os.path.join(d, "hubconf.py"))), None)
+    if midas_dir is None:
+        midas_unavailable_reason = "no MiDaS/hubconf.py in %s" % ", ".join(repr(d) for d in cand)
+        return None
+    added = midas_dir not in sys.path
+    if added:
+        sys.path.append(midas_dir)  # as the reference does (modules/model_co3d.py:11)
+    try:
+        hubconf = sys.modules.get("hubconf")
+        if hubconf is None or os.path.dirname(os.path.abspath(getattr(hubconf, "__file__", ""))) != os.path.abspath(midas_dir):
+            sys.modules.pop("hubconf", None)
+            hubconf = importlib.import_module("hubconf")
+        model = hubconf.DPT_SwinV2_T_256(pretrained=os.environ.get("AHV_MIDAS_PRETRAINED", "1") != "0")
+    except Exception as e:  # ImportError (timm), URLError (download), a changed factory ... : say which, carry on without
+        midas_unavailable_reason = "%s: %s: %s" % (os.path.join(midas_dir, "hubconf.py"), type(e).__name__, e)
+        if added:
+            sys.path.remove(midas_dir)
+        return None
+    midas_unavailable_reason = ""
+    return model

@@ -129,6 +129,23 @@ class CoarseToFine:
         self.last = {"coarse_scores": s1, "fine_scores": s2, "R_fine": R_fine if self.want_scores else None}
         return score, idx, R_pred, coarse_score, coarse_idx
 
+    def check(self):
+        """Host sync.  Raises if a one-launch step abandoned its device-wide meeting point (another kernel held compute units
+        for about a second: the stage-1 scores were then taken against an incomplete coarse winner).  The kernel poisons such a
+        step's outputs (NaN scores, index -1, NaN rotation), so the failure cannot be mistaken for a result; this names it."""
+        if self.fused and self._fused_state.gave_up():
+            raise RuntimeError("ahv_coarse_to_fine_f32: a workgroup gave up the meeting point (the device was shared with "
+                               "another kernel for ~1 s); this step's outputs are poisoned (NaN / -1). Use fused=False when "
+                               "other work runs on the GPU.")
+
+    def _reset_keys(self):
+        """After an exception inside a step the persistent keys may hold half a step's winners: hand them back empty."""
+        for k in self._keys:
+            k.fill_(KEY_EMPTY)
+        if self._fused_state is not None:
+            self._fused_state.keys.fill_(KEY_EMPTY)
+            self._fused_state.sync[:-1].zero_()
+
     @torch.no_grad()
     def __call__(self, vol_src: Optional[torch.Tensor] = None, vol_tgt: Optional[torch.Tensor] = None):
         """vol_src, vol_tgt (B,16,8,8,8) -> (fine score (B,), fine index (B,), R_pred (B,3,3),
@@ -139,7 +156,11 @@ class CoarseToFine:
         if not self.use_graph:
             if vol_src is None:
                 vol_src, vol_tgt = self.buffers
-            return self._step(vol_src, vol_tgt)
+            try:
+                return self._step(vol_src, vol_tgt)
+            except Exception:
+                self._reset_keys()  # a step that raised midway must not leave its winners to the next one
+                raise
         static = self.buffers
         if vol_src is not None and vol_src.data_ptr() != static[0].data_ptr():
             static[0].copy_(vol_src)

@@ -97,10 +97,30 @@ def test_one_launch_step_with_team_tails_and_per_sample_sets(ahv, setup):
     score, idx, R_pred, c_score, c_idx = [t.clone() for t in five(vs, vt)]
     r = ops.coarse_to_fine(vs, vt, R, five.D, W1, W2, b2, want_scores=True)
     assert torch.equal(r["coarse_idx"], c_idx) and torch.equal(r["fine_idx"], idx)
-    assert torch.allclose(r["coarse_scores"], five.last["coarse_scores"], atol=5e-7, rtol=0)
+    assert torch.equal(r["coarse_scores"], five.last["coarse_scores"])      # teams or single waves: the same bits
     assert torch.allclose(r["fine_scores"], five.last["fine_scores"], atol=5e-7, rtol=0)
     assert torch.allclose(r["fine_score"], score, atol=5e-7, rtol=0) and torch.equal(r["R_pred"], R_pred)
     assert not r["state"].gave_up()
+
+
+def test_one_launch_step_that_gave_up_is_poisoned_and_named(ahv, setup):
+    """a workgroup that abandons the device-wide meeting point (CUs held by another kernel for ~1 s)
+    scores stage 1 against an incomplete coarse key.  The launch sets its sticky error word -- and the last workgroup then
+    writes POISON instead of results (NaN scores, index -1, NaN rotation), so the failure cannot pass for a result, and
+    CoarseToFine.check() names it.  The give-up itself needs a second of starvation; here the error word is set by hand,
+    which is the state the decode sees after one."""
+    dev, vs3, vt3, W1, W2, b2 = setup
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(3000, 29)).to(dev)
+    c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=200, batch=2, use_graph=False, fused=True)
+    good = [t.clone() for t in c2f(vs3[:2].contiguous(), vt3[:2].contiguous())]
+    c2f.check()                                                    # nothing to report
+    assert torch.isfinite(good[0]).all() and (good[1] >= 0).all()
+    c2f._fused_state.sync[-1] = 1
+    score, idx, R_pred, c_score, c_idx = c2f(vs3[:2].contiguous(), vt3[:2].contiguous())
+    assert torch.isnan(score).all() and torch.isnan(c_score).all() and torch.isnan(R_pred).all()
+    assert (idx == -1).all() and (c_idx == -1).all()
+    with pytest.raises(RuntimeError, match="gave up the meeting point"):
+        c2f.check()
 
 
 def test_one_launch_step_through_CoarseToFine_eager_and_from_a_graph(ahv, setup):

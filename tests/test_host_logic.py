@@ -109,3 +109,54 @@ def test_lds_conflict_simulation_backs_the_table_in_ahv_device_h():
         k = bin(mask).count("1")
         want = ((0 if first else 4) + ((k >> 1) & 3), 2 * (lane >> 5) + (k >> 3), k & 1)
         assert tuple(box[0, 0, lane].astype(int)) == want, lane
+
+
+def test_estimator_tries_the_reference_backbone_factory(ahv, tmp_path, monkeypatch):
+    """modules/model_co3d.py:32: ``Estimator(cfg)`` builds ``DPT_SwinV2_T_256(pretrained=True)`` from MiDaS/hubconf.py.  The
+    mirror attempts exactly that (MiDaS dir from cfg / $AHV_MIDAS_DIR / ./MiDaS): with a hubconf present the one-argument
+    constructor yields a model whose forward(img, img) runs; without one (or with a failing factory) it says why."""
+    import sys
+    est = ahv.estimator
+    cfg = {"DATA": {"NUM_ROTA": 8, "ACC_THR": 15.0}, "TRAIN": {"LR": 1e-4, "MASK": False, "MASK_RATIO": 0.0}}
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("AHV_MIDAS_DIR", raising=False)
+    sys.modules.pop("hubconf", None)
+    m = est.Estimator(cfg)
+    assert m.feature_extractor is None and "no MiDaS/hubconf.py" in est.midas_unavailable_reason
+    with pytest.raises(RuntimeError, match="hubconf"):
+        m.forward(torch.zeros(1, 3, 256, 256), torch.zeros(1, 3, 256, 256))
+    # a stand-in MiDaS checkout: same factory name, same forward_transformer contract (layer_4 = (B,768,8,8))
+    midas = tmp_path / "MiDaS"
+    midas.mkdir()
+    (midas / "hubconf.py").write_text(
+        "import torch\n"
+        "class _DPT(torch.nn.Module):\n"
+        "    def __init__(self, pretrained):\n"
+        "        super().__init__()\n"
+        "        self.loaded = pretrained\n"
+        "        self.pretrained = torch.nn.Conv2d(3, 768, 32, stride=32)\n"
+        "    def forward_transformer(self, pretrained, x):\n"
+        "        y = pretrained(x)\n"
+        "        return y, y, y, y\n"
+        "def DPT_SwinV2_T_256(pretrained=True, **kw):\n"
+        "    return _DPT(pretrained)\n")
+    try:
+        m = est.Estimator(cfg)                      # found through ./MiDaS, the reference's working directory
+        assert type(m.feature_extractor).__name__ == "_DPT" and m.feature_extractor.loaded is True
+        assert est.midas_unavailable_reason == ""
+        torch.manual_seed(0)
+        with torch.no_grad():
+            v_src, v_tgt = m.forward(torch.randn(1, 3, 256, 256), torch.randn(1, 3, 256, 256))
+        assert v_src.shape == (1, 16, 8, 8, 8) and v_tgt.shape == (1, 16, 8, 8, 8) and torch.isfinite(v_src).all()
+        assert any(k.startswith("feature_extractor.pretrained.") for k in m.state_dict())   # checkpoint keys as the reference's
+        monkeypatch.setenv("AHV_MIDAS_PRETRAINED", "0")
+        assert est.Estimator(cfg).feature_extractor.loaded is False
+        # a factory that fails (timm missing, no network): None + the reason, no exception out of the constructor
+        (midas / "hubconf.py").write_text("def DPT_SwinV2_T_256(pretrained=True, **kw):\n    raise ImportError('No module named timm')\n")
+        sys.modules.pop("hubconf", None)
+        m = est.Estimator({**cfg, "MODEL": {"MIDAS_DIR": str(midas)}})
+        assert m.feature_extractor is None and "No module named timm" in est.midas_unavailable_reason
+    finally:
+        sys.modules.pop("hubconf", None)
+        if str(midas) in sys.path:
+            sys.path.remove(str(midas))

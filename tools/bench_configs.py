@@ -95,41 +95,42 @@ if not only or "shard" in only:
     for N in (1000, 6250, 10_000, 12_500, 25_000, 50_000):
         R = torch.from_numpy(ahv.rotations.haar_rotations_np(N, 9)).to(dev)
         row = {"config": "shard B=1", "N": N}
-        for name, kw in (("teams", {}), ("single_waves", {"no_teams": True})):
+        def make_step(kw, k=None, R_=R):
+            k = key if k is None else k
             def step():
-                ops.verify_pair(vs, vt, R, W1, W2, b2, want_scores=False, best_key=key, reset_best=False, **kw)
-                ops.select_rotation(key, R, reset_key=True)
-            row["us_per_step_" + name] = timeit(step, 200, warm=20) * 1e3
+                ops.verify_pair(vs, vt, R_, W1, W2, b2, want_scores=False, best_key=k, reset_best=False, **kw)
+                ops.select_rotation(k, R_, reset_key=True)
+            return step
+        for name, kw in (("teams", {}), ("single_waves", {"no_teams": True})):
+            row["us_per_step_" + name] = timeit(make_step(kw), 200, warm=20) * 1e3
         row["hyp_per_s"] = N / row["us_per_step_teams"] * 1e6
-        # two lanes: groups of 8 steps alternate between two streams (each with its own key), so that one step's drain
-        # (the wait for the slowest workgroup), the launch gap and the next step's prologue overlap
-        lanes = [(torch.cuda.Stream(), key.clone()) for _ in range(2)]
-        state = {"i": 0}
+        # the multi-rank cadence: 8 verify launches per select (bench.py under a process group), one stream and two.
+        # Two lanes: the groups alternate between two streams, each with its own keys, so that one step's drain -- the wait
+        # for the slowest workgroup, the launch gap, the next prologue -- overlaps the next step's hypotheses.
+        keys8 = [torch.full((8, 1), -(1 << 63), dtype=torch.int64, device=dev) for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
-        def step2():
-            st, k = lanes[(state["i"] // 8) & 1]
-            state["i"] += 1
-            with torch.cuda.stream(st):
-                ops.verify_pair(vs, vt, R, W1, W2, b2, want_scores=False, best_key=k, reset_best=False)
-                ops.select_rotation(k, R, reset_key=True)
-        for st, _ in lanes:
-            st.wait_stream(torch.cuda.current_stream())
-        t0 = time.perf_counter()
-        for _ in range(64):
-            step2()
-        torch.cuda.synchronize()
-        state["i"] = 0
-        t0 = time.perf_counter()
-        for _ in range(400):
-            step2()
-        torch.cuda.synchronize()
-        row["us_per_step_two_lanes_wall"] = (time.perf_counter() - t0) / 400 * 1e6
-        state["i"] = 0
-        t0 = time.perf_counter()
-        for _ in range(400):
-            step()
-        torch.cuda.synchronize()
-        row["us_per_step_one_lane_wall"] = (time.perf_counter() - t0) / 400 * 1e6
+        def run_groups(n_groups, lanes):
+            main = torch.cuda.current_stream()
+            for g in range(n_groups):
+                k8 = keys8[g % lanes]
+                if lanes > 1:
+                    torch.cuda.set_stream(streams[g % lanes])
+                for j in range(8):
+                    ops.verify_pair(vs, vt, R, W1, W2, b2, want_scores=False, best_key=k8[j], reset_best=False)
+                ops.select_rotation(k8.view(-1), R, reset_key=True)
+            if lanes > 1:
+                torch.cuda.set_stream(main)
+
+        for lanes in (1, 2):
+            for s_ in streams:
+                s_.wait_stream(torch.cuda.current_stream())
+            run_groups(8, lanes)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_groups(50, lanes)
+            torch.cuda.synchronize()
+            row["us_per_step_8_per_select" + ("" if lanes == 1 else "_two_lanes")] = (time.perf_counter() - t0) / 400 * 1e6
         print(json.dumps(row))
 
 if not only or "enc" in only:

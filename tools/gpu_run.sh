@@ -53,11 +53,15 @@ bench)
     timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err; echo "20/5 rc=$?"
     timeout -k 10 600 python3 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_200_20.json 2> $O/bench_200_20.err; echo "200/20 rc=$?"
     AHV_BENCH_FORCE_PG=1 timeout -k 10 600 python3 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_forced_pg.json 2> $O/bench_forced_pg.err; echo "forced pg rc=$?"
-    AHV_BENCH_BACKEND=gloo timeout -k 10 600 python3 bench.py --gpus 2 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo "2-rank gloo rc=$?"
+    timeout -k 10 600 python3 bench.py --gpus 2 --backend gloo --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo "2-rank gloo rc=$?"
     tail -c 1500 $O/bench_20_5.json
     ;;
 oplevel)
     timeout -k 10 600 bash tools/profile_oplevel.sh $tag > $O/profile_oplevel.log 2>&1; echo rc=$?; tail -5 $O/profile_oplevel.log
+    timeout -k 10 300 python3 tools/bench_configs.py 3 4 5 shard > $O/secondary.jsonl 2> $O/secondary.err; echo rc=$?; cat $O/secondary.jsonl
+    ;;
+benchtest)
+    timeout -k 10 900 python -m pytest tests/test_gpu_bench_contract.py -x -q -m gpu > $O/pytest_bench.log 2>&1; echo "pytest rc=$?"; tail -15 $O/pytest_bench.log
     ;;
 encoder)
     timeout -k 10 300 tools/kbench_enc.bin 1 --each > $O/enc_marginal.txt 2>&1; echo rc=$?

@@ -8,8 +8,8 @@ cd /tmp; export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-# --skip-strong-scaling: those legs launch the same kernel at B = 32 and would mix into the per-kernel averages
-CMD="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip-strong-scaling"
+# --skip-secondary: those legs launch the same kernel at other shapes and would mix into the per-kernel averages
+CMD="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || exit 1

@@ -48,11 +48,30 @@ if trace:
         steady = {"launches_dropped_before_plateau": k, "calls": len(rest), "median_ns": rest[len(rest) // 2],
                   "mean_ns": sum(rest) / len(rest), "min_ns": rest[0], "max_ns": rest[-1],
                   "first_launches_ns": [round(d) for d in durs[:8]]}
-summary = {"kernel": kname, "command": "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip-strong-scaling (tools/profile_bench.sh)",
+summary = {"kernel": kname, "command": "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --skip-secondary (tools/profile_bench.sh)",
            "kernel_trace": {"calls": calls, "average_ns": avg_ns, "steady_state": steady}, "counters": out}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     f, w = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
     summary["hbm_bytes_per_launch"] = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
                                        "value": (2 * f + w) * 1024, "fetch_kb": f, "write_kb": w}
 json.dump(summary, open(os.path.join("profiles", tag + suffix + "_pmc_summary.json"), "w"), indent=1)
+if "hbm_bytes_per_launch" in summary and not suffix and "--no-traffic" not in sys.argv:
+    # profiles/traffic.json: what bench.py replays as roofline.traffic -- with the hash of the scorer's sources the counters
+    # were taken on (bench.py reports the figure only while the hash still matches) and the commit it was taken at
+    import hashlib, subprocess
+    h = hashlib.sha256()
+    for name in ("ahv_score.hip", "ahv_device.h", "ahv_dual.h", "ahv_team.h", "ahv_exact.h", "ahv_split.h"):
+        h.update(open(os.path.join("3dahv_amd", "csrc", name), "rb").read())
+    try:
+        commit = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "3dahv_amd/csrc"], text=True).strip())
+    except Exception:
+        commit, dirty = None, None
+    json.dump({"fused_hbm_bytes_per_launch": summary["hbm_bytes_per_launch"]["value"],
+               "source": "profiles/%s_pmc_summary.json" % tag, "source_commit": commit, "source_tree_dirty": dirty,
+               "kernel_src_sha": h.hexdigest(), "formula": summary["hbm_bytes_per_launch"]["formula"],
+               "note": "ahv_verify_pair_f32 launch at N = 50 000, want_scores=False: 1.8 MB of R is the algorithmic read; the rest "
+                       "is per-workgroup constants (W1 48 KB + two volumes 64 KB per workgroup, 256 workgroups: L2 hits of which "
+                       "~1 MB reach the fabric counters) and the clock stamps of the diagnostic entry point"},
+              open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
