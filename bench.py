@@ -7,7 +7,7 @@ MI355X": strong scaling -- the hypothesis axis is cut into contiguous shards, ra
     forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max   ONE launch, ahv_verify_pair_f32
                                                                           (test_co3d.py:137-145)
     [N > 1: all-reduce(MAX) of the packed int64 keys over RCCL -- the keys of 8 steps per collective, in stream order]
-    decode the keys, gather R_pred = proposals[idx], hand the keys back empty   ONE launch per collective (test_co3d.py:145-146)
+    decode the keys, gather R_pred = proposals[idx], hand the keys back empty   ONE launch per 8 steps (test_co3d.py:145-146)
 Inputs are resident in HBM before the timed region.  `value` = 50 000 x steps / time: the whole job's hypotheses per
 second ("scaling": "strong").  The same run also times, as named secondary records: the per-step-collective cadence
 (one all-reduce + select per step), weak scaling (50 000 hypotheses PER RANK), BASELINE.json configs[3] (B = 32 x 50 000
@@ -234,8 +234,8 @@ def kernel_source_sha() -> str:
 class VerifyLoop:
     """One rank's verify steps on a fixed workload (the reference's per-pair hot loop, test_co3d.py:137-146):
         step i   = ONE fused launch: forward_3d2d(vol_tgt) + rotate + forward_3d2d + score + running max into its key slot
-        finalize = ONE launch per group of `group` steps: decode the keys, gather R_pred = proposals[idx], hand the keys
-                   back EMPTY (single process: group = 1, i.e. one select per step)
+        finalize = ONE launch per group of `group` steps (8): decode the keys, gather R_pred = proposals[idx], hand the keys
+                   back EMPTY
     With a process group the keys of `group` consecutive steps travel in ONE all-reduce(MAX) of group * B int64 words, issued
     in stream order (what a collective costs beside a 0.1 ... 0.7-ms kernel is its fixed part -- the event packets torch
     puts around it, 17 ... 36 us with a one-rank RCCL group, profiles/r04ab_process_group_variants.jsonl -- not its bytes).
@@ -350,7 +350,9 @@ def worker(args):
     split = bool(args.split_f16)
     # Under a process group the keys of `group` steps share one all-reduce, issued in stream order (DESIGN.md section 6:
     # what a collective costs is the event packets around it, not its bytes; the per-step cadence is timed beside it).
-    group = int(os.environ.get("AHV_BENCH_STEPS_PER_COLLECTIVE", "8" if use_pg else "1"))
+    # The same cadence without a group (one select per 8 steps): pairs are independent, nothing needs a step's winner before
+    # the next step starts (the reference appends it to a list, test_co3d.py:152), and N = 1 and N > 1 then time the same loop.
+    group = int(os.environ.get("AHV_BENCH_STEPS_PER_COLLECTIVE", "8"))
 
     vol_src, vol_tgt, W1, W2, b2, R_all = synth_inputs(ahv, dev, rank)
     head = (W1, W2, b2)
@@ -488,7 +490,7 @@ def worker(args):
             B = vs.shape[0]
             total = n_total if shard else n_total * world
             return lp, {"n_hyp_total": total, "B": B, "n_hyp_per_rank": b - a, "steps": steps, "warmup": warmup,
-                        "steps_per_collective": lp.group if use_pg else None, "lanes": lanes,
+                        "steps_per_collective": lp.group if use_pg else None, "steps_per_select": lp.group, "lanes": lanes,
                         "ms_per_step": t / steps * 1e3, "hypotheses_per_s": B * total * steps / t, "pairs_per_s": B * steps / t}
 
         sec_steps = max(24, min(args.steps, 96))
@@ -581,7 +583,7 @@ def worker(args):
                                "ahv_verify_pair_f32)%s + ONE select launch per %d step(s) (decode + gather R_pred + key reset)" % (
                                    " + ONE all-reduce(MAX) of the int64 keys of %d steps, in stream order" % loop.group
                                    if use_pg else "", loop.group),
-                       "steps_per_collective": loop.group if use_pg else None},
+                       "steps_per_collective": loop.group if use_pg else None, "steps_per_select": loop.group},
             # what the timed region computed (asserted above against torch.max over the materialised scores of
             # all ranks): lets a forced-process-group run be compared with a single-process run
             "result": {"best_idx": int(out["idx"].item()), "best_score": float(out["best"].item())},

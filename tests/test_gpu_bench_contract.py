@@ -59,7 +59,8 @@ def test_bench_json_line():
     # the secondary records of the same run
     sec = d["secondary"]
     a, b, w, two = (sec[k] for k in ("n50k_b1_collective_per_step", "configs3_b32_n50k", "weak_n50k_per_rank_b1", "n50k_b1_two_lanes"))
-    assert a["n_hyp_total"] == 50000 and a["n_hyp_per_rank"] == 50000 and a["B"] == 1
+    assert a["n_hyp_total"] == 50000 and a["n_hyp_per_rank"] == 50000 and a["B"] == 1 and a["steps_per_select"] == 1
+    assert d["config"]["steps_per_select"] == 8
     assert b["n_hyp_total"] == 50000 and b["B"] == 32 and b["steps"] == 5
     assert w["n_hyp_total"] == 50000 and two["lanes"] == 2 and a["lanes"] == 1
     assert abs(a["hypotheses_per_s"] - 50000 / (a["ms_per_step"] * 1e-3)) / a["hypotheses_per_s"] < 1e-6
