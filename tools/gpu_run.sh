@@ -67,6 +67,18 @@ encoder)
     timeout -k 10 300 tools/kbench_enc.bin 1 --each > $O/enc_marginal.txt 2>&1; echo rc=$?
     timeout -k 10 300 python3 tools/bench_configs.py enc enchost > $O/enc.jsonl 2> $O/enc.err; echo rc=$?; cat $O/enc.jsonl
     ;;
+encoder32)
+    cd /tmp; cd "$GRAFT_REPO_ROOT"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 tools/enc_b32.py 32 > $O/enc_b32.log 2>&1; echo rc=$?; tail -2 $O/enc_b32.log
+    python3 - <<PY
+import csv, glob
+st = glob.glob("$O/trace/*/*_kernel_stats.csv")[0]
+rows = [r for r in csv.DictReader(open(st)) if "ahv::" in r["Name"]]
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+    print("%-70s calls %4s avg %8.1f us  %5.1f %%" % (r["Name"].split("(")[0][-70:], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+PY
+    ;;
 eor)
     bash tools/gpu_end_of_round.sh $tag
     ;;
