@@ -121,6 +121,22 @@ int main(int argc, char** argv)
     }
     printf("  workgroups %d: first entry -> last exit %.1f us; mean entry delay %.1f us, prologue %.1f us, loop %.1f us, idle at the end %.1f us\n",
            nwg, (t1 - t0) * 0.01, entry / nwg, pro / nwg, loop / nwg, idle / nwg);
+    {   // distribution of the workgroups' exit times (relative to the first entry) and of their loop lengths
+        std::vector<double> ex, lp;
+        for (int w = 0; w < 1024; ++w) if (wg[4 * w + 2]) { ex.push_back((wg[4 * w + 2] - t0) * 0.01); lp.push_back((wg[4 * w + 2] - wg[4 * w + 1]) * 0.01); }
+        std::sort(ex.begin(), ex.end()); std::sort(lp.begin(), lp.end());
+        auto q = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        printf("  exit time   min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us\n", ex.front(), q(ex, .1), q(ex, .5), q(ex, .9), q(ex, .99), ex.back());
+        printf("  loop length min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us\n", lp.front(), q(lp, .1), q(lp, .5), q(lp, .9), q(lp, .99), lp.back());
+        // the ten slowest workgroups: index (= blockIdx.x), XCC, loop length
+        std::vector<std::pair<double, int>> byexit;
+        for (int w = 0; w < 1024; ++w) if (wg[4 * w + 2]) byexit.push_back({(wg[4 * w + 2] - t0) * 0.01, w});
+        std::sort(byexit.begin(), byexit.end());
+        printf("  slowest:");
+        for (size_t i = byexit.size() >= 10 ? byexit.size() - 10 : 0; i < byexit.size(); ++i)
+            printf(" wg%d(xcc%d %.1f)", byexit[i].second, (int)(wg[4 * byexit[i].second + 3] & 15), byexit[i].first);
+        printf("\n");
+    }
     {   // shader clock held during the loop: s_memtime ticks per 10-ns real-time tick, median over workgroups
         std::vector<unsigned long long> ck(1024 * 2);
         CK(hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(ahv::g_wgclk), ck.size() * 8));
