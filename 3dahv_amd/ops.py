@@ -209,9 +209,10 @@ def score_hypotheses(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Ten
     Decode with ``unpack_best``; ``n_offset`` is the global index of R[0] when N is sharded.
     ``split_f16``: opt-in kernel for this call (None: the enclosing ``split_f16_scorer`` block, else fp32).
     ``clock_stamps`` (int64, 4 * CU count, zeroed): diagnostic launch that also records the shader clock.
-    ``no_teams``: AHV_SCORE_NO_TEAMS -- every hypothesis by one wave, so that a score does not depend (in its last
-    bits) on N or on the hypothesis' position; ``spare_cus``: compute units left without a workgroup of the persistent
-    grid (room for a concurrent small kernel, e.g. the previous step's RCCL all-reduce).
+    ``no_teams``: AHV_SCORE_NO_TEAMS -- every hypothesis by one wave.  A scheduling knob only: by default a launch's
+    remainder goes to teams of four waves, whose score is the lone wave's bit for bit (a score is a function of the
+    volumes, the weights and R_n alone -- not of N, of ``n_offset`` or of how a set is sharded); ``spare_cus``: compute
+    units left without a workgroup of the persistent grid (a measurement knob, include/ahv_diag.h).
     With autograd recording and an input that requires grad, the returned scores carry the autograd edge of
     ``score_hypotheses_autograd`` (HIP backward) -- like the reference's op sequence, nothing is silently detached.
     """
@@ -380,9 +381,8 @@ class _ScoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2, n_offset=0, best_key=None, reset_best=None, split_f16=None):
-        # single waves only: the backward differentiates exactly this forward (teams associate the sums differently)
         scores, key = _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, True, best_key, reset_best,
-                                               split_f16, None, no_teams=True)
+                                               split_f16, None)
         ctx.save_for_backward(vol_src, feat_tgt, R, W1, W2, b2)
         ctx.mark_non_differentiable(key)
         return scores, key

@@ -10,11 +10,13 @@ echo "== bench 20/5" && timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 -
 echo "== bench 200/20" && timeout -k 10 600 python3 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_200_20.json 2> $O/bench_200_20.err; echo rc=$?
 echo "== bench forced pg" && AHV_BENCH_FORCE_PG=1 timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_forced_pg.json 2> $O/bench_forced_pg.err; echo rc=$?
 echo "== profile bench" && timeout -k 10 900 bash tools/profile_bench.sh ${1:-eor} > $O/profile.log 2>&1; echo rc=$?
-echo "== secondary" && timeout -k 10 600 python3 tools/bench_configs.py 3 4 5 > $O/secondary.jsonl 2> $O/secondary.err; echo rc=$?
+echo "== bench 2-rank gloo (rehearsal on one GPU)" && timeout -k 10 600 python3 bench.py --gpus 2 --backend gloo --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo rc=$?
+echo "== secondary" && timeout -k 10 600 python3 tools/bench_configs.py 3 4 5 shard > $O/secondary.jsonl 2> $O/secondary.err; echo rc=$?
 echo "== pairs" && timeout -k 10 600 python3 tools/bench_configs.py pairs > $O/pairs.jsonl 2> $O/pairs.err; echo rc=$?
 echo "== enc" && timeout -k 10 300 python3 tools/bench_configs.py enc enchost > $O/enc.jsonl 2> $O/enc.err; echo rc=$?
 echo "== train" && timeout -k 10 600 python3 tools/bench_configs.py train train9000 > $O/train.jsonl 2> $O/train.err; echo rc=$?
 echo "== kbench_enc" && timeout -k 10 300 tools/kbench_enc.bin 1 --each > $O/enc_marginal.txt 2>&1; echo rc=$?
 echo "== profile train" && timeout -k 10 600 bash tools/profile_train.sh ${1:-eor} > $O/profile_train.log 2>&1; echo rc=$?
 echo "== profile encoder" && timeout -k 10 600 bash tools/profile_encoder.sh ${1:-eor} > $O/profile_encoder.log 2>&1; echo rc=$?
+echo "== profile op-level" && timeout -k 10 600 bash tools/profile_oplevel.sh ${1:-eor} > $O/profile_oplevel.log 2>&1; echo rc=$?
 echo done
