@@ -109,8 +109,6 @@ __device__ __forceinline__ void exact_axis(ExactAxis& a, float g, int scale_byte
 
 // Quarter q (d in {2q, 2q+1}) of the rotated volume into the swizzled quarter image `buf`, corner by corner as ATen does
 // it.  Lane -> voxel as in the round-1 gather: (w = l & 7, d0 = (l >> 3) & 1, h = 4 p + 2 (l >> 5) + ((l >> 4) & 1)).
-// LINEAR: the image is X[c][voxel = a0 * 64 + h * 8 + w] (rotate_volume) instead of the scorer's swizzled quarter image.
-template <bool LINEAR = false>
 __device__ __forceinline__ void exact_gather_quarter(float* buf, const float* srcT, const float (&Rm)[9], int q, int lane)
 {
 #pragma clang fp contract(off)
@@ -145,9 +143,50 @@ __device__ __forceinline__ void exact_gather_quarter(float* buf, const float* sr
                 }
             }
         }
-        float* dst = buf + (LINEAR ? a0 * 64 + b * 8 + e : qoff(a0, b, e));
+        float* dst = buf + qoff(a0, b, e);
 #pragma unroll
         for (int c = 0; c < 16; ++c) dst[c * 128] = o[c];
+    }
+}
+
+// The same straight to global memory (rotate_volume): `oq` = out[n][0][128 q ...], channel planes 512 floats apart.
+__device__ __forceinline__ void exact_gather_quarter_global(float* oq, const float* srcT, const float (&Rm)[9], int q, int lane)
+{
+#pragma clang fp contract(off)
+    const int e = lane & 7, a0 = (lane >> 3) & 1, b0 = (lane >> 4) & 1, b1 = lane >> 5;
+    const float x = (2.0f * (float)e + 1.0f) / 8.0f - 1.0f;
+    const float z = (2.0f * (float)(2 * q + a0) + 1.0f) / 8.0f - 1.0f;
+#pragma unroll 1
+    for (int p = 0; p < 2; ++p) {
+        const int b = 4 * p + 2 * b1 + b0;
+        const float y = (2.0f * (float)b + 1.0f) / 8.0f - 1.0f;
+        const float gx = Rm[0] * x + Rm[1] * y + Rm[2] * z;
+        const float gy = Rm[3] * x + Rm[4] * y + Rm[5] * z;
+        const float gz = Rm[6] * x + Rm[7] * y + Rm[8] * z;
+        ExactAxis ax, ay, az;
+        exact_axis(ax, gx, 4 * kSrcStride);
+        exact_axis(ay, gy, 4 * kSrcRowsY * kSrcStride);
+        exact_axis(az, gz, 4 * kSrcPlaneRows * kSrcStride);
+        float o[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) o[c] = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int dx = n & 1, dy = (n >> 1) & 1, dz = n >> 2;
+            if (ax.in[dx] && ay.in[dy] && az.in[dz]) {
+                const float w = ax.w[dx] * ay.w[dy] * az.w[dz];
+                const f32x4* row = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(srcT) + az.off[dz] + ay.off[dy] + ax.off[dx]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = row[j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[4 * j + k] = o[4 * j + k] + w * v[k];
+                }
+            }
+        }
+        float* dst = oq + a0 * 64 + b * 8 + e;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c * 512] = o[c];
     }
 }
 

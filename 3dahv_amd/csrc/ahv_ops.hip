@@ -12,36 +12,65 @@ namespace ahv {
 // rotate_volume, fast path: volume (16,8,8,8) shared by all N hypotheses (the stride-0
 // expand of test_co3d.py:137).  HBM: 36 B in + 32 KiB out per hypothesis -> write-bandwidth bound,
 // provided the kernel needs less than the ~3 500 cycles per hypothesis and CU that 5.7 TB/s leave it.
-// Rounds 1-4 (tri_coef + tri_blend per voxel, 4-byte stores in 256-byte segments) needed ~2 100 vector
-// instructions per hypothesis and reached 5.14 TB/s = 0.82 of a copy.  Round 5: the fused scorer's gather --
-// hat weights on a clamped base row, one base address per voxel, the request ring, packed FMAs, the
-// point-mirror quarters (ahv_dual.h: ~650 vector instructions per hypothesis) -- blends a QUARTER
-// (128 voxels x 16 channels) into the wave's LDS image X[c][voxel]; the image is read back row-wise and leaves as
-// eight global_store_dwordx4 per quarter (16 bytes per lane, two 512-byte channel segments per instruction,
-// non-temporal): the transposition goes through the LDS, not through registers (round 4's four-voxels-per-lane
-// attempt needed 240 of them).  One wave per hypothesis, 4 waves per workgroup, 79.5 KiB of LDS -> 2 workgroups per CU.
+// Rounds 1-4 (tri_coef + tri_blend per voxel) needed ~2 100 vector instructions per hypothesis and reached 5.14 TB/s.
+// Round 5: the fused scorer's gather -- hat weights on a clamped base row, one base address per voxel, the request ring,
+// packed FMAs, the point-mirror quarters (ahv_dual.h: ~900 vector instructions per hypothesis) -- with a store that goes
+// straight to global memory: one non-temporal 4-byte store per channel and pass, two whole 128-byte lines per instruction.
+// No LDS besides the source image (47.5 KiB) -> three workgroups = 12 waves per CU at <= 168 registers (ring depth 2:
+// 3 and 4 rows spill).  First built with a per-wave LDS image and 16-byte stores (8 waves per CU): 1.245 ms against
+// 1.19-1.21 ms for this one on the same box, N = 200 000 (5.27 vs 5.43-5.52 TB/s; the minimum of ten launches 5.8).
+// What bounds it is the store stream itself: the same kernel with the gather removed (-DAHV_DIAG_ROT_STORE_ONLY) and
+// tools/store_probe.cpp (this store pattern, others, and a plain fill, from the same persistent grid) write 6.55 GB at
+// 5.3-6.1 TB/s whatever the pattern -- one 32 KiB region per wave, ~3 000 regions open at once -- and the gather with its
+// bank conflicts switched off (-DAHV_DIAG_LINEAR_GATHER) is no faster.
 // A NaN / inf voxel: the workgroup sees it while staging and every hypothesis of the launch goes through
-// exact_gather_quarter (ahv_exact.h: grid_sample's per-corner zeros padding, utils.py:129) instead.
+// exact_gather_quarter_global (ahv_exact.h: grid_sample's per-corner zeros padding, utils.py:129) instead.
 // ---------------------------------------------------------------------------------
 constexpr int kRotThreads = 256;
-constexpr int kRotImgFloats = 16 * 128;  // one quarter X[c][voxel], voxel = a0 * 64 + h * 8 + w: the output's own order
+#ifndef AHV_DIAG_ROT_DEPTH
+#define AHV_DIAG_ROT_DEPTH 2
+#endif
+constexpr int kRotDepth = AHV_DIAG_ROT_DEPTH;  // rows the gather requests ahead: 2 -> 160 registers, 3 / 4 -> 8 / 22 spills and slower
 
-// image -> out[n][c][128 Q + ...]: lane l reads channel 2 k + (l >> 5), voxels 4 (l & 31) .. + 3
-__device__ __forceinline__ void rot_flush_quarter(float* __restrict__ o, const float* img, int lane)
+// Where a blended voxel goes: straight to out[n][c][...], one non-temporal 4-byte store per channel.  In a pass the 64 lanes
+// own the voxels (a0, 4 p + bq, e) of the quarter -- two runs of 32 consecutive floats per channel plane -- so every store
+// instruction writes two whole 128-byte lines.
+struct RotStoreGlobal {
+    static constexpr bool kXdlKernel = kFp32LowHalf;
+    static constexpr int kDepth = kRotDepth;
+    float* d[2];  // the lane's voxel of pass 0 / pass 1 in channel plane 0 of this quarter
+    __device__ __forceinline__ void operator()(int p, const f32x2 (&o)[8]) const
+    {
+        float* dst = d[p];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+#ifdef AHV_DIAG_ROT_TEMPORAL
+            dst[c * 512] = o[c >> 1][c & 1];
+#else
+            __builtin_nontemporal_store(o[c >> 1][c & 1], dst + c * 512);
+#endif
+        }
+    }
+};
+
+template <bool MIR>
+__device__ __forceinline__ void rot_quarter(HatState& st, float* oq, const GatherDst& dst)
 {
-    const int v4 = 4 * (lane & 31), ch = lane >> 5;
-    f32x4 x[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const f32x4*>(img + (2 * k + ch) * 128 + v4);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(x[k], reinterpret_cast<f32x4*>(o + (2 * k + ch) * 512 + v4));
+    f32x2 o[8];
+    const RotStoreGlobal store = {{oq + (MIR ? dst.m0 : dst.o0), oq + (MIR ? dst.m1 : dst.o1)}};
+#ifdef AHV_DIAG_ROT_STORE_ONLY   // the store stream alone (wrong results): what the gather costs on top of it
+    for (int c = 0; c < 8; ++c) o[c] = f32x2{st.vx[0].w[0], st.vx[1].w[0]};
+    store(0, o);
+    store(1, o);
+#else
+    HatSteps<0, RotStoreGlobal, MIR>::run(st, o, store);
+#endif
 }
 
-__global__ __launch_bounds__(kRotThreads) void rotate_volume_16x8_kernel(
+__global__ __launch_bounds__(kRotThreads, 3) void rotate_volume_16x8_kernel(
     const float* __restrict__ vol, const float* __restrict__ R, long N, float* __restrict__ out)
 {
     __shared__ __attribute__((aligned(1024))) float srcT[kSrcFloats];
-    __shared__ __attribute__((aligned(16))) float img[4 * kRotImgFloats];
     __shared__ unsigned nf;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,7 +88,6 @@ __global__ __launch_bounds__(kRotThreads) void rotate_volume_16x8_kernel(
     }
     __syncthreads();
     const bool exact = __builtin_amdgcn_readfirstlane((int)nf) != 0;
-    float* buf = img + wave * kRotImgFloats;
     const GatherLane glane = gather_lane(lane);
     GatherDst gdst = gather_dst_linear(lane);
     asm volatile("" : "+v"(gdst.m0), "+v"(gdst.m1));
@@ -78,26 +106,25 @@ __global__ __launch_bounds__(kRotThreads) void rotate_volume_16x8_kernel(
             gather_hyp(gh, Rm, glane);
             HatState st;
             // quarters in the order 0, 3, 1, 2: quarter 3 - Q is the point mirror of quarter Q and reuses its set-up
-            hat_prologue<0>(st, srcT, gh);
-            hat_body_linear<128>(st, buf, gdst); wave_lds_fence();
-            rot_flush_quarter(o, buf, lane); wave_lds_fence();
-            hat_prologue_mirror(st, srcT);
-            hat_body_linear<128, true>(st, buf, gdst); wave_lds_fence();
-            rot_flush_quarter(o + 3 * 128, buf, lane); wave_lds_fence();
-            hat_prologue<1>(st, srcT, gh);
-            hat_body_linear<128>(st, buf, gdst); wave_lds_fence();
-            rot_flush_quarter(o + 128, buf, lane); wave_lds_fence();
-            hat_prologue_mirror(st, srcT);
-            hat_body_linear<128, true>(st, buf, gdst); wave_lds_fence();
-            rot_flush_quarter(o + 2 * 128, buf, lane); wave_lds_fence();
+#ifdef AHV_DIAG_ROT_STORE_ONLY
+            st.vx[0].w[0] = gh.ixy[0][0]; st.vx[1].w[0] = gh.izp[1];
+            rot_quarter<false>(st, o, gdst); rot_quarter<true>(st, o + 3 * 128, gdst);
+            rot_quarter<false>(st, o + 128, gdst); rot_quarter<true>(st, o + 2 * 128, gdst);
+            continue;
+#endif
+            hat_prologue<0, kFp32LowHalf, kRotDepth>(st, srcT, gh);
+            rot_quarter<false>(st, o, gdst);
+            hat_prologue_mirror<kRotDepth>(st, srcT);
+            rot_quarter<true>(st, o + 3 * 128, gdst);
+            hat_prologue<1, kFp32LowHalf, kRotDepth>(st, srcT, gh);
+            rot_quarter<false>(st, o + 128, gdst);
+            hat_prologue_mirror<kRotDepth>(st, srcT);
+            rot_quarter<true>(st, o + 2 * 128, gdst);
         } else {
+            // a NaN / inf voxel: every hypothesis corner by corner as grid_sample does it (ahv_exact.h), through the
+            // same lane -> voxel map as the stores above expect nothing of: each lane writes its own voxels
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                exact_gather_quarter<true>(buf, srcT, Rm, q, lane);
-                wave_lds_fence();
-                rot_flush_quarter(o + q * 128, buf, lane);
-                wave_lds_fence();
-            }
+            for (int q = 0; q < 4; ++q) exact_gather_quarter_global(o + q * 128, srcT, Rm, q, lane);
         }
     }
 }
@@ -650,7 +677,7 @@ hipError_t launch_rotate_volume(const float* vol, int64_t vol_batch_stride, cons
 {
     if (C == 16 && D == 8 && H == 8 && W == 8 && vol_batch_stride == 0) {
         long blocks = (N + 3) / 4;
-        const long cap = (long)num_cu * 2;  // 79.5 KiB of LDS per workgroup: two per CU are resident
+        const long cap = (long)num_cu * 3;  // 47.5 KiB of LDS per workgroup: three per CU are resident
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(rotate_volume_16x8_kernel, dim3((unsigned)blocks), dim3(kRotThreads), 0, stream, vol,
                            R, (long)N, out);
