@@ -604,8 +604,8 @@ namespace ahv {
 // time (fragment reads, s_waitcnt, 8 MFMAs, next reads ...): every group of MFMAs starts with an exposed LDS
 // round trip that only the partner wave can cover.  Here the 192 MFMAs are cut into 12 chunks of 16; the A
 // fragments (LDS table) and B operands (quarter image) of chunk k+1 are requested before the MFMAs of chunk k
-// are issued (512 matrix-pipe cycles, several LDS latencies), and sched_barrier keeps hipcc from sinking the
-// reads back to their uses.  Same MFMAs, same order per accumulator as gemm1_quarter_lds: bit-identical sums.
+// are done (512 matrix-pipe cycles, several LDS latencies), and sched_barrier / sched_group_barrier keep hipcc from
+// sinking the reads back to their uses.  Same MFMAs, same order per accumulator as gemm1_quarter_lds: bit-identical sums.
 //   chunks 0-3: x slab, channels 4k..4k+3;  4-7: y slab;  8-11: z slab, channel pairs cpp = k - 8.
 // ---------------------------------------------------------------------------------------------------------
 struct G1Chunk {
@@ -671,11 +671,31 @@ struct G1Pipe {
                                                int i0, int j, int kq, Hook& hook)
     {
         G1Chunk nxt;
-        if (K + 1 < 12) g1_load<Q, K + 1>(nxt, T, buf, i0, j, kq);
-        if (K == kG1HookChunk) hook();
-        __builtin_amdgcn_sched_barrier(0);
-        g1_mfma<Q, K>(acc, cur);
-        __builtin_amdgcn_sched_barrier(0);
+        if (K == kG1HookChunk) {
+            if (K + 1 < 12) g1_load<Q, K + 1>(nxt, T, buf, i0, j, kq);
+            hook();
+            __builtin_amdgcn_sched_barrier(0);
+            g1_mfma<Q, K>(acc, cur);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // Issue order (round 5): the next chunk's LDS reads go BETWEEN this chunk's MFMAs, one behind each -- an MFMA
+            // holds the matrix pipe for 32 cycles in which the wave's issue slot is free.  All of them in front of the
+            // first MFMA (rounds 2-4) left the pipe waiting for their issue whenever the SIMD's other wave was not in a
+            // GEMM: +1.0 % on the whole kernel (tools/kbench, three alternating runs on two boxes).
+            __builtin_amdgcn_sched_barrier(0);
+            if (K + 1 < 12) g1_load<Q, K + 1>(nxt, T, buf, i0, j, kq);
+            g1_mfma<Q, K>(acc, cur);
+            if (K + 1 < 12) {
+                constexpr int NL = (K + 1 < 8) ? 12 : 9;  // LDS reads of the next chunk
+#pragma unroll
+                for (int g = 0; g < NL; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 16 - NL, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (K + 1 < 12) G1Pipe<Q, K + 1>::run(acc, nxt, T, buf, i0, j, kq, hook);
     }
 };

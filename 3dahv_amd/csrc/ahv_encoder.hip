@@ -335,8 +335,8 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
 // Tiled linear for MANY rows (M >= 1024, i.e. B >= 16): C[M][N] = X[M][K] . W[N][K]^T, fp32 MFMA 16x16x4.
 // The skinny kernel above splits K over the waves of a workgroup and pays an 8-way LDS reduction per 64 x 32
 // output tile: right for 64..512 rows (weights are the traffic), 44 % of the matrix peak at 2048 rows.  Here a
-// workgroup (256 threads, 2 x 2 waves) owns a 128 x 128 output tile and walks K in steps of 16 through a
-// double-buffered LDS stage; a wave owns 64 x 64 (16 accumulator tiles).  Both operands are K-contiguous, so
+// workgroup (256 threads, 2 x 2 waves) owns a 128 x 128 output tile and walks K in steps of 16 through three
+// LDS stages; a wave owns 64 x 64 (16 accumulator tiles).  Both operands are K-contiguous, so
 // a tile row in LDS is one 64-byte line [16 k] and, with the k ordering "MFMA k-step s, lane group kq <-> k = 4 kq
 // + s", an operand fragment is one lane-linear (conflict-free) ds_read_b128 serving four MFMA k-steps.
 // GEGLU (the FF-in projection, attention.py:81-88): the 128 tile columns are, per wave column wc, 32 VALUE columns
@@ -350,11 +350,33 @@ struct TileArgs {
     int geglu_h;
 };
 
+// K pipeline (round 5): four LDS stages filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write --
+// the stage image is lane-linear, thread t owns bytes [16 t, 16 t + 16) of each 4 KiB half tile, which is exactly what one
+// such instruction per wave writes), two fragment sets.  In k-step kt a wave requests tile kt + 3, reads the fragments of
+// tile kt + 1 from LDS, THEN issues the 64 MFMAs of tile kt (whose fragments it read a k-step ago), waits until its own
+// pieces of tile kt + 2 have landed (vmcnt(4): tile kt + 3 stays in flight across the barrier) and meets the others at
+// the one raw s_barrier -- behind which the next MFMAs can issue at once.  Measured on the way (tools/_dbg/tile_probe,
+// M = 2048, K = 2048, N = 4096, two problems): two stages + fragments read after the barrier 0.77 of the fp32 matrix peak;
+// fragments read a k-step ahead 0.81; of the rest, the MFMA-only loop reaches 0.95, the register-staged tile
+// (global_load_dwordx4 + ds_write_b128) cost 0.10 and the fragment reads 0.04.
+#ifndef AHV_DIAG_TILE  // diagnostic only (wrong results): bit 1 no tile loads, 2 no fragment reads, 3 no barrier
+#define AHV_DIAG_TILE 0
+#endif
+struct TileFrags {
+    f32x4 a[4], b[4];
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 template <bool GEGLU>
 __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sA[2][128 * 16];
-    __shared__ __attribute__((aligned(16))) float sB[2][128 * 16];
+    // ONE LDS object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every ds_read):
+    // stage st = [A tile 128 x 16 | B tile 128 x 16] floats
+    __shared__ __attribute__((aligned(1024))) float smem[4 * 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -380,51 +402,83 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ga[2], gb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        ga[i] = *reinterpret_cast<const f32x4*>(xg[i]);
-        gb[i] = *reinterpret_cast<const f32x4*>(wg[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<f32x4*>(&sA[0][(srow + 64 * i) * 16 + 4 * sch]) = ga[i];
-        *reinterpret_cast<f32x4*>(&sB[0][(srow + 64 * i) * 16 + 4 * sch]) = gb[i];
-    }
-    __syncthreads();
     const int nk = a.K / 16;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
+    const int soff = srow * 16 + 4 * sch;                 // this thread's 16 bytes of a half tile (= 4 tid floats)
+    const int foffa = (64 * wr + r16) * 16 + 4 * kq;      // fragment rows of this lane (+ 16 rows per i)
+    const int foffb = 2048 + (64 * wc + r16) * 16 + 4 * kq;
+    auto gload = [&](int kt, int st) {  // tile kt -> stage st, four 1 KiB pieces per wave
+        float* dst = smem + st * 4096 + soff;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ga[i] = *reinterpret_cast<const f32x4*>(xg[i] + 16 * (kt + 1));
-                gb[i] = *reinterpret_cast<const f32x4*>(wg[i] + 16 * (kt + 1));
-            }
+        for (int i = 0; i < 2; ++i) {
+            glds16(xg[i] + 16 * kt, dst + 1024 * i);
+            glds16(wg[i] + 16 * kt, dst + 2048 + 1024 * i);
         }
-        f32x4 fa[4], fb[4];
+    };
+    auto fread = [&](TileFrags& f, int st) {
+        const float* src = smem + st * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            fa[i] = *reinterpret_cast<const f32x4*>(&sA[cur][(64 * wr + 16 * i + r16) * 16 + 4 * kq]);
-            fb[i] = *reinterpret_cast<const f32x4*>(&sB[cur][(64 * wc + 16 * i + r16) * 16 + 4 * kq]);
+            f.a[i] = *reinterpret_cast<const f32x4*>(src + foffa + 256 * i);
+            f.b[i] = *reinterpret_cast<const f32x4*>(src + foffb + 256 * i);
         }
+    };
+    auto mma = [&](const TileFrags& f) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s4], fb[j][s4], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][s4], f.b[j][s4], acc[i][j], 0, 0, 0);
+    };
+    // one k-step: `cur` holds tile kt's fragments, `nxt` receives tile kt + 1's; tile kt + 3 goes into the stage tile
+    // kt - 1 occupied (its fragments were read two barriers ago).  No conditions in here: behind the last tile the loads
+    // repeat tile nk - 1 into a stage nobody reads again and the fragment read fetches a tile nobody multiplies -- every
+    // branch would cost hipcc its count of what is in flight (it then waits for the fragment reads in front of the MFMAs).
+    auto kstep = [&](int kt, const TileFrags& cur, TileFrags& nxt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(AHV_DIAG_TILE & 2)) gload(kt + 3 < nk ? kt + 3 : nk - 1, (kt + 3) & 3);
+        if (!(AHV_DIAG_TILE & 4)) fread(nxt, (kt + 1) & 3);
+        mma(cur);
+        // issue order: the 12 memory instructions go BETWEEN the MFMAs (one per four), where their issue slots are free --
+        // twelve of them in front of the first MFMA leave the matrix pipe waiting whenever the SIMD's other wave stands
+        // at the same point
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<f32x4*>(&sA[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch]) = ga[i];
-                *reinterpret_cast<f32x4*>(&sB[cur ^ 1][(srow + 64 * i) * 16 + 4 * sch]) = gb[i];
-            }
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (an LDS-DMA piece)
         }
-        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0): `nxt` has long arrived; vmcnt(4): this wave's pieces of tile kt + 2 are in LDS, tile kt + 3 may still
+        // be on its way when the barrier is met
+        __builtin_amdgcn_s_waitcnt(0x0074);
+        if (!(AHV_DIAG_TILE & 8)) __builtin_amdgcn_s_barrier();
+    };
+    // prologue: tiles 0, 1, 2 requested; tiles 0 and 1 landed before the first barrier
+    TileFrags f0, f1;
+    gload(0, 0);
+    gload(1, 1);
+    gload(nk > 2 ? 2 : nk - 1, 2);
+    __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    fread(f0, 0);
+    if (AHV_DIAG_TILE & 4) fread(f1, 0);
+    // (a wait here, or hipcc carries "f0 pending" into the loop)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    for (int kt = 0; kt < nk; kt += 2) {  // nk is even (tile_eligible)
+        kstep(kt, f0, f1);
+        kstep(kt + 1, f1, f0);
     }
-    // D layout: acc[i][j][r] = C[m0 + 64 wr + 16 i + 4 kq + r][column 64 wc + 16 j + r16 of the tile]
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the repeated loads have landed before the LDS is given up
+    // D layout: acc[i][j][r] = C[m0 + 64 wr + 16 i + 4 kq + r][column 64 wc + 16 j + r16 of the tile]: 4-byte stores, four
+    // 64-byte row segments per instruction.  (The transposed tiles -- W rows as the A operand, a lane then holds four
+    // consecutive columns and stores 16 bytes, sixteen 64-byte row segments per instruction -- measured 1-3 % SLOWER.)
     if (GEGLU) {
         const int H = a.geglu_h;
 #pragma unroll
@@ -795,7 +849,7 @@ static bool tile_eligible(int M, int K, int N, int geglu_h)
 #ifndef AHV_TILE_MIN_M
 #define AHV_TILE_MIN_M 1024
 #endif
-    if (M < AHV_TILE_MIN_M || (M & 127) || (K & 15)) return false;
+    if (M < AHV_TILE_MIN_M || (M & 127) || (K & 31)) return false;  // K per split: an even number of 16-wide k-steps
     return geglu_h > 0 ? (geglu_h % 64 == 0 && N == 2 * geglu_h) : (N % 128 == 0);
 }
 

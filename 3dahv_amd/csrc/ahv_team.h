@@ -119,9 +119,17 @@ struct G1PipeXY {
     static __device__ __forceinline__ void run(f32x4 (&u)[2], G1Chunk& cur, const f32x4* T, const float* buf, int i0, int j, int kq)
     {
         G1Chunk nxt;
-        if (K + 1 < 8) g1_load_xy<(K + 1 < 8 ? K + 1 : 0)>(nxt, T, buf, i0, j, kq);
         __builtin_amdgcn_sched_barrier(0);
+        if (K + 1 < 8) g1_load_xy<(K + 1 < 8 ? K + 1 : 0)>(nxt, T, buf, i0, j, kq);
         g1_mfma_xy(u, cur);
+        if (K + 1 < 8) {  // the next chunk's 12 LDS reads between the MFMAs, one behind each (G1Pipe, ahv_dual.h)
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (K + 1 < 8) G1PipeXY<K + 1>::run(u, nxt, T, buf, i0, j, kq);
     }
