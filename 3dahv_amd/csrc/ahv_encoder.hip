@@ -214,8 +214,9 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
     constexpr int NS = KC / kStageK;  // stages
     constexpr int DEPTH = 2 < NS ? 2 : NS;  // stages requested ahead of their use (3, 4, 8 measured: 319.7 / 323.9 / 323.9 us
                                             // per forward against 318.5 at 2, round 3)
-    // two stage buffers (26 KB each at NT = 2): 2 workgroups per CU once M > 64.  (Three buffers with the next
-    // stage's fragments read ahead of the MFMAs were measured: equal at B = 1, 5-14 % slower at B = 2..8.)
+    // two stage buffers (26 KB each at NT = 2): 2 workgroups per CU once M > 64.  (Three buffers with the next stage's
+    // fragments read between this stage's MFMAs: equal at B = 1 -- 309.2 against 309.4 us per forward --, 4-10 % slower at
+    // B = 2..8, measured again in round 5 on the interleaved issue order below.)
     __shared__ __attribute__((aligned(16))) float sx[2][64 * kStageLd];
     __shared__ __attribute__((aligned(16))) float sw[2][16 * NT * kStageLd];
     __shared__ __attribute__((aligned(16))) float comb[4 * 64 * 4];  // the second wave of each pair hands its tile over
@@ -287,21 +288,37 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
         const int cur = st & 1;
-        if (st + DEPTH < NS) {
-            request(st + DEPTH);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // issue order: this stage's fragment reads first, then its (dependent, ~40 cycles apart) MFMAs with the requests of
+        // stage st + DEPTH and the LDS stores of stage st + 1 in the gaps between them (hard fences: sched_group_barrier
+        // does not move instructions the MFMAs' own operands depend on)
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 fx[KSTEPS], fw[KSTEPS];
 #pragma unroll
         for (int k = 0; k < KSTEPS; ++k) {
             fx[k] = *reinterpret_cast<const f32x4*>(&sx[cur][(16 * rt + r16) * kStageLd + 16 * (k40 + k) + 4 * kq]);
             fw[k] = *reinterpret_cast<const f32x4*>(&sw[cur][(16 * wtile + r16) * kStageLd + 16 * (k40 + k) + 4 * kq]);
         }
-        if (st + 1 < NS) park(st + 1, cur ^ 1);  // the next stage lands in the other buffer while these MFMAs run
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NM = 4 * KSTEPS;  // MFMAs of this stage
 #pragma unroll
-        for (int k = 0; k < KSTEPS; ++k)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[k][s4], fw[k][s4], acc, 0, 0, 0);
+        for (int q = 0; q < NM; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q >> 2][q & 3], fw[q >> 2][q & 3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int slot = q;  // one memory instruction behind each of the first six MFMAs
+            if (st + DEPTH < NS) {
+                const int sr = st + DEPTH;
+                if (slot == 0) gx[sr][0] = xok[0] ? *reinterpret_cast<const f32x4*>(xg[0] + kStageK * sr) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (slot == 1) gx[sr][1] = xok[1] ? *reinterpret_cast<const f32x4*>(xg[1] + kStageK * sr) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (slot == 2 && wload) gw[sr] = *reinterpret_cast<const f32x4*>(wg + kStageK * sr);
+            }
+            if (st + 1 < NS) {
+                const int sp = st + 1, buf = cur ^ 1;
+                if (slot == 3) *reinterpret_cast<f32x4*>(&sx[buf][srow * kStageLd + sc4]) = gx[sp][0];
+                if (slot == 4) *reinterpret_cast<f32x4*>(&sx[buf][(srow + 32) * kStageLd + sc4]) = gx[sp][1];
+                if (slot == 5 && wload) *reinterpret_cast<f32x4*>(&sw[buf][srow * kStageLd + sc4]) = gw[sp];
+            }
+            if (slot < 6) __builtin_amdgcn_sched_barrier(0);
+        }
         if (st + 1 < NS) __syncthreads();
     }
     AHV_ENC_STAMP(4);
