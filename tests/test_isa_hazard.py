@@ -140,3 +140,57 @@ def test_other_sources_issue_fp32_mfmas_only():
             assert m.group(1) == "mfma_f32_16x16x4f32", (f, m.group(1))
     users = [f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and '#include "ahv_split.h"' in open(os.path.join(CSRC, f)).read()]
     assert users == ["ahv_score.hip"], users
+
+
+def test_tile_linear_k_loop_issue_order(tmp_path):
+    """The encoder's tile linear (linear_tile_kernel, M >= 1024) gets its speed from WHERE the memory instructions of a
+    k-step are issued (profiles/r05_tile_kernel_diag.txt): tiles arrive by LDS-DMA (no staging registers, no
+    ds_write), the K loop is one basic block, no MFMA in it waits for a counter (the fragments were read a k-step ago), and
+    the twelve memory instructions of a k-step sit between the MFMAs, never more than two in a row.  hipcc loses this
+    silently (a branch in the k-step, a second __shared__ object, a reordered wait), so the ISA is checked."""
+    fns = _functions(_isa(os.path.join(CSRC, "ahv_encoder.hip"), tmp_path, slp=True))
+    tiles = {n: b for n, b in fns.items() if "linear_tile_kernel" in n}
+    assert len(tiles) == 2, list(tiles)
+    meta = re.findall(r"\.name:\s+(\S*linear_tile_kernel\S*)\s.*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)",
+                      _isa(os.path.join(CSRC, "ahv_encoder.hip"), tmp_path, slp=True), flags=re.S)
+    assert len(meta) == 2 and all(int(sp) == 0 and int(v) <= 256 for _, v, sp in meta), meta
+    for name, body in tiles.items():
+        lines = [l.strip() for l in body.splitlines() if l.strip()]
+        assert not any(l.startswith("ds_write") for l in lines), name                     # LDS-DMA only
+        assert not any(re.match(r"global_load_dwordx4\b", l) for l in lines), name
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\w+):", l)] if m}
+        loops = []
+        for i, l in enumerate(lines):
+            m = re.search(r"s_cbranch\w*\s+(\.LBB\w+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append((labels[m.group(1)], i))
+        hot = [(a, b) for a, b in loops if sum("v_mfma" in x for x in lines[a:b]) == 128]
+        assert len(hot) == 1, (name, loops)
+        a, b = hot[0]
+        loop = lines[a + 1:b]
+        assert not any(l.startswith((".LBB", "s_cbranch", "s_branch")) for l in loop), name    # one basic block
+        assert sum(l.startswith("global_load_lds_dwordx4") for l in loop) == 8                 # two k-steps x four pieces
+        assert sum(l.startswith("ds_read_b128") for l in loop) == 16
+        assert sum(l.startswith("s_barrier") for l in loop) == 2
+        # the two real waits of the loop stand directly in front of the barriers (vmcnt(4) lgkmcnt(0)); any other wait comes
+        # before the k-step has issued a memory instruction (a kernel-argument load hipcc carries into the loop header:
+        # nothing to wait for behind the previous barrier's wait) -- none between a fragment read / DMA and an MFMA
+        issued = 0
+        real = []
+        for i, l in enumerate(loop):
+            if l.startswith(("global_load_lds", "ds_read")):
+                issued += 1
+            elif l.startswith("s_barrier"):
+                issued = 0
+            elif l.startswith("s_waitcnt") and issued:
+                real.append(i)
+        assert len(real) == 2 and all(loop[i + 1].startswith("s_barrier") and "vmcnt(4)" in loop[i] for i in real), [loop[i] for i in real]
+        # memory instructions between the MFMAs: never more than two without an MFMA in between
+        run = worst = 0
+        for l in loop:
+            if l.startswith(("global_load_lds", "ds_read")):
+                run += 1
+                worst = max(worst, run)
+            elif l.startswith("v_mfma"):
+                run = 0
+        assert worst <= 2, (name, worst)
