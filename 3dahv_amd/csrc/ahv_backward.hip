@@ -451,9 +451,16 @@ struct W1Pipe {
                                                const float* da, const float* bx, const float* by, const float* bz)
     {
         W1Chunk nxt;
-        if (K + 1 < kW1Chunks) w1_load<Q, K + 1>(nxt, da, bx, by, bz);
         __builtin_amdgcn_sched_barrier(0);
+        if (K + 1 < kW1Chunks) w1_load<Q, K + 1>(nxt, da, bx, by, bz);
         w1_mfma<Q, K>(ax, ay, az, cur);
+        if (K + 1 < kW1Chunks) {  // the next chunk's LDS reads between this chunk's MFMAs (ahv_dual.h, G1Pipe)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (K + 1 < kW1Chunks) W1Pipe<Q, K + 1>::run(ax, ay, az, nxt, da, bx, by, bz);
     }
