@@ -48,6 +48,8 @@ int main()
         run("plain, K x 4", 2048, 2048, 4096, 1, 0);
         run("FF-out split-K 4", 2048, 2048, 256, 4, 0);
         run("FF-out split-K 8", 2048, 2048, 256, 8, 0);
+        run("qkv projection shape", 2048, 256, 768, 1, 0);
+        run("256 -> 256 shape", 2048, 256, 256, 1, 0);
         run("FF-in GEGLU, M / 2", 1024, 512, 4096, 1, 2048);
         run("FF-in GEGLU, M x 2", 4096, 512, 4096, 1, 2048);
     }
