@@ -361,26 +361,29 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
 // (v + b_v) * gelu(g + b_g) straight into the [M][H] buffer.
 // -------------------------------------------------------------------------------------------------
 struct TileArgs {
-    LinProb p[2];  // tile0 unused
-    int M, K, ntiles;  // K = K range of ONE split (blockIdx.z = ks), ntiles = column tiles per problem
+    LinProb p[kMaxProb];  // tile0 = first column tile of the problem in blockIdx.x
+    int nprob, M, K;      // K = K range of ONE split (blockIdx.z = ks)
     long ldx, ldw;
     int geglu_h;
 };
 
 // K pipeline (round 5): four LDS stages filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write --
-// the stage image is lane-linear, thread t owns bytes [16 t, 16 t + 16) of each 4 KiB half tile, which is exactly what one
+// the stage image is lane-linear, thread t owns bytes [16 t, 16 t + 16) of each 4 KiB piece, which is exactly what one
 // such instruction per wave writes), two fragment sets.  In k-step kt a wave requests tile kt + 3, reads the fragments of
-// tile kt + 1 from LDS, THEN issues the 64 MFMAs of tile kt (whose fragments it read a k-step ago), waits until its own
-// pieces of tile kt + 2 have landed (vmcnt(4): tile kt + 3 stays in flight across the barrier) and meets the others at
-// the one raw s_barrier -- behind which the next MFMAs can issue at once.  Measured on the way (tools/_dbg/tile_probe,
-// M = 2048, K = 2048, N = 4096, two problems): two stages + fragments read after the barrier 0.77 of the fp32 matrix peak;
-// fragments read a k-step ahead 0.81; of the rest, the MFMA-only loop reaches 0.95, the register-staged tile
-// (global_load_dwordx4 + ds_write_b128) cost 0.10 and the fragment reads 0.04.
+// tile kt + 1 from LDS, issues the MFMAs of tile kt (whose fragments it read a k-step ago), waits until its own pieces of
+// tile kt + 2 have landed (vmcnt: tile kt + 3 stays in flight across the barrier) and meets the others at the one raw
+// s_barrier -- behind which the next MFMAs can issue at once.  The memory instructions of a k-step are issued BETWEEN its
+// MFMAs (one per TM MFMAs), not in front of them.  Measured on the way (tools/tile_probe.cpp, M = 2048, K = 2048, N = 4096,
+// two problems): two stages + fragments read after the barrier 0.77 of the fp32 matrix peak; fragments read a k-step
+// ahead 0.81; LDS-DMA 0.83; the issue order 0.90 (profiles/r05_tile_kernel_diag.txt).
+// TM = 4: 128 x 128 tiles (a wave owns 64 x 64), M >= 1024 rows of the FF projections.  TM = 2: 64 x 64 tiles (a wave owns
+// 32 x 32) for the 256-wide projections, whose 128-tiles would not fill the chip.
 #ifndef AHV_DIAG_TILE  // diagnostic only (wrong results): bit 1 no tile loads, 2 no fragment reads, 3 no barrier
 #define AHV_DIAG_TILE 0
 #endif
+template <int TM>
 struct TileFrags {
-    f32x4 a[4], b[4];
+    f32x4 a[TM], b[TM];
 };
 
 __device__ __forceinline__ void glds16(const float* g, float* l)
@@ -388,101 +391,111 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <bool GEGLU>
+template <bool GEGLU, int TM>
 __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
 {
-    // ONE LDS object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every ds_read):
-    // stage st = [A tile 128 x 16 | B tile 128 x 16] floats
-    __shared__ __attribute__((aligned(1024))) float smem[4 * 4096];
+    static_assert(TM == 2 || TM == 4, "64 x 64 or 128 x 128 tiles");
+    static_assert(!GEGLU || TM == 4, "the GEGLU column pairing is laid out for 128-column tiles");
+    constexpr int T = 32 * TM;          // tile rows = tile columns
+    constexpr int HALF = T * 16;        // floats of one operand tile [T][16]
+    constexpr int STAGE = 2 * HALF;     // [A | B]
+    constexpr int NP = TM / 2;          // 1 KiB pieces per wave, operand and k-step
+    // ONE LDS object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every ds_read)
+    __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int pi = (int)blockIdx.x / a.ntiles, tile = (int)blockIdx.x - pi * a.ntiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxProb; ++i)
+        if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile0) pi = i;
     const LinProb pr = a.p[pi];
-    const int m0 = blockIdx.y * 128;
+    const int tile = (int)blockIdx.x - pr.tile0;
+    const int m0 = blockIdx.y * T;
     const int r16 = lane & 15, kq = lane >> 4;
     // staging: thread -> (row = tid / 4 (+64), 16-byte chunk = tid % 4) of both tiles
     const int srow = tid >> 2, sch = tid & 3;
-    const float* xg[2];
-    const float* wg[2];
+    const float* xg[NP];
+    const float* wg[NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const int j = srow + 64 * i;  // tile row
         xg[i] = pr.X + (long)(m0 + j) * a.ldx + (long)blockIdx.z * a.K + 4 * sch;
         int wrow;
         if (GEGLU) wrow = ((j >> 5) & 1) * a.geglu_h + tile * 64 + 32 * (j >> 6) + (j & 31);
-        else wrow = tile * 128 + j;
+        else wrow = tile * T + j;
         wg[i] = pr.W + (long)wrow * a.ldw + (long)blockIdx.z * a.K + 4 * sch;
     }
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 16;
-    const int soff = srow * 16 + 4 * sch;                 // this thread's 16 bytes of a half tile (= 4 tid floats)
-    const int foffa = (64 * wr + r16) * 16 + 4 * kq;      // fragment rows of this lane (+ 16 rows per i)
-    const int foffb = 2048 + (64 * wc + r16) * 16 + 4 * kq;
-    auto gload = [&](int kt, int st) {  // tile kt -> stage st, four 1 KiB pieces per wave
-        float* dst = smem + st * 4096 + soff;
+    const int soff = srow * 16 + 4 * sch;                        // this thread's 16 bytes of a piece (= 4 tid floats)
+    const int foffa = (16 * TM * wr + r16) * 16 + 4 * kq;        // fragment rows of this lane (+ 16 rows per i)
+    const int foffb = HALF + (16 * TM * wc + r16) * 16 + 4 * kq;
+    auto gload = [&](int kt, int st) {  // tile kt -> stage st, 2 NP pieces of 1 KiB per wave
+        float* dst = smem + st * STAGE + soff;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NP; ++i) {
             glds16(xg[i] + 16 * kt, dst + 1024 * i);
-            glds16(wg[i] + 16 * kt, dst + 2048 + 1024 * i);
+            glds16(wg[i] + 16 * kt, dst + HALF + 1024 * i);
         }
     };
-    auto fread = [&](TileFrags& f, int st) {
-        const float* src = smem + st * 4096;
+    auto fread = [&](TileFrags<TM>& f, int st) {
+        const float* src = smem + st * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TM; ++i) {
             f.a[i] = *reinterpret_cast<const f32x4*>(src + foffa + 256 * i);
             f.b[i] = *reinterpret_cast<const f32x4*>(src + foffb + 256 * i);
         }
     };
-    auto mma = [&](const TileFrags& f) {
+    auto mma = [&](const TileFrags<TM>& f) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][s4], f.b[j][s4], acc[i][j], 0, 0, 0);
     };
+    // vmcnt(TM) lgkmcnt(0): this wave's pieces of tile kt + 2 are in LDS, the TM pieces of tile kt + 3 may still be on
+    // their way when the barrier is met; `nxt` has long arrived
+    constexpr int kWait = 0x0070 | TM;
     // one k-step: `cur` holds tile kt's fragments, `nxt` receives tile kt + 1's; tile kt + 3 goes into the stage tile
     // kt - 1 occupied (its fragments were read two barriers ago).  No conditions in here: behind the last tile the loads
     // repeat tile nk - 1 into a stage nobody reads again and the fragment read fetches a tile nobody multiplies -- every
     // branch would cost hipcc its count of what is in flight (it then waits for the fragment reads in front of the MFMAs).
-    auto kstep = [&](int kt, const TileFrags& cur, TileFrags& nxt) {
+    auto kstep = [&](int kt, const TileFrags<TM>& cur, TileFrags<TM>& nxt) {
         __builtin_amdgcn_sched_barrier(0);
         if (!(AHV_DIAG_TILE & 2)) gload(kt + 3 < nk ? kt + 3 : nk - 1, (kt + 3) & 3);
         if (!(AHV_DIAG_TILE & 4)) fread(nxt, (kt + 1) & 3);
         mma(cur);
-        // issue order: the 12 memory instructions go BETWEEN the MFMAs (one per four), where their issue slots are free --
-        // twelve of them in front of the first MFMA leave the matrix pipe waiting whenever the SIMD's other wave stands
-        // at the same point
+        // issue order: the 3 TM memory instructions go BETWEEN the MFMAs (one per TM), where their issue slots are free --
+        // all of them in front of the first MFMA leave the matrix pipe waiting whenever the SIMD's other wave stands at
+        // the same point
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (an LDS-DMA piece)
+        for (int g = 0; g < TM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);  // TM MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM (an LDS-DMA piece)
         }
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        for (int g = 0; g < 2 * TM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);  // TM MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // lgkmcnt(0): `nxt` has long arrived; vmcnt(4): this wave's pieces of tile kt + 2 are in LDS, tile kt + 3 may still
-        // be on its way when the barrier is met
-        __builtin_amdgcn_s_waitcnt(0x0074);
+        __builtin_amdgcn_s_waitcnt(kWait);
         if (!(AHV_DIAG_TILE & 8)) __builtin_amdgcn_s_barrier();
     };
     // prologue: tiles 0, 1, 2 requested; tiles 0 and 1 landed before the first barrier
-    TileFrags f0, f1;
+    TileFrags<TM> f0, f1;
     gload(0, 0);
     gload(1, 1);
     gload(nk > 2 ? 2 : nk - 1, 2);
-    __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0)
+    __builtin_amdgcn_s_waitcnt(kWait);
     __builtin_amdgcn_s_barrier();
     fread(f0, 0);
     if (AHV_DIAG_TILE & 4) fread(f1, 0);
@@ -493,10 +506,10 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
         kstep(kt + 1, f1, f0);
     }
     __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the repeated loads have landed before the LDS is given up
-    // D layout: acc[i][j][r] = C[m0 + 64 wr + 16 i + 4 kq + r][column 64 wc + 16 j + r16 of the tile]: 4-byte stores, four
+    // D layout: acc[i][j][r] = C[m0 + 16 TM wr + 16 i + 4 kq + r][column 16 TM wc + 16 j + r16 of the tile]: 4-byte stores, four
     // 64-byte row segments per instruction.  (The transposed tiles -- W rows as the A operand, a lane then holds four
     // consecutive columns and stores 16 bytes, sixteen 64-byte row segments per instruction -- measured 1-3 % SLOWER.)
-    if (GEGLU) {
+    if constexpr (GEGLU) {
         const int H = a.geglu_h;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -513,12 +526,15 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     } else {
         float* P = pr.P + (long)blockIdx.z * a.M * pr.N;  // split-K slab [ks][M][N]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < TM; ++j) {
+            const int col = tile * T + 16 * TM * wc + 16 * j + r16;
+            const float bias = (pr.bias != nullptr && gridDim.z == 1) ? pr.bias[col] : 0.0f;  // a bias only without split-K (host)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    P[(long)(m0 + 64 * wr + 16 * i + 4 * kq + r) * pr.N + tile * 128 + 64 * wc + 16 * j + r16] = acc[i][j][r];
+                    P[(long)(m0 + 16 * TM * wr + 16 * i + 4 * kq + r) * pr.N + col] = acc[i][j][r] + bias;
+        }
     }
 }
 
@@ -820,9 +836,15 @@ struct LinSpec {
     int N;
 };
 
+static bool tile64_eligible(const LinSpec* specs, int nprob, int M, int K);
+static hipError_t launch_linear_tile(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
+                                     hipStream_t s, int tile);
+
 static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
                                 hipStream_t s, int mode = 0)
 {
+    if (mode == 0 && KS == 1 && geglu_h == 0 && K == 256 && tile64_eligible(specs, nprob, M, K))
+        return launch_linear_tile(specs, nprob, ldx, ldw, M, K, 1, 0, s, 64);
     const bool wide = geglu_h > 0;  // the GEGLU projection: value tile + gate tile per workgroup
     const int cols = wide ? 32 : 16;
     const int Kw = K / KS / 8;
@@ -870,16 +892,38 @@ static bool tile_eligible(int M, int K, int N, int geglu_h)
     return geglu_h > 0 ? (geglu_h % 64 == 0 && N == 2 * geglu_h) : (N % 128 == 0);
 }
 
-static hipError_t launch_linear_tile(const LinSpec* specs, long ldx, long ldw, int M, int K, int KS, int geglu_h,
-                                     hipStream_t s)
+// tile = 128: the two-problem FF projections; tile = 64: up to four plain problems (q / k / v, proj_in / proj_out)
+// 256-wide projections (K = 256, N = 256 / 512 / 768) at many rows: 64 x 64 tiles instead of the skinny kernel, whose
+// workgroups re-read their 64 x 256 X tile once per 16 output columns.  Measured per forward (tools/kbench_enc, graph):
+// B = 32: 2040 -> 2012 us (17.3 against 21.5 us per launch); B = 16: 1238 -> 1253; B = 8: 753 -> 761; B = 4: 490 -> 508.
+#ifndef AHV_TILE64_MIN_M
+#define AHV_TILE64_MIN_M 2048
+#endif
+static bool tile64_eligible(const LinSpec* specs, int nprob, int M, int K)
+{
+    if (M < AHV_TILE64_MIN_M || (M & 63) || (K & 31) || nprob > kMaxProb) return false;
+    for (int i = 0; i < nprob; ++i)
+        if (specs[i].N & 63) return false;
+    return true;
+}
+
+static hipError_t launch_linear_tile(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
+                                     hipStream_t s, int tile)
 {
     TileArgs a;
-    a.M = M; a.K = K / KS; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
-    for (int i = 0; i < 2; ++i) a.p[i] = LinProb{specs[i].X, specs[i].W, specs[i].P, specs[i].bias, specs[i].N, 0};
-    a.ntiles = geglu_h > 0 ? geglu_h / 64 : specs[0].N / 128;
-    const dim3 grid(2 * a.ntiles, M / 128, geglu_h > 0 ? 1 : KS);
-    if (geglu_h > 0) AHV_ENC_LAUNCH(linear_tile_kernel<true>, grid, dim3(256), 0, s, a);
-    else AHV_ENC_LAUNCH(linear_tile_kernel<false>, grid, dim3(256), 0, s, a);
+    a.nprob = nprob; a.M = M; a.K = K / KS; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
+    int tiles = 0;
+    for (int i = 0; i < kMaxProb; ++i) {
+        const LinSpec& sp = specs[i < nprob ? i : 0];
+        a.p[i] = LinProb{sp.X, sp.W, sp.P, sp.bias, sp.N, tiles};
+        if (i < nprob) tiles += geglu_h > 0 ? geglu_h / 64 : sp.N / tile;
+    }
+    const dim3 grid(tiles, M / tile, geglu_h > 0 ? 1 : KS);
+    if (geglu_h > 0 && tile == 128) AHV_ENC_LAUNCH((linear_tile_kernel<true, 4>), grid, dim3(256), 0, s, a);
+    else if (geglu_h > 0) return hipErrorInvalidValue;
+    else if (tile == 128) AHV_ENC_LAUNCH((linear_tile_kernel<false, 4>), grid, dim3(256), 0, s, a);
+    else if (tile == 64) AHV_ENC_LAUNCH((linear_tile_kernel<false, 2>), grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -952,7 +996,7 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].cat, w[i]->w_ff1, ws[i].part, w[i]->b_ff1, 4096};
         // B >= 16, even: 128 x 128 tiles; FF-out (N = 256: only 64 tiles per stream) keeps its 4-way split-K
         const bool tiled = tile_eligible(M, 512, 4096, 2048);
-        if (tiled) AHV_TRY(launch_linear_tile(sp, 512, 512, M, 512, 1, 2048, s), "ff in + geglu (tiled)");
+        if (tiled) AHV_TRY(launch_linear_tile(sp, 2, 512, 512, M, 512, 1, 2048, s, 128), "ff in + geglu (tiled)");
         else AHV_TRY(launch_linear(sp, 2, 512, 512, M, 512, 1, 2048, s), "ff in + geglu");
         LnArgs ln;
         ln.M = M;
@@ -962,7 +1006,7 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
         if (tiled || M > AHV_FFOUT_KS8_MAX_M) {
             // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
             for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
-            if (tiled) AHV_TRY(launch_linear_tile(sp, 2048, 2048, M, 2048, 4, 0, s), "ff out (tiled, split-K 4)");
+            if (tiled) AHV_TRY(launch_linear_tile(sp, 2, 2048, 2048, M, 2048, 4, 0, s, 128), "ff out (tiled, split-K 4)");
             else AHV_TRY(launch_linear(sp, 2, 2048, 2048, M, 2048, 4, 0, s), "ff out");
             ln.KS = 4;
             for (int i = 0; i < 2; ++i) ln.p[i] = LnProb{ws[i].qkv, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};

@@ -17,7 +17,8 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max()).item()
 
 
-@pytest.mark.parametrize("B", [1, 3, 16, 17])   # 16: the 128x128-tiled FF-in kernel (M >= 1024, M % 128 == 0); 17: back on the skinny one
+@pytest.mark.parametrize("B", [1, 3, 16, 17, 32])   # 16: the 128x128-tiled FF kernels (M >= 1024, M % 128 == 0); 17: back on the
+                                                     # skinny ones; 32: the 64x64-tiled q / k / v projections too (M >= 2048)
 def test_transformer_blocks_match_torch_ops(fa, B):
     g = torch.Generator().manual_seed(B)
     x = torch.randn(B, 256, 8, 8, generator=g).cuda()
@@ -165,7 +166,8 @@ def full(ahv):
     return g, m.cuda()
 
 
-@pytest.mark.parametrize("B", [1, 2, 17])  # 17 = the stored pair tiled (skinny kernels, odd row count)
+@pytest.mark.parametrize("B", [1, 2, 17, 32])  # 17 = the stored pair tiled (skinny kernels, odd row count); 32 = the tiled
+                                               # kernels (128-tiles for the FF projections, 64-tiles for the 256-wide ones)
 def test_hip_forward_2d3d_matches_reference_fixture(full, B):
     """ahv_forward_2d3d_f32 vs the reference's own outputs: <= 1e-4 of the largest entry (measured ~1e-6)."""
     g, m = full

@@ -146,15 +146,16 @@ def test_tile_linear_k_loop_issue_order(tmp_path):
     """The encoder's tile linear (linear_tile_kernel, M >= 1024) gets its speed from WHERE the memory instructions of a
     k-step are issued (profiles/r05_tile_kernel_diag.txt): tiles arrive by LDS-DMA (no staging registers, no
     ds_write), the K loop is one basic block, no MFMA in it waits for a counter (the fragments were read a k-step ago), and
-    the twelve memory instructions of a k-step sit between the MFMAs, never more than two in a row.  hipcc loses this
+    the memory instructions of a k-step sit between the MFMAs, never more than two in a row.  hipcc loses this
     silently (a branch in the k-step, a second __shared__ object, a reordered wait), so the ISA is checked."""
     fns = _functions(_isa(os.path.join(CSRC, "ahv_encoder.hip"), tmp_path, slp=True))
     tiles = {n: b for n, b in fns.items() if "linear_tile_kernel" in n}
-    assert len(tiles) == 2, list(tiles)
+    assert len(tiles) == 3, list(tiles)     # 128-tiles with / without GEGLU, 64-tiles
     meta = re.findall(r"\.name:\s+(\S*linear_tile_kernel\S*)\s.*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)",
                       _isa(os.path.join(CSRC, "ahv_encoder.hip"), tmp_path, slp=True), flags=re.S)
-    assert len(meta) == 2 and all(int(sp) == 0 and int(v) <= 256 for _, v, sp in meta), meta
+    assert len(meta) == 3 and all(int(sp) == 0 and int(v) <= 256 for _, v, sp in meta), meta
     for name, body in tiles.items():
+        tm = 2 if "ELi2E" in name else 4    # MFMA tiles per wave and direction: k-step = 4 tm^2 MFMAs, 3 tm memory instructions
         lines = [l.strip() for l in body.splitlines() if l.strip()]
         assert not any(l.startswith("ds_write") for l in lines), name                     # LDS-DMA only
         assert not any(re.match(r"global_load_dwordx4\b", l) for l in lines), name
@@ -164,13 +165,13 @@ def test_tile_linear_k_loop_issue_order(tmp_path):
             m = re.search(r"s_cbranch\w*\s+(\.LBB\w+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
                 loops.append((labels[m.group(1)], i))
-        hot = [(a, b) for a, b in loops if sum("v_mfma" in x for x in lines[a:b]) == 128]
+        hot = [(a, b) for a, b in loops if sum("v_mfma" in x for x in lines[a:b]) == 8 * tm * tm]
         assert len(hot) == 1, (name, loops)
         a, b = hot[0]
         loop = lines[a + 1:b]
         assert not any(l.startswith((".LBB", "s_cbranch", "s_branch")) for l in loop), name    # one basic block
-        assert sum(l.startswith("global_load_lds_dwordx4") for l in loop) == 8                 # two k-steps x four pieces
-        assert sum(l.startswith("ds_read_b128") for l in loop) == 16
+        assert sum(l.startswith("global_load_lds_dwordx4") for l in loop) == 2 * tm            # two k-steps x tm pieces
+        assert sum(l.startswith("ds_read_b128") for l in loop) == 4 * tm
         assert sum(l.startswith("s_barrier") for l in loop) == 2
         # the two real waits of the loop stand directly in front of the barriers (vmcnt(4) lgkmcnt(0)); any other wait comes
         # before the k-step has issued a memory instruction (a kernel-argument load hipcc carries into the loop header:
@@ -184,7 +185,7 @@ def test_tile_linear_k_loop_issue_order(tmp_path):
                 issued = 0
             elif l.startswith("s_waitcnt") and issued:
                 real.append(i)
-        assert len(real) == 2 and all(loop[i + 1].startswith("s_barrier") and "vmcnt(4)" in loop[i] for i in real), [loop[i] for i in real]
+        assert len(real) == 2 and all(loop[i + 1].startswith("s_barrier") and "vmcnt(%d)" % tm in loop[i] for i in real), [loop[i] for i in real]
         # memory instructions between the MFMAs: never more than two without an MFMA in between
         run = worst = 0
         for l in loop:

@@ -14,7 +14,7 @@ __global__ void fillk(float* p, size_t n, unsigned seed)
         p[i] = ((float)(h & 0xffffff) / 8388608.0f - 1.0f) * 0.05f;
     }
 }
-static void run(const char* name, int M, int K, int N, int KS, int H)
+static void run(const char* name, int M, int K, int N, int KS, int H, int tile = 128)
 {
     float *X[2], *W[2], *P[2], *b[2];
     for (int i = 0; i < 2; ++i) {
@@ -28,7 +28,7 @@ static void run(const char* name, int M, int K, int N, int KS, int H)
     std::vector<float> ts;
     for (int it = 0; it < 25; ++it) {
         CK(hipEventRecord(e0));
-        CK(ahv::launch_linear_tile(sp, K, K, M, K, KS, H, 0));
+        CK(ahv::launch_linear_tile(sp, 2, K, K, M, K, KS, H, 0, tile));
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it >= 5) ts.push_back(ms * 1e3f);
@@ -50,6 +50,13 @@ int main()
         run("FF-out split-K 8", 2048, 2048, 256, 8, 0);
         run("qkv projection shape", 2048, 256, 768, 1, 0);
         run("256 -> 256 shape", 2048, 256, 256, 1, 0);
+        run("qkv, 64-tiles", 2048, 256, 768, 1, 0, 64);
+        run("256 -> 256, 64-tiles", 2048, 256, 256, 1, 0, 64);
+        run("qkv, 64-tiles, M 1024", 1024, 256, 768, 1, 0, 64);
+        run("qkv, 64-tiles, M 512", 512, 256, 768, 1, 0, 64);
+        run("qkv, 64-tiles, M 256", 256, 256, 768, 1, 0, 64);
+        run("FF-out split-K 4, 64-tiles", 2048, 2048, 256, 4, 0, 64);
+        run("FF-out split-K 2, 64-tiles", 2048, 2048, 256, 2, 0, 64);
         run("FF-in GEGLU, M / 2", 1024, 512, 4096, 1, 2048);
         run("FF-in GEGLU, M x 2", 4096, 512, 4096, 1, 2048);
     }
