@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
-// The same linear, K-PIPELINED through LDS (MODE 0 / 1; grid and LinArgs as linear_kernel, 256 threads).
+// The same linear, K-PIPELINED through LDS (MODE 0 / 1; grid, LinArgs and 512 threads as linear_kernel).
 // linear_kernel requests its whole operand set at once and as MFMA fragments: the four lanes of a quad then sit
 // in four different 128-byte lines and the texture path delivers ~16 B/clk (tools/launch_floor.cpp: 128 KB re-read
 // per workgroup 3.3 us as fragments, 1.15 us row-contiguous), so a workgroup of the FF-in projection spends ~5 us
