@@ -118,7 +118,7 @@ def score_hypotheses_sharded(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: t
 
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> int:
     """Data-parallel gradient averaging, the exchange Lightning's DDP strategy performs for the reference's
-    ``trainer.fit`` (modules/model_co3d.py:101-145 with ``strategy='ddp'`` in train_co3d.py).  Gradients are packed
+    ``trainer.fit`` (modules/model_co3d.py:101-145 with ``strategy='ddp'``, train_estimator_co3d.py:23-24).  Gradients are packed
     into flat buckets of up to ``bucket_bytes`` (the aligner has ~230 tensors / 192 MB: a few large RCCL
     all-reduces instead of hundreds of small ones), summed, divided by the world size and unpacked in place.
     Parameters without a gradient on this rank (``bn_down``) are skipped on every rank alike.  Returns the

@@ -3,7 +3,7 @@ path (option A):
 
     utils.rotate_volume                          -> 3dahv_amd.ops.rotate_volume        (utils.py:113-131)
     modules.modules.Feature_Aligner.forward_3d2d -> HIP head kernel                    (modules/modules.py:112-124)
-    modules.modules.Feature_Aligner.forward_2d3d -> HIP encoder (inference calls only) (modules/modules.py:86-110)
+    modules.modules.Feature_Aligner.forward_2d3d -> HIP encoder (inference calls: no_grad OR module.eval())  (modules/modules.py:86-110)
 
 Usage from the reference's checkout, before the script's own imports bind the names:
 
@@ -22,21 +22,45 @@ from . import ops
 _saved = {}
 
 
+def _inference_call(module) -> bool:
+    """What the patched callables treat as an inference call.  The reference's evaluation scripts never enter
+    ``torch.no_grad()``: test_co3d.py:219 only sets ``model.eval()`` (and modules/model_co3d.py:22 switches anomaly
+    detection on), so grad mode is ON and every parameter requires grad while they run.  An eval-mode module is
+    therefore inference here: the HIP kernels run under ``no_grad`` and the results come back detached, which keeps
+    the downstream calls (``rotate_volume`` of a detached volume, the score lines) on their plain paths too.  A module
+    in training mode keeps autograd: ``forward_3d2d`` / ``rotate_volume`` through the HIP backward,
+    ``forward_2d3d`` through the reference's own implementation."""
+    import torch
+    return (not torch.is_grad_enabled()) or (not module.training)
+
+
+calls = {"forward_2d3d_hip": 0, "forward_2d3d_reference": 0, "forward_3d2d_inference": 0, "forward_3d2d_autograd": 0}
+
+
 def _hip_forward_3d2d(self, img_feat):
+    import torch
     c1, c2 = self.feature_embedding_2d[0], self.feature_embedding_2d[2]
+    if _inference_call(self):
+        calls["forward_3d2d_inference"] += 1
+        with torch.no_grad():
+            return ops.forward_3d2d(img_feat, c1.weight, c2.weight, c2.bias)
+    calls["forward_3d2d_autograd"] += 1
     return ops.forward_3d2d(img_feat, c1.weight, c2.weight, c2.bias)
 
 
 def _hip_forward_2d3d(self, img_feat_src, img_feat_tgt, random_mask=True, mask_ratio=0.25):
-    """The reference module's own weights, packed once for the C ABI; training-style calls (autograd on,
-    or random_mask=True) fall through to the reference implementation."""
-    import torch
+    """The reference module's own weights, packed once for the C ABI.  Inference calls (``_inference_call``; the
+    scripts pass ``random_mask=False``, modules/model_co3d.py:67) run ``ahv_forward_2d3d_f32`` and return detached
+    volumes; training-style calls (module in training mode with autograd on, or ``random_mask=True``) and other
+    shapes go to the reference implementation -- ``patch.calls`` counts which one ran."""
     from .aligner import hip_forward_2d3d
-    ok = (img_feat_src.is_cuda and not torch.is_grad_enabled() and random_mask is not True
+    ok = (img_feat_src.is_cuda and _inference_call(self) and random_mask is not True
           and tuple(img_feat_src.shape[1:]) == (768, 8, 8) and getattr(self, "mid_channel", 0) == 256)
     if not ok:
+        calls["forward_2d3d_reference"] += 1
         return _saved["forward_2d3d"][1](self, img_feat_src, img_feat_tgt, random_mask, mask_ratio)
-    return hip_forward_2d3d(self, img_feat_src, img_feat_tgt)
+    calls["forward_2d3d_hip"] += 1
+    return hip_forward_2d3d(self, img_feat_src, img_feat_tgt)   # runs under no_grad; fresh tensors, no graph
 
 
 def install(utils_module=None, modules_module=None):

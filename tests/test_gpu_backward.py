@@ -232,6 +232,43 @@ def test_infonce_gradients_match_all_torch_graph(ahv, dev):
         assert relerr(a, b.reshape(a.shape)) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_infonce_matches_the_reference_run_gradients(ahv, dev, tag):
+    """G11 `infonce_grad` (tools/gen_golden.py gen_infonce): the loss, similarities and five gradients the
+    REFERENCE's own code produced under autograd (utils.rotate_volume utils.py:113-131 + Feature_Aligner.forward_3d2d
+    modules/modules.py:112-124 + the loss lines of modules/model_co3d.py:41-61), per-sample hypothesis sets with the
+    GT at index 0.  The mirror's infoNCE_loss (one fused HIP launch forward, the three-kernel HIP backward) must
+    give the same loss (1e-5), similarities (1e-4 relative, the forward's contract) and gradients (GRAD_RTOL of
+    each tensor's largest entry; reference gradients are fp32 here, so a near-kink pre-activation falls back on
+    the kink-aware fp64 comparison)."""
+    g = load_golden("infonce_grad")
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).to(dev)
+    B, N = g[tag + "_R"].shape[:2]
+    m = ahv.estimator.EstimatorCo3d(tiny_cfg(N)).to(dev).train()
+    c1, c2 = m.feature_aligner.feature_embedding_2d[0], m.feature_aligner.feature_embedding_2d[2]
+    with torch.no_grad():
+        c1.weight.copy_(t("W1").reshape(c1.weight.shape))
+        c2.weight.copy_(t("W2").reshape(c2.weight.shape))
+        c2.bias.copy_(t("b2"))
+    vs, vt = t(tag + "_vol_src").requires_grad_(True), t(tag + "_vol_tgt").requires_grad_(True)
+    R, gt = t(tag + "_R"), t(tag + "_gt")
+    per_sample = m.infoNCE_loss(vs, vt, R, gt, reduce_mean=False)
+    loss = m.infoNCE_loss(vs, vt, R, gt)
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    assert np.max(np.abs(per_sample.detach().cpu().numpy() - g[tag + "_loss_per_sample"])) < 1e-5
+    sim = ahv.ops.score_hypotheses(vs.detach(), m.feature_aligner.forward_3d2d(vt.detach()).detach(), R,
+                                   *[w.detach() for w in m.feature_aligner.head_weights()])[0]
+    ref_sim = g[tag + "_sim"]
+    assert np.max(np.abs(sim.cpu().numpy() - ref_sim) / np.abs(ref_sim).clip(1e-2)) < 1e-4
+    got = torch.autograd.grad(loss, [vs, vt, c1.weight, c2.weight, c2.bias])
+    errs = {}
+    for a, key in zip(got, ("d_vol_src", "d_vol_tgt", "d_W1", "d_W2", "d_b2")):
+        ref = torch.from_numpy(g[tag + "_" + key]).double().to(dev)
+        errs[key] = relerr(a.reshape(ref.shape), ref)
+    print(tag, {k: "%.1e" % v for k, v in errs.items()})
+    assert all(v < GRAD_RTOL for v in errs.values()), errs
+
+
 def test_training_steps_reduce_the_loss(ahv, dev):
     """training_step (modules/model_co3d.py:71-91) end to end: backbone -> encoder (torch autograd) -> sampled
     rotations with the ground truth as hypothesis 0 -> InfoNCE through the HIP backward -> AdamW."""

@@ -157,6 +157,120 @@ def test_patched_reference_callables_run_on_hip(ahv, dev, g128):
     assert abs(pred_sim.item() - float(g128["best"][0])) < 1e-5
 
 
+def test_option_a_under_the_reference_scripts_own_conditions(ahv, dev):
+    """INTEGRATION.md option A exactly as /root/reference/test_co3d.py would exercise it: grad mode ON (the script never
+    enters no_grad), anomaly detection ON (modules/model_co3d.py:22), ``model.eval()`` (test_co3d.py:219), a backbone
+    whose parameters require grad (so ``layer_4`` does too), N = 50 000.  The verbatim sequence test_co3d.py:133-146
+    runs on a reference-shaped stand-in: an Estimator-like module whose Feature_Aligner's OWN forward_2d3d is the
+    stock-torch implementation and whose forward_3d2d raises unless patched.  Seed 0 builds the same weights and the
+    same layer_4 pair as tools/gen_golden.py's reference aligner (identical registration order; checked bit for bit on
+    the CPU), so the result is held to the reference-run digest G2 (50 000 Haar rotations, seed 3).
+    Asserts: (i) G2's arg-max, best score and top-16 scores; (ii) ahv_forward_2d3d_f32 was the encoder that ran and
+    every head call took the inference path; (iii) peak memory stays below the reference's own dataflow."""
+    import hashlib
+    import types
+    from .conftest import load_golden
+    dg = load_golden("score_n50k_digest")
+
+    class RefAligner(ahv.aligner.Feature_Aligner):     # torch-operator forward_2d3d, like the reference's class
+        def forward_2d3d(self, a, b, random_mask=True, mask_ratio=0.25):
+            self.use_hip_encoder = self.att.use_hip = False
+            return super().forward_2d3d(a, b, random_mask, mask_ratio)
+
+        def forward_3d2d(self, x):
+            raise AssertionError("not patched")
+
+    class Backbone(torch.nn.Module):                    # stands in for MiDaS: image id -> layer_4, parameters require grad
+        def __init__(self, layer4):
+            super().__init__()
+            self.register_buffer("layer4", layer4)
+            self.gain = torch.nn.Parameter(torch.ones(()))
+
+        def forward(self, img):
+            return self.layer4[img.flatten()[0].long()][None] * self.gain
+
+    class Estimator(torch.nn.Module):                   # modules/model_co3d.py:26-39,63-69
+        def __init__(self, layer4):
+            super().__init__()
+            self.feature_extractor = Backbone(layer4)
+            self.feature_aligner = RefAligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4)
+
+        def feature_extraction(self, img):
+            return self.feature_extractor(img)
+
+        def forward(self, img_src, img_tgt):
+            img_feat_src = self.feature_extraction(img_src)
+            img_feat_tgt = self.feature_extraction(img_tgt)
+            return self.feature_aligner.forward_2d3d(img_feat_src, img_feat_tgt, random_mask=False, mask_ratio=0)
+
+    torch.manual_seed(0)                                # tools/gen_golden.py seeded_pair: aligner first, then layer_4
+    fa = RefAligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4)
+    layer4 = torch.randn(2, 3, 768, 8, 8)
+    model = Estimator(torch.stack([layer4[0, 0], layer4[1, 0]]))
+    model.feature_aligner.load_state_dict(fa.state_dict())
+    model = model.to(dev)
+    R_np = ahv.rotations.haar_rotations_np(50000, seed=int(dg["seed"]))
+    assert hashlib.sha256(R_np.tobytes()).hexdigest() == str(dg["R_sha256"])
+    proposals = torch.from_numpy(R_np).to(dev)
+    image1, image2 = torch.zeros(3, 4, 4, device=dev), torch.ones(3, 4, 4, device=dev)
+
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+    mm.Feature_Aligner = RefAligner
+    assert torch.is_grad_enabled()
+    torch.autograd.set_detect_anomaly(True)
+    ahv.patch.install(um, mm)
+    before = dict(ahv.patch.calls)
+    try:
+        model.eval()
+        rotate_volume = um.rotate_volume
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        # ---- test_co3d.py:133-146, verbatim
+        img_feat_src, img_feat_tgt = model(image1[None], image2[None])
+
+        B, C, D, H, W = img_feat_src.shape
+
+        img_feat_src_2_tgt = [rotate_volume(img_feat[None].expand(proposals.shape[0], -1, -1, -1, -1), proposals) for img_feat in img_feat_src]
+        img_feat_src_2_tgt = torch.stack(img_feat_src_2_tgt).reshape(-1, C, D, H, W)
+
+        img_feat_src_2_tgt = model.feature_aligner.forward_3d2d(img_feat_src_2_tgt).reshape(B, proposals.shape[0], -1, H*W)
+        img_feat_tgt = model.feature_aligner.forward_3d2d(img_feat_tgt)
+
+        pred_sim = (img_feat_src_2_tgt * img_feat_tgt[:, None]).sum(dim=2).mean(dim=-1)
+        all_sim = pred_sim
+
+        pred_sim, pred_index = torch.max(pred_sim, dim=1)
+        pred_src_2_tgt_R = proposals[pred_index]
+        # ----
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated(dev) - base
+    finally:
+        ahv.patch.uninstall()
+        torch.autograd.set_detect_anomaly(False)
+    ran = {k: ahv.patch.calls[k] - before[k] for k in before}
+    # (ii) which code ran
+    assert ran == {"forward_2d3d_hip": 1, "forward_2d3d_reference": 0, "forward_3d2d_inference": 2, "forward_3d2d_autograd": 0}, ran
+    assert not img_feat_src.requires_grad and not all_sim.requires_grad
+    # (i) the reference-run digest
+    assert pred_index.item() == int(dg["best_idx"][0])
+    assert abs(pred_sim.item() - float(dg["best"][0])) < 1e-4 * abs(float(dg["best"][0]))
+    top = all_sim[0, torch.from_numpy(dg["top16_idx"]).to(dev)].cpu().numpy()
+    assert np.max(np.abs(top - dg["top16_score"]) / np.abs(dg["top16_score"])) < 1e-4
+    every = all_sim[0, ::97].cpu().numpy()
+    assert np.max(np.abs(every - dg["every97_score"]) / np.abs(dg["every97_score"]).clip(1e-2)) < 1e-4
+    assert torch.equal(pred_src_2_tgt_R[0], proposals[int(dg["best_idx"][0])])
+    # (iii) memory: the script's own tensors are the rotated volumes twice (list + torch.stack's copy, 1.64 GB each),
+    # the features (0.41 GB) and their product (0.41 GB) = 4.1 GB.  The reference's dataflow needs those AND the
+    # sampling grid (0.3 GB), three permuted slab copies + their concatenation (4.9 + 4.9 GB) and the conv / relu /
+    # normalize temporaries: > 14 GB (SURVEY 8d: ~560 KB per hypothesis).
+    n = proposals.shape[0]
+    own = n * (2 * 32768 + 2 * 8192)
+    assert peak <= 1.1 * own, (peak, own)
+    print("option A peak memory %.2f GB (script's own tensors %.2f GB)" % (peak / 1e9, own / 1e9))
+
+
 def test_graphed_encoder_matches_eager(ahv, dev):
     torch.manual_seed(5)
     fa = ahv.aligner.Feature_Aligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4).to(dev).eval()

@@ -132,3 +132,46 @@ def test_nonfinite_inputs_match_the_reference(oracle, g128):
         assert idx[0] == ref_idx, name
         n_cases += 1
     assert n_cases == 10
+
+
+def infonce_from_torch_ref(g, tag, dtype=torch.float32):
+    """modules/model_co3d.py:41-61 over oracle/torch_ref.py's operators on the G11 inputs -> (loss, sim, 5 gradients)."""
+    from oracle import torch_ref
+    t = lambda k: torch.from_numpy(g[k]).to(dtype)
+    vs, vt = t(tag + "_vol_src").requires_grad_(True), t(tag + "_vol_tgt").requires_grad_(True)
+    W1, W2, b2 = (t(k).requires_grad_(True) for k in ("W1", "W2", "b2"))
+    R, pos = t(tag + "_R"), torch.from_numpy(g[tag + "_positive"])
+    ft = torch_ref.forward_3d2d(vt, W1, W2, b2)
+    sim = []
+    for b in range(vs.shape[0]):
+        n = R.shape[1]
+        f = torch_ref.forward_3d2d(torch_ref.rotate_volume(vs[b:b + 1].expand(n, -1, -1, -1, -1), R[b]), W1, W2, b2)
+        sim.append((f * ft[b:b + 1]).sum(dim=1).mean(dim=-1))
+    sim = torch.stack(sim)
+    e = torch.exp(sim / 0.1)
+    loss = (-torch.log((e * pos).sum(dim=-1) / e.sum(dim=-1).clamp(min=1e-8))).mean()
+    return loss, sim, torch.autograd.grad(loss, [vs, vt, W1, W2, b2])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_torch_ref_autograd_matches_the_reference_gradients(tag):
+    """G11 `infonce_grad`: loss, similarities and d loss / d (vol_src, vol_tgt, W1, W2, b2) that the reference's own
+    rotate_volume / forward_3d2d produced under autograd (tools/gen_golden.py gen_infonce).  The torch restatement
+    runs the same ATen operators in the same order, forward and backward; the positive mask is re-derived from R and
+    the GT as modules/model_co3d.py:44-46 does."""
+    g = load_golden("infonce_grad")
+    R, gt = torch.from_numpy(g[tag + "_R"]), torch.from_numpy(g[tag + "_gt"])
+    gt_sim = (torch.sum(R.flatten(2) * gt.view(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+    assert np.array_equal((180 * torch.arccos(gt_sim) / np.pi <= int(g["acc_thr"])).numpy(), g[tag + "_positive"])
+    assert g[tag + "_positive"][:, :3].tolist() == [[True, True, False]] * R.shape[0]
+    loss, sim, grads = infonce_from_torch_ref(g, tag)
+    # same ATen operators in the same order; the reductions' summation order follows the thread count, hence not bit-exact
+    assert relerr(sim.detach().numpy(), g[tag + "_sim"]) < 1e-6
+    assert abs(loss.item() - float(g[tag + "_loss"])) <= 2e-6
+    for got, key in zip(grads, ("d_vol_src", "d_vol_tgt", "d_W1", "d_W2", "d_b2")):
+        assert relerr(got.numpy(), g[tag + "_" + key]) < 1e-5, key
+    # and the fp64 evaluation of the same graph (what tests/test_gpu_backward.py holds the HIP backward to) agrees
+    # with the reference's fp32 gradients to fp32 rounding
+    _, _, grads64 = infonce_from_torch_ref(g, tag, torch.float64)
+    for got, key in zip(grads64, ("d_vol_src", "d_vol_tgt", "d_W1", "d_W2", "d_b2")):
+        assert relerr(got.numpy(), g[tag + "_" + key].astype(np.float64)) < 2e-4, key

@@ -237,6 +237,61 @@ def gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt):
     np.savez(os.path.join(OUT, "nonfinite.npz"), **out)
 
 
+def gen_infonce(rotate_volume, fa, vol_src3, vol_tgt3):
+    """G11 `infonce_grad`: the reference's training loss and its gradients, produced by the
+    reference's own differentiable callables under torch autograd.  `utils.rotate_volume` (utils.py:113-131) and
+    `Feature_Aligner.forward_3d2d` (modules/modules.py:112-124) execute as shipped; the loss lines of
+    `Estimator.infoNCE_loss` (modules/model_co3d.py:41-61 -- the class needs lightning / timm and is not importable)
+    are issued as the same torch expressions, as the score lines are for G1.  Per-sample hypothesis sets with the GT
+    at index 0 (model_co3d.py:85-86), ACC_THR = 30 (config.yaml:9), temperature 0.1.  Two cases: B = 2 x 9 and
+    B = 3 x 40; in each, hypothesis 1 is the GT turned by 12 degrees (a second positive) and hypothesis 2 the GT
+    turned by 31 degrees (just outside).  Stored: loss, per-sample loss, sim, the positive mask and
+    d loss / d (vol_src, vol_tgt, W1, W2, b2)."""
+    import copy
+    ACC_THR = 30
+    out = {}
+    for tag, B, N, seed in (("a", 2, 9, 110), ("b", 3, 40, 111)):
+        f = copy.deepcopy(fa).train()
+        gt = torch.from_numpy(rot.haar_rotations_np(B, seed=seed))
+        sampled = torch.from_numpy(rot.haar_rotations_np(B * N, seed=seed + 7)).reshape(B, N, 3, 3).clone()
+        sampled[:, 0] = gt
+        sampled[:, 1] = torch.from_numpy(axis_rot("z", 12.0)) @ gt
+        sampled[:, 2] = torch.from_numpy(axis_rot("x", 31.0)) @ gt
+        v1 = vol_src3[:B].clone().requires_grad_(True)
+        v2 = vol_tgt3[:B].clone().requires_grad_(True)
+        # ---- modules/model_co3d.py:41-61, line by line (self.num_rota = N, self.feature_aligner = f)
+        bs = gt.shape[0]
+        with torch.no_grad():
+            gt_sim = (torch.sum(sampled.flatten(2) * gt.view(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+            gt_dis = torch.arccos(gt_sim) / np.pi
+            posi_indices = [torch.nonzero(180 * gt_dis[i] <= ACC_THR).squeeze(-1) for i in range(bs)]
+        warp = [rotate_volume(v1[idx:idx + 1].expand(N, -1, -1, -1, -1), sampled[idx]) for idx in range(bs)]
+        warp = [f.forward_3d2d(w) for w in warp]
+        f2 = f.forward_3d2d(v2)
+        sim = [(warp[idx] * f2[idx:idx + 1]).sum(dim=1).mean(dim=-1) for idx in range(bs)]
+        positive_sim = torch.stack([torch.exp(sim[idx][posi_indices[idx]] / 0.1).sum(dim=0) for idx in range(bs)])
+        positive_negative_sim = (torch.exp(torch.stack(sim) / 0.1)).sum(dim=-1)
+        per_sample = -torch.log(positive_sim / positive_negative_sim.clamp(min=1e-8))
+        loss = per_sample.mean()
+        # ----
+        c1, c2 = f.feature_embedding_2d[0], f.feature_embedding_2d[2]
+        g = torch.autograd.grad(loss, [v1, v2, c1.weight, c2.weight, c2.bias])
+        positive = torch.zeros(B, N, dtype=torch.bool)
+        for i in range(bs):
+            positive[i, posi_indices[i]] = True
+        out.update({tag + "_vol_src": v1.detach().numpy(), tag + "_vol_tgt": v2.detach().numpy(),
+                    tag + "_R": sampled.numpy(), tag + "_gt": gt.numpy(), tag + "_positive": positive.numpy(),
+                    tag + "_sim": torch.stack(sim).detach().numpy(), tag + "_loss": loss.detach().numpy(),
+                    tag + "_loss_per_sample": per_sample.detach().numpy(),
+                    tag + "_d_vol_src": g[0].numpy(), tag + "_d_vol_tgt": g[1].numpy(),
+                    tag + "_d_W1": g[2].reshape(32, 384).numpy(), tag + "_d_W2": g[3].reshape(32, 32).numpy(),
+                    tag + "_d_b2": g[4].numpy()})
+        print("G11 %s B=%d N=%d loss %.6f positives %s |dV| max %.3e |dW1| max %.3e" % (
+            tag, B, N, loss.item(), positive.sum(dim=1).tolist(), g[0].abs().max().item(), g[2].abs().max().item()))
+    W1, W2, b2 = head_weights(fa)
+    np.savez(os.path.join(OUT, "infonce_grad.npz"), W1=W1, W2=W2, b2=b2, acc_thr=np.int64(ACC_THR), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -250,6 +305,9 @@ def main():
     fa, vol_src3, vol_tgt3 = seeded_pair(Feature_Aligner)
     W1, W2, b2 = head_weights(fa)
     vol_src, vol_tgt = vol_src3[:1], vol_tgt3[:1]
+    if "--only-g11" in sys.argv:    # round 6 addition alone
+        gen_infonce(rotate_volume, fa, vol_src3, vol_tgt3)
+        return
     if "--only-g10" in sys.argv:    # round 5 addition alone
         gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt)
         return
@@ -354,6 +412,7 @@ def main():
     gen_grid_digest(rotate_volume, fa, vol_src, vol_tgt)
     gen_batched32(rotate_volume, Feature_Aligner, fa)
     gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt)
+    gen_infonce(rotate_volume, fa, vol_src3, vol_tgt3)
     gen_encoder_full(Feature_Aligner)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
