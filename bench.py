@@ -272,11 +272,13 @@ class VerifyLoop:
         B = self.B  # (empty slots of a partial group decode to -inf / -1)
         lane["out"] = (best.view(self.group, B), idx.view(self.group, B), R_pred.view(self.group, B, 3, 3))
 
-    def run(self, steps, events=None, stamps=None):
-        """`steps` steps, every one finalized on return (the streams are NOT synchronised).  `events`: {step: event pair} for
-        the launches to bracket with HIP events on the launch's own stream (a SAMPLE: a record idles the queue ~6 us)."""
+    def run(self, steps, brackets=None, stamps=None):
+        """`steps` steps, every one finalized on return (the streams are NOT synchronised).  `brackets`: [(first step, last
+        step, event, event)] -- HIP events recorded on the launches' own stream in front of launch `first` and behind launch
+        `last` (a record idles the queue ~6 us: a bracket spans a whole group of launches and ends before the group's select)."""
         import torch
-        events = events or {}
+        before = {b[0]: b[2] for b in (brackets or [])}
+        after = {b[1]: b[3] for b in (brackets or [])}
         multi = len(self.lanes) > 1
         main = torch.cuda.current_stream() if multi else None
         lane = self.lanes[0]
@@ -286,15 +288,14 @@ class VerifyLoop:
                 lane = self.lanes[g % len(self.lanes)]
                 if multi:
                     torch.cuda.set_stream(lane["stream"])
-            ev = events.get(i)
-            if ev is not None:
-                ev[0].record()
+            if i in before:
+                before[i].record()
             # `stamps` given: the same kernel also writes every workgroup's s_memtime / s_memrealtime pair (shader clock)
             self.ops.verify_pair(self.vs, self.vt, self.R, *self.head, n_offset=self.n_offset, want_scores=False,
                                  best_key=lane["keys"][j], reset_best=False, split_f16=self.split,
                                  clock_stamps=None if stamps is None else stamps[i])
-            if ev is not None:
-                ev[1].record()
+            if i in after:
+                after[i].record()
             if j == self.group - 1 or i == steps - 1:  # the group is complete (or the run ends inside it)
                 self._finalize(lane)
         if multi:
@@ -304,6 +305,35 @@ class VerifyLoop:
         j = (steps - 1) % self.group
         best, idx, R_pred = lane["out"]
         self.out = {"best": best[j], "idx": idx[j], "R_pred": R_pred[j]}
+
+
+def rank_identity(torch, dev, rank, local_rank, backend):
+    """What a reader of a multi-rank line looks for first: which physical GPU each rank drove."""
+    p = torch.cuda.get_device_properties(dev)
+    bus = None
+    if all(hasattr(p, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    else:
+        try:  # hipDeviceGetPCIBusId of the runtime torch already loaded
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            if ctypes.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(dev.index)) == 0:
+                bus = buf.value.decode()
+        except OSError:
+            pass
+    coll = None
+    if backend == "nccl":
+        try:
+            coll = "rccl " + ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001 -- identity is evidence, never a reason to fail the run
+            coll = "rccl (version unavailable: %s)" % type(e).__name__
+    else:
+        coll = backend
+    uuid = getattr(p, "uuid", None)
+    return {"rank": rank, "local_rank": local_rank, "device_index": int(dev.index), "device": p.name,
+            "gcn_arch": getattr(p, "gcnArchName", None), "pci_bus_id": bus, "uuid": None if uuid is None else str(uuid),
+            "host": socket.gethostname(), "pid": os.getpid(), "collectives": coll,
+            "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
 
 
 def worker(args):
@@ -359,8 +389,22 @@ def worker(args):
     # strong scaling: ONE set of 50 000 hypotheses, this rank's contiguous shard of it
     lo, hi = adist.shard_range(N_HYP, rank, world)
     R, n_offset, n_local = R_all[lo:hi].contiguous(), lo, hi - lo
-    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, split)
+    # Lanes: with more than one rank the step loop runs on TWO lanes -- groups of steps alternate between two streams, each
+    # with its own key buffer and its own communicator, so that one step's drain (the wait for the slowest workgroup, the
+    # launch gap, the next prologue: ~18 us that do not shrink with N) overlaps the next step's hypotheses.
+    # One rank: one lane, one stream -- the N = 1 line is the same measurement as in every earlier round.
+    lanes = int(os.environ.get("AHV_BENCH_LANES", "2" if (world > 1 or os.environ.get("AHV_BENCH_TWO_LANES_PG", "0") == "1") else "1"))
+    lanes = max(1, min(lanes, 2))
+    loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, split, lanes=lanes)
     ncu = lib.ahv_device_cu_count()
+    ident = rank_identity(torch, dev, rank, local_rank, args.backend if use_pg else "none")
+    ranks_info = [ident]
+    if use_pg:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, ident)
+        if args.backend == "nccl" and world > 1:   # one GPU per rank, every one a different device
+            seen = {(r["host"], r["pci_bus_id"] or r["uuid"] or r["device_index"]) for r in ranks_info}
+            assert len(seen) == world, "ranks share a GPU: %s" % ranks_info
 
     def barrier():
         if use_pg:
@@ -369,14 +413,26 @@ def worker(args):
     def new_events(n):
         return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
 
-    def sampled_events(steps):
-        """Event pairs for every k-th step (k = 8, or less so that a short run still gets >= 3 samples): the kernel time of
-        the contract's `roofline` comes from HIP events on the kernel's stream INSIDE the timed region, but each record
-        costs the queue ~6 us of idling (the 12 us per step of round 3's every-launch bracketing were 1.7 % of `value`);
-        the in-kernel real-time stamps of EVERY timed launch are reported beside them."""
-        k = 8 if steps >= 24 else max(1, steps // 3)
-        idx = list(range(k // 2, steps, k))  # mid-interval: an unbiased sample (step 0 runs behind the barrier's idle gap)
-        return dict(zip(idx, new_events(len(idx)))), k
+    def group_brackets(steps, grp):
+        """HIP-event brackets for the contract's `roofline.kernel_ms`: one bracket per group of `grp` consecutive launches
+        of the timed region (first record in front of the group's first launch, second behind its last, BEFORE the group's
+        select), every group but the first (step 0 runs behind the barrier's idle gap; a run of one group keeps it).
+        A bracket's time / its launches includes the launch gaps between them and amortises the ~6 us a record idles the
+        queue over the group, so that kernel_ms <= ms_per_step holds by construction (three single-launch
+        brackets at --steps 20 each carried their own record and came out ABOVE ms_per_step)."""
+        out = []
+        n_groups = (steps + grp - 1) // grp
+        for g in range(n_groups):
+            first, last = g * grp, min(steps, (g + 1) * grp) - 1
+            if g == 0 and n_groups > 1:
+                continue
+            e0, e1 = new_events(1)[0]
+            out.append((first, last, e0, e1))
+        return out
+
+    def bracket_ms(brackets):
+        """[(ms per launch, launches)] of the brackets (after a synchronize)."""
+        return [(b[2].elapsed_time(b[3]) / (b[1] - b[0] + 1), b[1] - b[0] + 1) for b in brackets]
 
     def prewarm(min_ms, max_ms=1500.0, batch=8):
         """Untimed, TIME-based pre-warm of the same step: the chip needs ~30 ms of this kernel to ramp its clock
@@ -387,7 +443,7 @@ def worker(args):
         settled = False
         while min_ms > 0:
             evs = new_events(batch)
-            loop.run(batch, dict(enumerate(evs)))
+            loop.run(batch, [(i, i, a, b) for i, (a, b) in enumerate(evs)])
             torch.cuda.synchronize()
             done += batch
             last = (last + [a.elapsed_time(b) for a, b in evs])[-3:]
@@ -403,7 +459,7 @@ def worker(args):
         return {"prewarm_ms": (time.perf_counter() - t0) * 1e3, "prewarm_steps": done, "prewarm_settled": settled,
                 "prewarm_last_kernel_ms": [round(x, 4) for x in last]}
 
-    def timed(lp, steps, warmup, events=None, stamps=None):
+    def timed(lp, steps, warmup, brackets=None, stamps=None):
         """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
         if warmup:
             lp.run(warmup)
@@ -411,7 +467,7 @@ def worker(args):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        lp.run(steps, events, stamps)
+        lp.run(steps, brackets, stamps)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -443,13 +499,28 @@ def worker(args):
     gc.disable()
     with torch.no_grad():
         pre = prewarm(args.prewarm_ms)
-        events, ev_every = sampled_events(args.steps)
         stamps = torch.zeros(args.steps, 4 * ncu, dtype=torch.int64, device=dev)
-        dt = timed(loop, args.steps, args.warmup, events, stamps)
+        if lanes == 1:
+            # fused kernel, HIP events on its stream, inside the timed region
+            brackets = group_brackets(args.steps, loop.group)
+            dt = timed(loop, args.steps, args.warmup, brackets, stamps)
+            kern_src = "HIP events on the kernel's stream INSIDE the timed region: one bracket per group of %d launches " \
+                       "(first group left out), time / launches" % loop.group
+        else:
+            # Two lanes: consecutive launches overlap, so an event pair around a launch would time the overlap, not the
+            # kernel.  The timed region carries no events; `roofline.achieved` is priced from the WALL time (flops x steps /
+            # timed seconds) and kernel_ms comes from a ONE-LANE calibration leg of the same step in front of it.
+            cal = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, split, lanes=1)
+            cal_steps = max(2 * cal.group, min(args.steps, 48))
+            brackets = group_brackets(cal_steps, cal.group)
+            cal_dt = timed(cal, cal_steps, 0, brackets)
+            dt = timed(loop, args.steps, args.warmup, None, stamps)
+            kern_src = "one-lane calibration leg (%d steps, same shard, same collectives, %.4f ms per step) in front of the " \
+                       "two-lane timed region: HIP events per group of %d launches" % (cal_steps, cal_dt / cal_steps * 1e3, cal.group)
         out = dict(loop.out)
-        # fused kernel, HIP events on its stream, a sample of the timed launches
-        kern_list = [events[i][0].elapsed_time(events[i][1]) for i in sorted(events)]
-        kern_ms = float(np.mean(kern_list))
+        kern_pairs = bracket_ms(brackets)
+        kern_list = [ms for ms, _ in kern_pairs]
+        kern_ms = float(sum(ms * n for ms, n in kern_pairs) / sum(n for _, n in kern_pairs))
         # shader clock held DURING the timed launches: per workgroup (s_memtime delta) / (s_memrealtime delta at
         # 100 MHz); median over workgroups and launches (MI355X_MICROARCH.md "DVFS give-back" item 6)
         st_all = stamps.cpu().numpy().reshape(args.steps, -1, 4)
@@ -512,12 +583,13 @@ def worker(args):
             s32, _ = ops.verify_pair(vs32, vt32, R_all, *head, split_f16=split)
             assert torch.equal(lp3.out["idx"], torch.max(s32, dim=1)[1])
             del s32
-            # two lanes: independent pairs on two streams (under a process group: two communicators) -- what a loop over
-            # many pairs gets when one step's drain overlaps the next step's ramp.  Single process by default; with a
-            # process group only on request (AHV_BENCH_TWO_LANES_PG=1): never a new code path in somebody else's 8-GPU run.
-            if not use_pg or os.environ.get("AHV_BENCH_TWO_LANES_PG", "0") == "1":
+            # the other lane count: one rank times two lanes beside its one-stream headline; a multi-rank run (two lanes by
+            # default, each lane its own communicator) times the one-stream loop beside it
+            if lanes == 1:
                 lp2, secondary["n50k_b1_two_lanes"] = leg(vol_src, vol_tgt, R_all, 2 * sec_steps, 48, grp=max(group, 4), lanes=2)
-                assert int(lp2.out["idx"].item()) == int(out["idx"].item())
+            else:
+                lp2, secondary["n50k_b1_one_stream"] = leg(vol_src, vol_tgt, R_all, sec_steps, 48, lanes=1)
+            assert int(lp2.out["idx"].item()) == int(out["idx"].item())
             if world == 1:
                 # what a strong-scaling run can reach, from this GPU alone: the shard a rank of an n-GPU run scores per
                 # step (contiguous 1/n of the same set, n_offset, the multi-rank cadence of 8 steps per select, no
@@ -544,7 +616,11 @@ def worker(args):
 
     if rank == 0:
         value = N_HYP * args.steps / dt                      # the whole job: ONE set of 50 000 hypotheses per step
-        achieved = FLOPS_PER_HYP * n_local / (kern_ms * 1e-3) / 1e12   # the timed kernel scores this rank's shard
+        if lanes == 1:
+            achieved = FLOPS_PER_HYP * n_local / (kern_ms * 1e-3) / 1e12   # the timed kernel scores this rank's shard
+        else:   # overlapping launches: this rank's algorithmic flops of the timed region / its wall time
+            achieved = FLOPS_PER_HYP * n_local * args.steps / dt / 1e12
+        per_step = None if secondary is None else secondary["n50k_b1_collective_per_step"]
         # HBM bytes per launch: NOT measured in this run (PMC passes need rocprofv3) -- the committed figure of
         # tools/profile_bench.sh on the same command, reported only while it describes THIS kernel and THIS launch shape:
         # the hash of the scorer's sources must equal the one recorded with the counters (else null + the reason), the
@@ -572,7 +648,13 @@ def worker(args):
             "metric": "rotation hypotheses scored/sec (B=1)", "value": value, "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", **pre,
+            "data": "synthetic",
+            # the reference's literal cadence (test_co3d.py:145-146: torch.max + proposals[idx] after EVERY pair; with ranks,
+            # one all-reduce per step too), timed in the same run on one stream; `value` amortises the select (and the
+            # collective) over `steps_per_select` independent pairs -- the same cadence at every N
+            "ms_per_step_select_every_step": None if per_step is None else per_step["ms_per_step"],
+            "value_select_every_step": None if per_step is None else per_step["hypotheses_per_s"],
+            **pre,
             "config": {"workload": "CO3D pair (BASELINE.json configs[1]): B=1, ONE set of N_hyp=50000 Haar rotations split "
                                    "over the GPUs (contiguous shards, n_offset), source volume 16x8x8x8 (P=512 voxel sites x "
                                    "16 ch), head 384->32->32, 64 positions",
@@ -583,7 +665,13 @@ def worker(args):
                                "ahv_verify_pair_f32)%s + ONE select launch per %d step(s) (decode + gather R_pred + key reset)" % (
                                    " + ONE all-reduce(MAX) of the int64 keys of %d steps, in stream order" % loop.group
                                    if use_pg else "", loop.group),
-                       "steps_per_collective": loop.group if use_pg else None, "steps_per_select": loop.group},
+                       "steps_per_collective": loop.group if use_pg else None, "steps_per_select": loop.group,
+                       "lanes": lanes,
+                       "lanes_note": None if lanes == 1 else "groups of %d steps alternate between %d streams, each with its own "
+                                     "key buffer and its own communicator: independent pairs overlap one step's drain with the "
+                                     "next step's hypotheses (AHV_BENCH_LANES=1 for the one-stream loop; secondary."
+                                     "n50k_b1_one_stream times it in this run)" % (loop.group, lanes),
+                       "ranks": ranks_info},
             # what the timed region computed (asserted above against torch.max over the materialised scores of
             # all ranks): lets a forced-process-group run be compared with a single-process run
             "result": {"best_idx": int(out["idx"].item()), "best_score": float(out["best"].item())},
@@ -591,10 +679,10 @@ def worker(args):
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": kern_ms,
                          "kernel_ms_min": float(np.min(kern_list)), "kernel_ms_median": float(np.median(kern_list)),
-                         "kernel_ms_mean": kern_ms, "kernel_ms_per_step": [round(x, 4) for x in kern_list],
-                         "kernel_ms_is": "HIP event pairs on the kernel's stream around every %d-th launch of the timed region "
-                                         "(%d samples; a record idles the queue ~6 us, so not every launch)" % (
-                                             ev_every, len(kern_list)),
+                         "kernel_ms_mean": kern_ms, "kernel_ms_per_bracket": [round(x, 4) for x in kern_list],
+                         "kernel_ms_is": kern_src + " (%d brackets, %d launches)" % (len(kern_pairs), sum(n for _, n in kern_pairs)),
+                         "achieved_is": "algorithmic flops per launch / kernel_ms" if lanes == 1 else
+                                        "this rank's algorithmic flops of the timed region / its wall time (launches overlap)",
                          "hypothesis_loop_ms_all_launches_median": float(np.median(loop_ms)) if loop_ms else None,
                          "hypothesis_loop_ms_is": "in-kernel s_memrealtime stamps of ALL %d timed launches: first workgroup "
                                                   "entering its hypothesis loop -> last leaving it" % args.steps,

@@ -49,10 +49,22 @@ def test_bench_json_line():
     assert "ms" not in d["config"] and d["config"]["backend"] == "single process"
     # the time-based pre-warm ran (>= 60 ms of the same step) and is disclosed; the per-step list is complete
     assert d["prewarm_ms"] >= 60.0 and d["prewarm_steps"] >= 8
-    assert len(r["kernel_ms_per_step"]) == 5 and "every 1-th launch" in r["kernel_ms_is"]   # 5 steps: all bracketed
+    # 5 steps = one (partial) group of launches = one event bracket INSIDE the timed region, ahead of the group's select:
+    # the kernel time can never exceed the step time it is part of
+    assert len(r["kernel_ms_per_bracket"]) == 1 and "(1 brackets, 5 launches)" in r["kernel_ms_is"]
+    assert "INSIDE the timed region" in r["kernel_ms_is"] and r["achieved_is"] == "algorithmic flops per launch / kernel_ms"
+    assert r["kernel_ms"] <= d["ms_per_step"]
     assert 0.5 * r["kernel_ms"] < r["hypothesis_loop_ms_all_launches_median"] <= r["kernel_ms"]
-    assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= max(r["kernel_ms_per_step"]) + 1e-6
+    assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= max(r["kernel_ms_per_bracket"]) + 1e-6
     assert abs(r["kernel_ms_mean"] - r["kernel_ms"]) < 1e-12
+    # one rank, one lane, and which GPU it was
+    assert d["config"]["lanes"] == 1 and len(d["config"]["ranks"]) == 1
+    who = d["config"]["ranks"][0]
+    assert who["rank"] == 0 and who["device_index"] == 0 and "MI355" in who["device"] and who["pci_bus_id"]
+    # the reference's literal cadence (select after every pair) is a top-level figure, never better than the headline's
+    assert d["ms_per_step_select_every_step"] == d["secondary"]["n50k_b1_collective_per_step"]["ms_per_step"]
+    assert d["value_select_every_step"] == d["secondary"]["n50k_b1_collective_per_step"]["hypotheses_per_s"]
+    assert 0.97 * d["ms_per_step"] < d["ms_per_step_select_every_step"] < d["ms_per_step"] + 0.03
     assert "TIMED launches" in r["shader_clock_source"]
     assert out.stdout.strip() == lines[0]                                  # stdout = the one JSON line, nothing else
     assert r["kernel"].startswith("score_hypotheses_dual_kernel<false, true>")   # the one-launch verify step
@@ -90,8 +102,9 @@ def test_bench_rccl_branch_on_one_gpu():
         assert out.returncode == 0, out.stderr[-3000:]
         return json.loads(out.stdout.strip())
 
-    a, b = run({}), run({"AHV_BENCH_FORCE_PG": "1"})
+    a, b = run({}), run({"AHV_BENCH_FORCE_PG": "1", "AHV_BENCH_LANES": "1"})
     assert a["config"]["backend"] == "single process" and b["config"]["backend"] == "rccl"
+    assert b["config"]["lanes"] == 1 and "rccl" in b["config"]["ranks"][0]["collectives"]
     assert b["n_gpus"] == 1 and a["result"] == b["result"]
     assert b["config"]["steps_per_collective"] == 8 and a["config"]["steps_per_collective"] is None
     assert b["scaling"] == "strong" and b["secondary"]["n50k_b1_collective_per_step"]["steps_per_collective"] == 1
@@ -106,11 +119,24 @@ def test_bench_rccl_branch_on_one_gpu():
     gap = a["ms_per_step"] - a["roofline"]["kernel_ms"]
     if tb > 1.02 * ta or gap > 0.010:
         a2 = run({})
-        ta, tb = min(ta, a2["ms_per_step"]), min(tb, run({"AHV_BENCH_FORCE_PG": "1"})["ms_per_step"])
+        ta, tb = min(ta, a2["ms_per_step"]), min(tb, run({"AHV_BENCH_FORCE_PG": "1", "AHV_BENCH_LANES": "1"})["ms_per_step"])
         gap = min(gap, a2["ms_per_step"] - a2["roofline"]["kernel_ms"])
     assert tb <= 1.03 * ta, (ta, tb)   # (two processes: the clock they are granted differs by up to ~1 %)
     # one step = ONE fused launch + ONE select launch: what is not the scorer stays small (21 us in round 3)
-    assert gap < 0.012, (a["ms_per_step"], a["roofline"]["kernel_ms"], gap)
+    assert 0 <= gap < 0.012, (a["ms_per_step"], a["roofline"]["kernel_ms"], gap)
+    # What a multi-rank run takes by default: TWO lanes, each with its own stream, key buffer and RCCL communicator
+    # (AHV_BENCH_TWO_LANES_PG=1 selects it at one rank).  Same winner, no slower than one stream, priced from wall time with
+    # the kernel time of a one-lane calibration leg -- so an 8-GPU run is not the first run of two communicators either.
+    c = run({"AHV_BENCH_FORCE_PG": "1", "AHV_BENCH_TWO_LANES_PG": "1"})
+    assert c["config"]["backend"] == "rccl" and c["config"]["lanes"] == 2 and c["result"] == a["result"]
+    assert "own communicator" in c["config"]["lanes_note"] and c["config"]["steps_per_collective"] == 8
+    r = c["roofline"]
+    assert "calibration leg" in r["kernel_ms_is"] and "wall time" in r["achieved_is"]
+    assert abs(r["achieved"] - 1839104 * 50000 / (c["ms_per_step"] * 1e-3) / 1e12) / r["achieved"] < 1e-6
+    assert 0.5 < r["frac"] < 1.0 and r["kernel_ms"] <= 1.02 * c["ms_per_step"]
+    assert c["ms_per_step"] <= 1.03 * tb, (c["ms_per_step"], tb)
+    one = c["secondary"]["n50k_b1_one_stream"]
+    assert one["lanes"] == 1 and one["steps_per_collective"] == 8 and "n50k_b1_two_lanes" not in c["secondary"]
 
 
 def test_bench_launches_its_own_ranks():
@@ -133,7 +159,14 @@ def test_bench_launches_its_own_ranks():
     assert sec["n50k_b1_collective_per_step"]["steps_per_collective"] == 1 and d["config"]["steps_per_collective"] == 8
     assert sec["weak_n50k_per_rank_b1"]["n_hyp_total"] == 100000 and sec["weak_n50k_per_rank_b1"]["n_hyp_per_rank"] == 50000
     assert sec["configs3_b32_n50k"]["n_hyp_per_rank"] == 25000 and "predicted_strong_scaling" not in sec
-    assert "n50k_b1_two_lanes" not in sec   # two communicators only on request (AHV_BENCH_TWO_LANES_PG=1)
+    # more than one rank: two lanes (two communicators) by default, the one-stream loop timed beside it
+    assert d["config"]["lanes"] == 2 and sec["n50k_b1_one_stream"]["lanes"] == 1 and "n50k_b1_two_lanes" not in sec
+    assert "calibration leg" in d["roofline"]["kernel_ms_is"]
+    # which GPU each rank drove (here: both ranks on the one device of the box, over gloo)
+    who = d["config"]["ranks"]
+    assert [w["rank"] for w in who] == [0, 1] and all(w["device_index"] == 0 and w["collectives"] == "gloo" for w in who)
+    assert who[0]["pid"] != who[1]["pid"] and who[0]["pci_bus_id"] == who[1]["pci_bus_id"]
+    assert d["ms_per_step_select_every_step"] == sec["n50k_b1_collective_per_step"]["ms_per_step"]
     # a failing rank takes the launch down with a non-zero code instead of hanging in a collective
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "nccl",
                           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
