@@ -83,7 +83,8 @@ class CoarseToFine:
             raise RuntimeError("the one-launch step needs one rank, no collectives and the HIP backend")
         self.fused = bool(fused)
         self._fused_state = ops.CoarseToFineState(batch, dev) if self.fused else None
-        self._fused_out = {}
+        self._fused_out = {}     # slot -> the one-launch step's output buffers (a slot = one step of a multi-step graph)
+        self._many = None        # (K, static inputs, captured graph, outputs) of run_many
 
     def _merge(self, key):
         if self.collectives:  # world > 1, or forced on a 1-rank group: same call, same captured node
@@ -101,11 +102,11 @@ class CoarseToFine:
         return self._static
 
     # ---- the step, written once; runs eagerly or under capture
-    def _step(self, vol_src, vol_tgt):
+    def _step(self, vol_src, vol_tgt, slot: int = 0):
         o = self.ops
         if self.fused:
             r = o.coarse_to_fine(vol_src, vol_tgt, self.R_coarse, self.D, self.W1, self.W2, self.b2, state=self._fused_state,
-                                 want_scores=self.want_scores, no_teams=self.no_teams, out=self._fused_out)
+                                 want_scores=self.want_scores, no_teams=self.no_teams, out=self._fused_out.setdefault(slot, {}))
             # (the refinement set is never materialised here: R_fine stays None)
             self.last = {"coarse_scores": r.get("coarse_scores"), "fine_scores": r.get("fine_scores"), "R_fine": None}
             return r["fine_score"], r["fine_idx"], r["R_pred"], r["coarse_score"], r["coarse_idx"]
@@ -180,3 +181,49 @@ class CoarseToFine:
                 self._out = self._step(*static)
         self._graph.replay()
         return self._out
+
+    @torch.no_grad()
+    def run_many(self, vol_src: Optional[torch.Tensor] = None, vol_tgt: Optional[torch.Tensor] = None, steps: int = 8):
+        """``steps`` consecutive verify steps -- volumes ``(steps, B, 16, 8, 8, 8)`` -- as ONE hipGraph launch; returns a list
+        of ``steps`` result tuples (static buffers with ``use_graph``).  Why it exists: a hipGraphLaunch leaves the device
+        idle for ~9 us between the last kernel of one replay and the first of the next (ROCm 7.2, `rocprofv3
+        --kernel-trace`, profiles/r06_graph_timeline.txt) while plain launches follow each other with no gap, so a graph of
+        ONE 0.2-ms step replays 4 % slower than the same step issued eagerly; with several steps per graph the gap is paid
+        once per replay and the captured steps run back to back.  Without ``use_graph`` the steps are issued eagerly.
+        Called with no volumes it runs on the static inputs as they are (``many_buffers(steps)``)."""
+        if (vol_src is None) != (vol_tgt is None):
+            raise RuntimeError("pass both volumes or neither")
+        if not self.use_graph:
+            if vol_src is None:
+                vol_src, vol_tgt = self.many_buffers(steps)
+            try:
+                return [self._step(vol_src[k], vol_tgt[k], slot=k) for k in range(steps)]
+            except Exception:
+                self._reset_keys()
+                raise
+        static = self.many_buffers(steps)
+        if vol_src is not None and vol_src.data_ptr() != static[0].data_ptr():
+            static[0].copy_(vol_src)
+            static[1].copy_(vol_tgt)
+        if self._many[2] is None:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):  # warm-up outside capture
+                for k in range(min(2, steps)):
+                    self._step(static[0][k], static[1][k], slot=k)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = [self._step(static[0][k], static[1][k], slot=k) for k in range(steps)]
+            self._many[2], self._many[3] = graph, outs
+        self._many[2].replay()
+        return self._many[3]
+
+    def many_buffers(self, steps: int):
+        """Static inputs ``(vol_src, vol_tgt)``, each ``(steps, B, 16, 8, 8, 8)``, of ``run_many``."""
+        if self._many is None or self._many[0] != steps:
+            dev = self.R_coarse.device
+            bufs = tuple(torch.zeros((steps, self.B, 16, 8, 8, 8), dtype=torch.float32, device=dev) for _ in range(2))
+            self._many = [steps, bufs, None, None]
+        return self._many[1]

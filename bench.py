@@ -441,7 +441,10 @@ def worker(args):
         agree within 1 % (or max_ms).  Returns what it did, for the JSON line."""
         t0, done, last = time.perf_counter(), 0, []
         settled = False
-        while min_ms > 0:
+        # (every lane runs at least one whole group here: a lane's first collective creates its communicator, which must
+        # not happen inside the timed region)
+        batch = max(batch, loop.group * len(loop.lanes))
+        while min_ms > 0 or (len(loop.lanes) > 1 and done == 0):
             evs = new_events(batch)
             loop.run(batch, [(i, i, a, b) for i, (a, b) in enumerate(evs)])
             torch.cuda.synchronize()
@@ -449,7 +452,7 @@ def worker(args):
             last = (last + [a.elapsed_time(b) for a, b in evs])[-3:]
             elapsed = (time.perf_counter() - t0) * 1e3
             settled = len(last) == 3 and (max(last) - min(last)) <= 0.01 * min(last)
-            stop = (elapsed >= min_ms and settled) or elapsed >= max_ms
+            stop = (elapsed >= min_ms and settled) or elapsed >= max_ms or min_ms <= 0
             if use_pg:  # every rank must run the same number of steps (each carries a collective): stop together
                 flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -597,16 +600,16 @@ def worker(args):
                 pred = {"note": "t(50 000) / (n * t(50 000 / n)) on ONE GPU, 8 steps per select, no collective: the efficiency an "
                                 "n-GPU strong-scaling run can reach before link latency"}
                 t_ref = {}
-                for lanes in (1, 2):
-                    _, r = leg(vol_src, vol_tgt, R_all, sec_steps if lanes == 1 else 2 * sec_steps, 48, grp=8, lanes=lanes)
-                    t_ref[lanes] = r["ms_per_step"]
+                for nl in (1, 2):
+                    _, r = leg(vol_src, vol_tgt, R_all, sec_steps if nl == 1 else 2 * sec_steps, 48, grp=8, lanes=nl)
+                    t_ref[nl] = r["ms_per_step"]
                 for n in (2, 4, 8):
                     a, b = adist.shard_range(N_HYP, n - 1, n)   # the last rank's shard (offsets included)
                     row = {"n_hyp_per_rank": b - a}
-                    for lanes in (1, 2):
-                        _, r = leg(vol_src, vol_tgt, R_all[a:b], 2 * sec_steps, 48, grp=8, lanes=lanes, offset=a)
-                        row["ms_per_step" + ("" if lanes == 1 else "_two_lanes")] = r["ms_per_step"]
-                        row["efficiency" + ("" if lanes == 1 else "_two_lanes")] = t_ref[lanes] / (n * r["ms_per_step"])
+                    for nl in (1, 2):
+                        _, r = leg(vol_src, vol_tgt, R_all[a:b], 2 * sec_steps, 48, grp=8, lanes=nl, offset=a)
+                        row["ms_per_step" + ("" if nl == 1 else "_two_lanes")] = r["ms_per_step"]
+                        row["efficiency" + ("" if nl == 1 else "_two_lanes")] = t_ref[nl] / (n * r["ms_per_step"])
                     pred["n_gpus_%d" % n] = row
                 pred["ms_per_step_n50k"] = t_ref[1]
                 pred["ms_per_step_n50k_two_lanes"] = t_ref[2]

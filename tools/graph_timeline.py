@@ -25,7 +25,12 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 LEGS = [("eager_5", False, False, 1), ("graph_5", False, True, 1), ("eager_1", True, False, 1), ("graph_1", True, True, 1),
-        ("graph_5x8", False, True, 8)]
+        ("graph_5x8", False, True, 8), ("graph_1x8", True, True, 8)]
+# AHV_GTL_PG=1: a one-rank RCCL group, the five-launch step with its two key all-reduces issued (force_collectives): what a
+# rank of a multi-GPU run enqueues per step, eagerly and from the graph (the collectives captured with the kernels)
+PG = os.environ.get("AHV_GTL_PG", "0") == "1"
+if PG:
+    LEGS = [("eager_5_rccl", False, False, 1), ("graph_5_rccl", False, True, 1), ("graph_5x8_rccl", False, True, 8)]
 STEPS = 320
 
 
@@ -35,6 +40,12 @@ def run():
     ahv = importlib.import_module("3dahv_amd")
     ops = ahv.ops
     dev = torch.device("cuda:0")
+    if PG:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     g = torch.Generator().manual_seed(0)
     W1 = ((torch.rand(32, 384, generator=g) * 2 - 1) / np.sqrt(384.0)).to(dev)
     W2 = ((torch.rand(32, 32, generator=g) * 2 - 1) / np.sqrt(32.0)).to(dev)
@@ -51,7 +62,7 @@ def run():
         torch.cuda.synchronize()
     for k, (name, fused, use_graph, per_graph) in enumerate(LEGS):
         c2f = ahv.refine.CoarseToFine(W1, W2, b2, R, n_fine=1000, max_angle_deg=10.0, batch=1, use_graph=use_graph and per_graph == 1,
-                                      fused=fused)
+                                      fused=fused, force_collectives=PG)
         c2f.buffers[0].copy_(vol[0])
         c2f.buffers[1].copy_(vol[1])
         if per_graph > 1:   # several steps in ONE captured graph
@@ -84,6 +95,8 @@ def run():
                           "us_per_step_wall": dt / STEPS * 1e6}), flush=True)
         ops.so3_grid(2000 + k, dev)
         torch.cuda.synchronize()
+    if PG:
+        dist.destroy_process_group()
 
 
 def summarize(path):
@@ -93,8 +106,8 @@ def summarize(path):
     assert len(marks) == 2 * len(LEGS), (len(marks), "marker launches")
     for k, (name, fused, use_graph, per_graph) in enumerate(LEGS):
         seg = rows[marks[2 * k] + 1:marks[2 * k + 1]]
-        per_step = 1 if fused else 5
-        assert len(seg) == STEPS * per_step, (name, len(seg))
+        per_step = len(seg) // STEPS      # 1 / 5 kernels per step, plus whatever the collectives launch
+        assert len(seg) == STEPS * per_step and per_step >= (1 if fused else 5), (name, len(seg))
         s = np.array([int(r["Start_Timestamp"]) for r in seg], dtype=np.int64).reshape(STEPS, per_step)
         e = np.array([int(r["End_Timestamp"]) for r in seg], dtype=np.int64).reshape(STEPS, per_step)
         sel = slice(STEPS // 4, STEPS - 8)
@@ -112,7 +125,7 @@ def summarize(path):
         names = [r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ahv::", "")[:40] for r in seg[:per_step]]
         print("%-10s period %7.2f us | kernels %7.2f | idle inside a step %5.2f | idle between steps %5.2f (mean %5.2f)%s" % (
             name, np.median(period), np.median(busy), np.median(inside), np.median(between), between.mean(), extra))
-        if k == 0 or k == 2:
+        if not (use_graph and per_graph == 1) and per_graph == 1:
             durs = np.median((e - s)[sel], axis=0) / 1e3
             print("           kernels: " + ", ".join("%s %.1f" % (n, d) for n, d in zip(names, durs)))
 
