@@ -76,7 +76,7 @@ int cu_count()
 
 extern "C" {
 
-int ahv_abi_version(void) { return (2 << 16) | 1; }
+int ahv_abi_version(void) { return (2 << 16) | 2; }
 
 const char* ahv_last_error(void) { return g_err; }
 

@@ -438,6 +438,12 @@ __device__ __forceinline__ void score_hypotheses_body(
 #else
         const bool exact = nf_w || (unsigned)__builtin_amdgcn_readfirstlane((int)lds_nf.src_gen) == gen;
 #endif
+        if constexpr (SPLIT) {
+            if (nf_w) {  // non-finite WEIGHTS: the exact path reads them unscaled, so the volume must be unscaled too
+                restage_src_volume_unscaled(lds_src, vol_src + (long)b * (16 * 512), wave * 64 + opaque(lane));
+                __syncthreads();
+            }
+        }
         bool tg_ready = !TGT;
         if constexpr (TGT) {
             // forward_3d2d(vol_tgt[b]) (test_co3d.py:141, modules/modules.py:112-124) by team 1, one quarter per wave, while

@@ -111,6 +111,19 @@ __device__ __forceinline__ int stage_src_volume_scaled(float* srcT, const float*
     return e;
 }
 
+// The exact path (ahv_exact.h) multiplies the source image by the UNSCALED head weights from global memory and never
+// undoes the prescales: when it is the WEIGHTS that are non-finite while the volume is finite, the image above holds the
+// volume times 2^e and the pre-activations that stay finite (W1 = -inf against positive voxels: -inf, ReLU'd to 0) come
+// out against a bias that is 2^e too small.  Such a sample is staged again as it is (rare path, uniform branch).
+__device__ __forceinline__ void restage_src_volume_unscaled(float* srcT, const float* __restrict__ vol, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid + 512 * k, c = i >> 9, v = i & 511;
+        srcT[((v >> 6) * kSrcPlaneRows + ((v >> 3) & 7) * kSrcRowsY + (v & 7)) * kSrcStride + c] = vol[i];
+    }
+}
+
 // ---- rotated quarter image ---------------------------------------------------------------
 // Two planes of 4 KB per wave: the hi halves and, 4 096 bytes on, the lo halves.  Inside a plane voxel (a0, b, e) of the
 // quarter owns the 32-byte row a0 + 2e + 16b = [c0-7 | c8-15]; the 16-byte slot of a chunk inside its 256-byte LDS line

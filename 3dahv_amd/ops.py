@@ -495,8 +495,16 @@ class CoarseToFineState:
         self.sync = torch.zeros((2 * B + 1,), dtype=torch.int32, device=dev)
 
     def gave_up(self) -> bool:
-        """True if a workgroup of some step abandoned the meeting point (host sync; the flag is sticky)."""
+        """True if a workgroup of some step abandoned the meeting point (host sync).  The flag is STICKY: the kernel never
+        clears it, and every later step on this state poisons its outputs (NaN / -1) too until ``clear_error()``."""
         return bool(self.sync[-1].item() != 0)
+
+    def clear_error(self) -> None:
+        """Make the state usable again after a give-up: keys back to empty, the meeting point's counters to zero (a step
+        that gave up may have left them mid-count) and the error word cleared -- on the current stream, after every launch
+        that used the state."""
+        self.keys.fill_(_lib.AHV_KEY_EMPTY)
+        self.sync.zero_()
 
 
 def coarse_to_fine(vol_src: torch.Tensor, vol_tgt: torch.Tensor, R: torch.Tensor, D: torch.Tensor, W1: torch.Tensor,

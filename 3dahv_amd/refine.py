@@ -45,11 +45,13 @@ class CoarseToFine:
     hence opt-in.
     Scores do not depend on how the hypothesis sets are split over ranks, bit for bit (a team's score is a lone wave's);
     ``no_teams`` is the scheduling knob of ``ops.score_hypotheses``.  ``check()`` (host sync) raises if a one-launch step
-    had to give its meeting point up -- such a step's outputs are poisoned (NaN, -1), never plausible."""
+    had to give its meeting point up -- such a step's outputs are poisoned (NaN, -1), never plausible.
+    ``use_graph``: None = captured when the step carries collectives, eager otherwise (see __init__); ``run_many`` replays
+    several steps from one graph."""
 
     def __init__(self, W1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, R_coarse: torch.Tensor,
                  D: Optional[torch.Tensor] = None, n_fine: int = 1000, max_angle_deg: float = 10.0,
-                 batch: int = 1, use_graph: bool = True, group=None, seed: int = 0, backend=None,
+                 batch: int = 1, use_graph: Optional[bool] = None, group=None, seed: int = 0, backend=None,
                  want_scores: bool = False, force_collectives: bool = False, no_teams: bool = False,
                  fused: Optional[bool] = None):
         dev = R_coarse.device
@@ -72,6 +74,13 @@ class CoarseToFine:
         self.c_lo, self.c_hi = shard_range(self.R_coarse.shape[0], self.rank, self.world)
         self.f_lo, self.f_hi = shard_range(self.D.shape[0], self.rank, self.world)
         capturable = (not self.collectives) or (inited and dist.get_backend(group) == "nccl")
+        # Default (use_graph=None), from the kernel-trace timelines of profiles/r06_graph_timeline.txt: a hipGraphLaunch idles
+        # the device ~9 us between two replays, plain launches none -- so WITHOUT collectives a single step is issued eagerly
+        # (200.9 against 207.9 us; run_many captures several steps per graph and replays at 199.9); WITH collectives the
+        # eager step idles ~20 us inside itself (the event packets around each all-reduce) and the graph wins (207.8
+        # against 220.0 us), so a multi-rank step is captured whenever the backend can be (RCCL).
+        if use_graph is None:
+            use_graph = self.collectives
         self.use_graph = bool(use_graph and dev.type == "cuda" and capturable)
         # the two keys live with the object: every step's select hands them back empty
         self._keys = [torch.full((batch,), KEY_EMPTY, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -137,8 +146,15 @@ class CoarseToFine:
         step's outputs (NaN scores, index -1, NaN rotation), so the failure cannot be mistaken for a result; this names it."""
         if self.fused and self._fused_state.gave_up():
             raise RuntimeError("ahv_coarse_to_fine_f32: a workgroup gave up the meeting point (the device was shared with "
-                               "another kernel for ~1 s); this step's outputs are poisoned (NaN / -1). Use fused=False when "
-                               "other work runs on the GPU.")
+                               "another kernel for ~1 s); the outputs of that step AND of every step since are poisoned "
+                               "(NaN / -1): the error word is sticky. Call clear_error() to use this object again, or use "
+                               "fused=False when other work runs on the GPU.")
+
+    def clear_error(self):
+        """After a give-up (``check()`` raised): reset the one-launch step's state -- keys, meeting-point counters, the sticky
+        error word -- so that the next step runs clean."""
+        if self._fused_state is not None:
+            self._fused_state.clear_error()
 
     def _reset_keys(self):
         """After an exception inside a step the persistent keys may hold half a step's winners: hand them back empty."""

@@ -50,6 +50,9 @@ def nonfinite_cases(g128):
     g = load_golden("nonfinite")
     for k, name in enumerate(g["names"]):
         inp = {key: np.array(g128[key]) for key in ("vol_src", "vol_tgt", "W1", "W2", "b2")}
+        if "abs_src" in g.files and bool(g["abs_src"][k]):   # strictly positive volumes (gen_nonfinite)
+            for key in ("vol_src", "vol_tgt"):
+                inp[key] = (np.abs(inp[key]) + np.float32(0.1)).astype(np.float32)
         which = {"src": "vol_src", "tgt": "vol_tgt"}.get(str(g["tensor"][k]), str(g["tensor"][k]))
         idx = tuple(int(i) for i in g["index"][k] if i >= 0)
         inp[which].view(np.uint32)[idx] = g["bits"][k]

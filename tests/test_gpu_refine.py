@@ -121,6 +121,16 @@ def test_one_launch_step_that_gave_up_is_poisoned_and_named(ahv, setup):
     assert (idx == -1).all() and (c_idx == -1).all()
     with pytest.raises(RuntimeError, match="gave up the meeting point"):
         c2f.check()
+    # the word is sticky -- the NEXT step is poisoned as well, until clear_error() resets the state
+    again = c2f(vs3[:2].contiguous(), vt3[:2].contiguous())
+    assert torch.isnan(again[0]).all()
+    with pytest.raises(RuntimeError, match="sticky"):
+        c2f.check()
+    c2f.clear_error()
+    clean = c2f(vs3[:2].contiguous(), vt3[:2].contiguous())
+    c2f.check()
+    for a, b in zip(clean, good):
+        assert torch.equal(a, b)
 
 
 def test_one_launch_step_through_CoarseToFine_eager_and_from_a_graph(ahv, setup):

@@ -332,7 +332,7 @@ def test_non_finite_inputs_match_the_reference(ops, oracle, ahv, G, g128, dev, s
             assert int(ops.unpack_best(key)[1][0].item()) == ref_idx, name
 
     cases = list(nonfinite_cases(g128))
-    assert len(cases) == 10
+    assert len(cases) == 11
     for name, inp, Rn, ref, ref_idx in cases:
         d = {k: to_dev(v, dev) for k, v in inp.items()}
         R = to_dev(Rn, dev)

@@ -131,7 +131,7 @@ def test_nonfinite_inputs_match_the_reference(oracle, g128):
             assert np.max(np.abs(scores[fin] - ref[fin]) / np.abs(ref[fin]).clip(1e-2)) < 1e-4, name
         assert idx[0] == ref_idx, name
         n_cases += 1
-    assert n_cases == 10
+    assert n_cases == 11
 
 
 def infonce_from_torch_ref(g, tag, dtype=torch.float32):

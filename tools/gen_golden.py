@@ -192,7 +192,11 @@ NONFINITE_CASES = (
     ("tgt_ninf", "tgt", (0, 7, 0, 0, 0), 0xFF800000),
     ("w1_ninf", "W1", (3, 17), 0xFF800000),
     ("b2_negnan", "b2", (5,), 0xFFC00000),
+    # round 6: W1 = -inf against strictly POSITIVE volumes (|v| + 0.1, source and target): wherever no sample point leaves
+    # the volume the pre-activation is -inf, ReLU'd to 0, and the reference's score stays FINITE
+    ("w1_ninf_posvol", "W1", (3, 17), 0xFF800000),
 )
+ABS_SRC_CASES = ("w1_ninf_posvol",)
 
 
 def nonfinite_rotations():
@@ -213,11 +217,14 @@ def gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt):
     out = {"R": R.numpy(), "names": np.array([c[0] for c in NONFINITE_CASES]),
            "tensor": np.array([c[1] for c in NONFINITE_CASES]),
            "index": np.array([list(c[2]) + [-1] * (5 - len(c[2])) for c in NONFINITE_CASES], dtype=np.int64),
-           "bits": np.array([c[3] for c in NONFINITE_CASES], dtype=np.uint32)}
+           "bits": np.array([c[3] for c in NONFINITE_CASES], dtype=np.uint32),
+           "abs_src": np.array([c[0] in ABS_SRC_CASES for c in NONFINITE_CASES])}
     scores, best, best_idx = [], [], []
     for name, which, idx, bits in NONFINITE_CASES:
         val = np.array([bits], dtype=np.uint32).view(np.float32)[0]
         vs, vt, f = vol_src.clone(), vol_tgt.clone(), copy.deepcopy(fa)
+        if name in ABS_SRC_CASES:   # both volumes: the target's features go through the same W1
+            vs, vt = vs.abs() + 0.1, vt.abs() + 0.1
         with torch.no_grad():
             if which == "src":
                 vs.numpy()[idx] = val
@@ -231,8 +238,9 @@ def gen_nonfinite(rotate_volume, fa, vol_src, vol_tgt):
         scores.append(sim.numpy())
         best.append(b.numpy())
         best_idx.append(i.numpy())
-        print("G10 %-12s NaN scores %3d / %d, inf %d, best %s idx %d" % (
-            name, int(torch.isnan(sim).sum()), sim.numel(), int(torch.isinf(sim).sum()), b.item(), i.item()))
+        print("G10 %-14s NaN scores %3d / %d, inf %d, finite %d, best %s idx %d" % (
+            name, int(torch.isnan(sim).sum()), sim.numel(), int(torch.isinf(sim).sum()), int(torch.isfinite(sim).sum()),
+            b.item(), i.item()))
     out.update(scores=np.stack(scores), best=np.stack(best), best_idx=np.stack(best_idx))
     np.savez(os.path.join(OUT, "nonfinite.npz"), **out)
 
