@@ -61,7 +61,51 @@ struct LinArgs {
 #endif
 };
 
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+// GELU(g) = g/2 (1 + erf(g / sqrt 2)), exact-erf form (nn.GELU() default, attention.py:81-88), for a PAIR of values on the
+// packed fp32 pipe.  libdevice's erff is a branch between two polynomials (35 vector instructions per value behind
+// s_cbranch_execz: a 128 x 128 GEGLU tile spends as long in it as in 300 MFMAs, and fp32 MFMAs do not overlap VALU work on
+// gfx950); here both ranges of N. Juffa's single-precision erf (< 1 ulp each: |x| <= 0.9277 an odd polynomial, beyond it
+// 1 - exp(p(|x|)) with a two-term log2(e) so that v_exp_f32 sees an exact argument) are evaluated for both values with
+// v_pk_fma_f32 and selected: 18 instructions per value, no branch.  Differs from erff by <= 2 ulp (G7 measures 2e-6 either way).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define AHV_PK(c) (f32x2{c, c})
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f32x2 erf_pk(f32x2 a)
+{
+    const f32x2 t = __builtin_elementwise_abs(a);
+    const f32x2 s = a * a;
+    f32x2 r = pk_fma(AHV_PK(-1.72853470e-5f), t, AHV_PK(3.83197126e-4f));
+    const f32x2 u = pk_fma(AHV_PK(-3.88396438e-3f), t, AHV_PK(2.42546219e-2f));
+    r = pk_fma(r, s, u);
+    r = pk_fma(r, t, AHV_PK(-1.06777877e-1f));
+    r = pk_fma(r, t, AHV_PK(-6.34846687e-1f));
+    r = pk_fma(r, t, AHV_PK(-1.28717512e-1f));
+    r = pk_fma(r, t, -t);
+    const f32x2 ph = r * AHV_PK(1.44269502e+0f);                                              // r log2(e), head
+    const f32x2 pl = pk_fma(r, AHV_PK(1.44269502e+0f), -ph) + r * AHV_PK(1.92596299e-8f);     // ... and tail
+    f32x2 e = {__builtin_amdgcn_exp2f(ph[0]), __builtin_amdgcn_exp2f(ph[1])};
+    e = pk_fma(e, pl * AHV_PK(0.693147181f), e);
+    const f32x2 big = AHV_PK(1.0f) - e;
+    f32x2 q = AHV_PK(-5.96761703e-4f);
+    q = pk_fma(q, s, AHV_PK(4.99119423e-3f));
+    q = pk_fma(q, s, AHV_PK(-2.67681349e-2f));
+    q = pk_fma(q, s, AHV_PK(1.12819925e-1f));
+    q = pk_fma(q, s, AHV_PK(-3.76125336e-1f));
+    q = pk_fma(q, s, AHV_PK(1.28379166e-1f));
+    q = pk_fma(q, a, a);
+    f32x2 out;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) out[k] = t[k] > 0.927734375f ? __builtin_copysignf(big[k], a[k]) : q[k];
+    return out;
+}
+
+// (v0, v1) * GELU(g0, g1)
+__device__ __forceinline__ f32x2 geglu_pk(f32x2 v, f32x2 g)
+{
+    const f32x2 half = g * AHV_PK(0.5f);
+    return v * pk_fma(half, erf_pk(g * AHV_PK(0.70710678118654752f)), half);
+}
 
 __device__ __forceinline__ float wave_sum(float x)
 {
@@ -176,7 +220,7 @@ __global__ __launch_bounds__(512) void linear_kernel(const LinArgs a)
                 v += red[(wv * 64 + r) * 32 + c];
                 gt += red[(wv * 64 + r) * 32 + 16 + c];
             }
-            out[(long)r * a.geglu_h + c] = v * gelu_erf(gt);
+            out[(long)r * a.geglu_h + c] = geglu_pk(f32x2{v, 0.0f}, f32x2{gt, 0.0f})[0];
         }
     } else {
         float* out = pr.P + ((long)ks * a.M + m0) * pr.N + n0;
@@ -330,7 +374,11 @@ __global__ __launch_bounds__(512) void linear_staged_kernel(const LinArgs a)
         if (GEGLU_OUT) {
             float* out = pr.P + (long)(m0 + 16 * rt + 4 * kq) * a.geglu_h + n0 + r16;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long)r * a.geglu_h] = (acc[r] + gbias_v) * gelu_erf(other[r] + gbias_g);
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 y = geglu_pk(f32x2{acc[r] + gbias_v, acc[r + 1] + gbias_v}, f32x2{other[r] + gbias_g, other[r + 1] + gbias_g});
+                out[(long)r * a.geglu_h] = y[0];
+                out[(long)(r + 1) * a.geglu_h] = y[1];
+            }
         } else if (NT == 1) {
             float* out = pr.P + ((long)ks * a.M + m0 + 16 * rt + 4 * kq) * pr.N + n0 + r16;
             const float bias = pr.bias ? pr.bias[n0 + r16] : 0.0f;  // a 1x1 conv's bias (single K slice only: host)
@@ -365,6 +413,7 @@ struct TileArgs {
     int nprob, M, K;      // K = K range of ONE split (blockIdx.z = ks)
     long ldx, ldw;
     int geglu_h;
+    const float* zero;    // CONV: 64 bytes of zeros (what a tap outside the 8 x 8 image reads)
 };
 
 // K pipeline (round 5): four LDS stages filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write --
@@ -391,11 +440,19 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <bool GEGLU, int TM>
+// CONV (TM = 2, round 6): the 3 x 3 convolutions of the 2-D res-block (modules/modules.py:126-164) as an implicit GEMM on
+// this kernel: K = (tap, channel) = 9 x 256, a 64-row tile is exactly one sample's 8 x 8 tokens, and the A row a thread
+// fetches for k-tile kt is its own token shifted by the tap of that k-tile -- or the 64 zero bytes of `a.zero` when the tap
+// leaves the image (zero padding; LDS-DMA cannot mask a lane, it can be pointed somewhere else).  The tap of a k-tile is
+// scalar arithmetic on the loop counter, the select two vector instructions per k-step: no branch in the K loop.  Round 5
+// ran these two launches on the skinny kernel, one tap per K slice: 9 216 workgroups that each re-read a 64 x 256 X tile
+// for 16 output columns, 64.5 us per launch at B = 32 (0.48 of the fp32 matrix peak).
+template <bool GEGLU, int TM, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
 {
     static_assert(TM == 2 || TM == 4, "64 x 64 or 128 x 128 tiles");
     static_assert(!GEGLU || TM == 4, "the GEGLU column pairing is laid out for 128-column tiles");
+    static_assert(!CONV || (TM == 2 && !GEGLU), "the implicit-GEMM convolution walks one sample (64 tokens) per tile");
     constexpr int T = 32 * TM;          // tile rows = tile columns
     constexpr int HALF = T * 16;        // floats of one operand tile [T][16]
     constexpr int STAGE = 2 * HALF;     // [A | B]
@@ -435,12 +492,27 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     const int soff = srow * 16 + 4 * sch;                        // this thread's 16 bytes of a piece (= 4 tid floats)
     const int foffa = (16 * TM * wr + r16) * 16 + 4 * kq;        // fragment rows of this lane (+ 16 rows per i)
     const int foffb = HALF + (16 * TM * wc + r16) * 16 + 4 * kq;
+    // CONV: this thread's token (y, x) inside the sample and the sample's first row
+    const int cty = srow >> 3, ctx = srow & 7;
+    const float* xs = pr.X + (long)m0 * 256 + 4 * sch;
     auto gload = [&](int kt, int st) {  // tile kt -> stage st, 2 NP pieces of 1 KiB per wave
         float* dst = smem + st * STAGE + soff;
+        if constexpr (CONV) {
+            const int kg = (int)blockIdx.z * a.K + 16 * kt;   // uniform: the k-tile's first column in (tap, channel) order
+            const int tap = kg >> 8, ci = kg & 255;
+            const int t3 = (tap * 11) >> 5;                   // tap / 3 for tap < 9
+            const int dy = t3 - 1, dx = tap - 3 * t3 - 1;
+            const int ny = cty + dy, nx = ctx + dx;
+            const bool inside = (unsigned)(ny | nx) < 8u;     // a negative coordinate sets the sign bit of the OR
+            const float* src = inside ? xs + ((ny * 8 + nx) * 256 + ci) : a.zero + 4 * sch;
+            glds16(src, dst);
+            glds16(wg[0] + 16 * kt, dst + HALF);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            glds16(xg[i] + 16 * kt, dst + 1024 * i);
-            glds16(wg[i] + 16 * kt, dst + HALF + 1024 * i);
+            for (int i = 0; i < NP; ++i) {
+                glds16(xg[i] + 16 * kt, dst + 1024 * i);
+                glds16(wg[i] + 16 * kt, dst + HALF + 1024 * i);
+            }
         }
     };
     auto fread = [&](TileFrags<TM>& f, int st) {
@@ -518,9 +590,12 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; r += 2) {
                     const long row = m0 + 64 * wr + 16 * i + 4 * kq + r;
-                    pr.P[row * H + col] = (acc[i][j][r] + bv) * gelu_erf(acc[i][j + 2][r] + bg);
+                    const f32x2 y = geglu_pk(f32x2{acc[i][j][r] + bv, acc[i][j][r + 1] + bv},
+                                             f32x2{acc[i][j + 2][r] + bg, acc[i][j + 2][r + 1] + bg});
+                    pr.P[row * H + col] = y[0];
+                    pr.P[(row + 1) * H + col] = y[1];
                 }
         }
     } else {
@@ -720,6 +795,7 @@ struct Nchw2TokArgs {
     const float* in[2];  // [B][C][64]
     float* out[2];       // [B*64][C]
     int C, B;
+    float* zero;         // 16 floats the first workgroup clears: the zero row of the implicit-GEMM convolutions
 };
 
 __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const Nchw2TokArgs a)
@@ -728,6 +804,7 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const Nchw2TokArgs 
     const float* in = a.in[blockIdx.z];
     float* out = a.out[blockIdx.z];
     const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    if (a.zero != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 16) a.zero[threadIdx.x] = 0.0f;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int c = i >> 6, m = i & 63;
         tile[c][m] = in[((long)b * a.C + c0 + c) * 64 + m];
@@ -838,7 +915,7 @@ struct LinSpec {
 
 static bool tile64_eligible(const LinSpec* specs, int nprob, int M, int K);
 static hipError_t launch_linear_tile(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
-                                     hipStream_t s, int tile);
+                                     hipStream_t s, int tile, const float* zero = nullptr);
 
 static hipError_t launch_linear(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
                                 hipStream_t s, int mode = 0)
@@ -908,7 +985,7 @@ static bool tile64_eligible(const LinSpec* specs, int nprob, int M, int K)
 }
 
 static hipError_t launch_linear_tile(const LinSpec* specs, int nprob, long ldx, long ldw, int M, int K, int KS, int geglu_h,
-                                     hipStream_t s, int tile)
+                                     hipStream_t s, int tile, const float* zero)
 {
     TileArgs a;
     a.nprob = nprob; a.M = M; a.K = K / KS; a.ldx = ldx; a.ldw = ldw; a.geglu_h = geglu_h;
@@ -918,7 +995,13 @@ static hipError_t launch_linear_tile(const LinSpec* specs, int nprob, long ldx, 
         a.p[i] = LinProb{sp.X, sp.W, sp.P, sp.bias, sp.N, tiles};
         if (i < nprob) tiles += geglu_h > 0 ? geglu_h / 64 : sp.N / tile;
     }
+    a.zero = zero;
     const dim3 grid(tiles, M / tile, geglu_h > 0 ? 1 : KS);
+    if (zero != nullptr) {  // the 3 x 3 convolution as an implicit GEMM (K = 9 x 256)
+        if (tile != 64 || geglu_h > 0 || K != 2304 || ldx != 256) return hipErrorInvalidValue;
+        AHV_ENC_LAUNCH((linear_tile_kernel<false, 2, true>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (geglu_h > 0 && tile == 128) AHV_ENC_LAUNCH((linear_tile_kernel<true, 4>), grid, dim3(256), 0, s, a);
     else if (geglu_h > 0) return hipErrorInvalidValue;
     else if (tile == 128) AHV_ENC_LAUNCH((linear_tile_kernel<false, 4>), grid, dim3(256), 0, s, a);
@@ -1096,6 +1179,7 @@ static hipError_t launch_finish(const float* const P[2], const float* const bias
     const long n = (long)M * (N / 4);
     const dim3 grid((unsigned)((n + 255) / 256), 2);
     if (KS == 1) AHV_ENC_LAUNCH(finish_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (KS == 2) AHV_ENC_LAUNCH(finish_kernel<2>, grid, dim3(256), 0, s, a);
     else if (KS == 3) AHV_ENC_LAUNCH(finish_kernel<3>, grid, dim3(256), 0, s, a);
     else if (KS == 4) AHV_ENC_LAUNCH(finish_kernel<4>, grid, dim3(256), 0, s, a);
     else if (KS == 9) AHV_ENC_LAUNCH(finish_kernel<9>, grid, dim3(256), 0, s, a);
@@ -1109,12 +1193,16 @@ int forward_2d3d(const ahv_aligner_weights* w, const float* l4_src, const float*
     const int M = 64 * B, MV = 512 * B;
     const EncWs e[2] = {carve_enc(ws, M, 0), carve_enc(ws, M, 1)};
     float* tws = ws + 2 * (size_t)M * kRowFloats;
+    float* zero_row = ws + forward_2d3d_workspace_floats(B) - 64;   // the workspace's last 256 bytes
+    // many rows (B >= 16): the two 3 x 3 convolutions on the tile kernel, K split so that 512 workgroups fill the chip
+    const int conv_ks = (M >= 1024 && (M & 63) == 0) ? (M >= 4096 ? 1 : 4096 / M) : 0;   // 4 (B = 16), 2 (B = 32), 1
     hipError_t err;
 #define AHV_TRY(call, name) do { err = (call); if (err != hipSuccess) { *what = name; return (int)err; } } while (0)
 #define PAIR(T, name, a0, a1) T const name[2] = {a0, a1}
     {   // (B,768,8,8) -> tokens [M][768]
         Nchw2TokArgs a;
         a.in[0] = l4_src; a.in[1] = l4_tgt; a.out[0] = e[0].T0; a.out[1] = e[1].T0; a.C = 768; a.B = B;
+        a.zero = zero_row;
         AHV_ENC_LAUNCH(nchw_to_tokens_kernel, dim3(768 / 64, B, 2), dim3(256), 0, s, a);
         AHV_TRY(hipGetLastError(), "layout");
     }
@@ -1131,12 +1219,15 @@ int forward_2d3d(const ahv_aligner_weights* w, const float* l4_src, const float*
         AHV_TRY(launch_linear(sp, 2, 768, 768, M, 768, 3, 0, s), "embedding conv1x1");
         AHV_TRY(launch_finish(S, nullptr, nullptr, E0, nullptr, 3, M, 256, 256, 0, 0, 0, 256, 0, s), "embedding sum");
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].E0, w->w_conv1, e[i].S, nullptr, 256};
-        AHV_TRY(launch_linear(sp, 2, 256, 2304, M, 2304, 9, 0, s, 1), "res-block conv1");
-        AHV_TRY(launch_finish(S, nullptr, nullptr, H1, nullptr, 9, M, 256, 256, 0, 256, 0, 256, 0, s), "res-block relu");
+        const int cks = conv_ks > 0 ? conv_ks : 9;
+        if (conv_ks > 0) AHV_TRY(launch_linear_tile(sp, 2, 256, 2304, M, 2304, conv_ks, 0, s, 64, zero_row), "res-block conv1 (tiles)");
+        else AHV_TRY(launch_linear(sp, 2, 256, 2304, M, 2304, 9, 0, s, 1), "res-block conv1");
+        AHV_TRY(launch_finish(S, nullptr, nullptr, H1, nullptr, cks, M, 256, 256, 0, 256, 0, 256, 0, s), "res-block relu");
         for (int i = 0; i < 2; ++i) sp[i] = LinSpec{e[i].H1, w->w_conv2, e[i].S, nullptr, 256};
-        AHV_TRY(launch_linear(sp, 2, 256, 2304, M, 2304, 9, 0, s, 1), "res-block conv2");
+        if (conv_ks > 0) AHV_TRY(launch_linear_tile(sp, 2, 256, 2304, M, 2304, conv_ks, 0, s, 64, zero_row), "res-block conv2 (tiles)");
+        else AHV_TRY(launch_linear(sp, 2, 256, 2304, M, 2304, 9, 0, s, 1), "res-block conv2");
         PAIR(const float*, resE0, e[0].E0, e[1].E0);
-        AHV_TRY(launch_finish(S, nullptr, resE0, Xin, w->posemb, 9, M, 256, 256, 0, 0, 256, 256, 0, s), "res-block skip + posemb");
+        AHV_TRY(launch_finish(S, nullptr, resE0, Xin, w->posemb, cks, M, 256, 256, 0, 0, 256, 256, 0, s), "res-block skip + posemb");
     }
     {   // BidirectionTransformer: shared GroupNorm, per-stream proj_in, blocks, per-stream proj_out + residual
         GnArgs g;

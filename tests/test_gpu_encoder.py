@@ -166,8 +166,10 @@ def full(ahv):
     return g, m.cuda()
 
 
-@pytest.mark.parametrize("B", [1, 2, 17, 32])  # 17 = the stored pair tiled (skinny kernels, odd row count); 32 = the tiled
-                                               # kernels (128-tiles for the FF projections, 64-tiles for the 256-wide ones)
+@pytest.mark.parametrize("B", [1, 2, 17, 16, 32, 64])  # 17 = the stored pair tiled (skinny kernels, odd row count); 32 = the
+                                               # tiled kernels (128-tiles for the FF projections, 64-tiles for the 256-wide
+                                               # ones); 16 / 32 / 64 = the 3 x 3 convolutions as implicit GEMMs on 64-tiles
+                                               # with K split 4 / 2 / 1 ways
 def test_hip_forward_2d3d_matches_reference_fixture(full, B):
     """ahv_forward_2d3d_f32 vs the reference's own outputs: <= 1e-4 of the largest entry (measured ~1e-6)."""
     g, m = full

@@ -9,6 +9,24 @@ ahv = importlib.import_module("3dahv_amd")
 ops = ahv.ops
 dev = torch.device("cuda:0")
 FLOPS = 1_839_104
+# Backward of the fused scorer, algorithmic FLOP per hypothesis and kernel:
+#   head  recompute the forward 1 839 104 + dW2 = dv relu(u)^T 2*64*32*32 + dr = W2^T dv 2*64*32*32          = 2 101 248
+#   dW1   gather the rotated volume 131 072 + dW1 += du X^T 2*64*384*32                                      = 1 703 936
+#   dV    dX = W1^T du 2*64*384*32 + adjoint of the gather (scatter) 131 072                                  = 1 703 936
+FLOPS_BWD_KERNELS = {"head": 2_101_248, "dW1": 1_703_936, "dV": 1_703_936}
+FLOPS_BWD = sum(FLOPS_BWD_KERNELS.values())   # 5 509 120
+PEAK = 157.3
+
+
+def bwd_roofline(n_hyp, ms):
+    """The contract's `roofline` object for the three-kernel backward as a whole (fp32 MFMA bound; the only per-hypothesis
+    HBM traffic is dL/du: 8 KB written once, read twice = 24 KB against 5.5 MFLOP)."""
+    ach = n_hyp * FLOPS_BWD / ms / 1e9
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK, "traffic": None,
+            "kernels": "score_backward_head_kernel + score_backward_w1_kernel (+ reduce) + score_backward_volume_kernel",
+            "algorithmic_flops_per_hypothesis": FLOPS_BWD, "algorithmic_flops_per_kernel": FLOPS_BWD_KERNELS,
+            "algorithmic_hbm_bytes_per_hypothesis": 3 * 8192 + 36 + 4,
+            "note": "includes the head kernel's recompute of the forward (1 839 104 FLOP): nothing of the forward is kept in HBM"}
 
 
 def timeit(fn, iters, warm=3, warm_ms=80.0):
@@ -254,7 +272,8 @@ if not only or "train" in only:
     rel = max(((x - y).abs().max() / y.abs().max()).item() for x, y in zip(ga, gb))
     print(json.dumps({"config": "training scorer step", "B": B, "N": N, "hip_fwd_bwd_ms": ms_hip, "hip_fwd_only_ms": ms_fwd,
                       "hip_bwd_only_ms": ms_bwd, "torch_autograd_ms": ms_torch, "speedup": ms_torch / ms_hip,
-                      "max_rel_grad_diff_vs_torch_fp32": rel, "hyp_per_s_fwd_bwd": B * N / ms_hip * 1e3}))
+                      "max_rel_grad_diff_vs_torch_fp32": rel, "hyp_per_s_fwd_bwd": B * N / ms_hip * 1e3,
+                      "roofline": bwd_roofline(B * N, ms_bwd)}))
 
 if "train9000" in only:
     # the reference's CO3D training size (train_estimator_co3d.py:12-15: NUM_ROTA = 9000, BS = 32): 288 000 hypothesis
@@ -270,11 +289,10 @@ if "train9000" in only:
     lib = ahv._lib.load()
     ms_fwd = timeit(lambda: ops.score_hypotheses(vs9, ft9, R9, W1, W2, b2), 5)
     ms_bwd = timeit(lambda: ops.score_hypotheses_backward(vs9, ft9, R9, W1, W2, b2, gs9), 5)
-    FLOPS_BWD = 5.4e6  # algorithmic work of the backward per hypothesis
     print(json.dumps({"config": "training scorer step, CO3D training size", "B": B, "N": N, "hip_fwd_only_ms": ms_fwd,
                       "hip_bwd_only_ms": ms_bwd, "hyp_per_s_fwd_bwd": B * N / (ms_fwd + ms_bwd) * 1e3,
                       "fwd_frac_fp32_mfma_peak": B * N * FLOPS / ms_fwd / 1e9 / 157.3,
-                      "bwd_tflops": B * N * FLOPS_BWD / ms_bwd / 1e9,
+                      "bwd_tflops": B * N * FLOPS_BWD / ms_bwd / 1e9, "roofline": bwd_roofline(B * N, ms_bwd),
                       "backward_workspace_GB": lib.ahv_score_hypotheses_backward_workspace_bytes(B, N) / 1e9}))
 
 if not only or "trainstep" in only:
