@@ -945,6 +945,389 @@ __global__ __launch_bounds__(kVolThreads, 2) void score_backward_volume_kernel(
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Kernel 2b, round 6: the same dV = sum_h trilinear_h^T (W1^T du_h), WITHOUT LDS atomics.
+//
+// What bounded score_backward_volume_kernel above (profiles/r06_training_pmc_summary.json, B = 32 x N = 9 000: 8.4 ms, 0.37 of
+// the fp32 matrix peak) is its scatter: 1 024 ds_add_u64 wave-instructions per hypothesis on a pipe the four SIMDs share, and
+// three vector instructions per atomic (scale, round to integer, sign-extend) that fp32 MFMAs cannot overlap -- 5 679 vector
+// instructions per hypothesis against 768 MFMAs.  A plain read-modify-write moves the same bytes with ONE packed FMA per two
+// channels, but it is only correct if no two lanes of an instruction (and no two waves) touch the same word.  Both can be
+// arranged:
+//   * between waves: a workgroup runs TWO hypotheses at a time (slots), each with a PRIVATE fp32 image of dV; the four waves
+//     of a slot (one per SIMD) own four channels each, so they share the hypothesis' corner table and never an address.  (Four
+//     private images -- one per hypothesis in flight, as kernel 2b has them in flight -- do not fit the 160 KB of LDS beside
+//     the dX images; hence four waves per hypothesis, split by channel.)
+//   * inside an instruction: lanes = 8 voxels x 8 corners, each lane the four channels of its wave (16 bytes).  The 8 corners of
+//     a voxel are 8 different rows; the 8 voxels are 4 apart in z, y and x, and for a rotation two lattice points 4 apart land
+//     >= 4 / sqrt(3) > 2 apart along some axis, so their 2 x 2 x 2 footprints are disjoint.  A matrix that is not a rotation
+//     (|R^T R - I| > 0.04 anywhere; the ABI accepts any R) takes the same code one voxel at a time.
+//   * the forward's clamped footprint (base row in [0, 6], hat weights) gives corners outside the volume a weight of exactly
+//     0 on a row that may belong to another lane's voxel: such a corner is redirected to a trash row when the corner table is
+//     built (its byte offset is part of the table), so a zero weight never writes a live word back.
+// Sums are fp32 in the order the hypotheses arrive (the fixed-point image of kernel 2b was exact and order-free): the
+// gradients agree with the fp64 reference to ~1e-6 of their largest entry, like those of the other kernels.
+// Per hypothesis and wave: 192 MFMAs (x / y slabs: 2 row tiles of (channel, k); z slab: ONE row tile of (depth, channel) over
+// the four depths of a half volume -- quarters {H, H + 2} -- so that no MFMA row is wasted on four channels), 64 scatter
+// steps of (16-byte image read, two packed FMAs, 16-byte image write) with the step's operands (dX of the voxel, weight and
+// row offset of the corner) requested two steps ahead.  Every LDS layout below is chosen so that the lanes of an access spread
+// over the banks (SQ_LDS_BANK_CONFLICT went 12.7 k -> 2.9 k cycles per hypothesis on the way, tools/profile_kbench_bwd.sh).
+// Measured (tools/kbench_bwd 32 9000): 7.6 ms against 8.4 ms; 2 736 vector and 1 606 LDS instructions per hypothesis (5 679 /
+// 1 840).  What bounds it now is the LDS itself -- 10.0 k busy cycles per hypothesis of the 14.3 k the workgroup spends on
+// it -- and the latency of the ONE read-modify-write chain a wave can have in flight (in-kernel stamps, -DAHV_RMW_STAMPS:
+// 220-290 cycles per step; dX 5.0 k cycles per half for 3.1 k cycles of MFMAs).
+// -------------------------------------------------------------------------------------------------
+constexpr int kRmwThreads = 512;                  // 8 waves = 2 slots x 4 members, member m on SIMD m
+// Private image of dV: channel-last, 16 words per voxel; a y row of 8 voxels is padded by 4 words and a depth plane by 8, so
+// that the 8 rows of a footprint start at words {0, 16, 132, 148} (+ 1064 for z + 1) = banks {0, 16, 4, 20} and {8, 24, 12, 28}:
+// a lane updates the FOUR channels of its wave at one corner (16 bytes), and the 8 corners of a voxel cover all 32 banks
+// exactly once -- any 8 voxels of an instruction hit every bank 8 times, the LDS's own rate for 1 KiB.
+constexpr int kImgRowBytes = 64;
+constexpr int kImgYRowBytes = 8 * kImgRowBytes + 16;
+constexpr int kImgPlaneBytes = 8 * kImgYRowBytes + 32;
+constexpr int kImgTrashBytes = 8 * kImgPlaneBytes;      // the row behind the last plane: target of zero-weight corners
+constexpr int kImgWords = (kImgTrashBytes + kImgRowBytes) / 4;
+// dX image of a wave: channel-last, word address = al * kXPlane + b * kXRow + e * 4 + channel.  A y row (8 voxels x 4 channels)
+// is padded to 34 words and a plane to 274: the x / y slab updates walk b (or e) across the lanes of an MFMA tile, and with
+// the unpadded strides (32 and 288 words, both multiples of the 32 banks) all 64 lanes of such an access met in 4 banks --
+// SQ_LDS_BANK_CONFLICT 12.7 k of 20.5 k LDS cycles per hypothesis in the first version of this kernel.
+constexpr int kXRow = 34;                 // (2 mod 8, and the plane 2 mod 16: the eight voxels of a scatter step -- 4 apart in b, e and
+constexpr int kXPlane = 8 * kXRow + 2;    //  depth -- then read eight different 4-bank groups; rows are 8-byte aligned only, so 16 bytes
+constexpr int kXbufWords = 4 * kXPlane;   //  travel as two halves)
+constexpr int kCt2Row = 12;                       // corner table: 8 weights, 8 x u16 byte offsets per voxel ...
+constexpr int kCt2BRow = 8 * kCt2Row + 2;         // ... 8 voxels (one y row) + 2 words: voxels 4 apart in y then sit 8 banks apart,
+constexpr int kCt2Words = 64 * kCt2BRow;          //     voxels 4 apart in x 16 -- the four voxels of a scatter step never share a bank
+
+struct RmwSync {
+    unsigned ready, done;
+};
+
+__device__ __forceinline__ void rmw_signal(unsigned* ctr, int lane)
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes and reads are complete
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void rmw_wait(unsigned* ctr, unsigned target)
+{
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// |R^T R - I| <= 0.04 entrywise: the eigenvalues of R^T R are then >= 0.88, two lattice points 4 apart map >= 3.75 apart and
+// >= 2.16 apart along some axis -- their footprints cannot share a row.  NaN compares false: not a rotation.
+__device__ __forceinline__ bool rmw_rotation_like(const float* Rm)
+{
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            const float d = fmaf(Rm[i], Rm[j], fmaf(Rm[3 + i], Rm[3 + j], Rm[6 + i] * Rm[6 + j])) - (i == j ? 1.0f : 0.0f);
+            ok = ok && (fabsf(d) <= 0.04f);
+        }
+    return ok;
+}
+
+// Corner table of quarter Q (one voxel per lane and pass, the gather's lane map): per voxel the 8 hat-weight products
+// (index = 4 z + 2 y + x) and the BYTE offsets of the 8 rows in a private image -- the trash row where the weight is 0.
+template <int Q>
+__device__ __forceinline__ void rmw_corners(float* ctab, const GatherHyp& h, const GatherDst& dst)
+{
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float jx, jy, jz, wx0, wx1, wy0, wy1, wz0, wz1;
+        hat_axis(gather_coord<Q>(h, 0, p), jx, wx0, wx1);
+        hat_axis(gather_coord<Q>(h, 1, p), jy, wy0, wy1);
+        hat_axis(gather_coord<Q>(h, 2, p), jz, wz0, wz1);
+        const float w00 = wz0 * wy0, w01 = wz0 * wy1, w10 = wz1 * wy0, w11 = wz1 * wy1;
+        const float w[8] = {w00 * wx0, w00 * wx1, w01 * wx0, w01 * wx1, w10 * wx0, w10 * wx1, w11 * wx0, w11 * wx1};
+        const unsigned base = (unsigned)fmaf(jz, (float)kImgPlaneBytes, fmaf(jy, (float)kImgYRowBytes, jx * (float)kImgRowBytes));
+        unsigned off[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const unsigned o = base + (unsigned)((n & 1) * kImgRowBytes + ((n & 2) ? kImgYRowBytes : 0) + ((n & 4) ? kImgPlaneBytes : 0));
+            off[n] = (w[n] != 0.0f) ? o : (unsigned)kImgTrashBytes;   // (NaN != 0: a NaN weight writes NaN to its own row)
+        }
+        const int vox = Q * 128 + (p ? dst.o1 : dst.o0);
+        float* row = ctab + (vox >> 3) * kCt2BRow + (vox & 7) * kCt2Row;   // 8-byte aligned
+        *reinterpret_cast<f32x2*>(row + 0) = f32x2{w[0], w[1]};
+        *reinterpret_cast<f32x2*>(row + 2) = f32x2{w[2], w[3]};
+        *reinterpret_cast<f32x2*>(row + 4) = f32x2{w[4], w[5]};
+        *reinterpret_cast<f32x2*>(row + 6) = f32x2{w[6], w[7]};
+        *reinterpret_cast<f32x2*>(row + 8) = f32x2{__uint_as_float(off[0] | (off[1] << 16)), __uint_as_float(off[2] | (off[3] << 16))};
+        *reinterpret_cast<f32x2*>(row + 10) = f32x2{__uint_as_float(off[4] | (off[5] << 16)), __uint_as_float(off[6] | (off[7] << 16))};
+    }
+}
+
+// dX of this wave's four channels over half volume H (depth planes a = 2 H + (al & 1) + 4 (al >> 1), al = 0..3) into the
+// channel-last image xbuf[al][b * 8 + e][4]: the z slab first (plain 16-byte stores: a lane's four accumulator rows ARE the
+// four channels of one voxel), then the x and y slabs of the two quarters added on top.
+template <int H>
+__device__ __forceinline__ void rmw_dx_half(const float (&wx)[2][8], const float (&wy)[2][8], const float (&wz)[2][8],
+                                            const DuRegs& du, float* xbuf, int lane)
+{
+    const int n = lane & 15, kq = lane >> 4;
+    {
+        float* zb = xbuf + kq * kXPlane + (n >> 3) * kXRow + (n & 7) * 4;  // voxel (al = kq, b = 2 t + (n >> 3), e = n & 7)
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[H][sp], du.v[t][sp], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[H][sp], du.v[t + 1][sp], d1, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x2*>(zb + 2 * t * kXRow) = f32x2{d0[0], d0[1]};
+            *reinterpret_cast<f32x2*>(zb + 2 * t * kXRow + 2) = f32x2{d0[2], d0[3]};
+            *reinterpret_cast<f32x2*>(zb + 2 * (t + 1) * kXRow) = f32x2{d1[0], d1[1]};
+            *reinterpret_cast<f32x2*>(zb + 2 * (t + 1) * kXRow + 2) = f32x2{d1[2], d1[3]};
+        }
+    }
+    wave_lds_fence();
+    // x and y slabs of the two quarters, added onto the z slab in LDS.  Block order x0, x1, y0, y1 (x / y slab of quarter
+    // H + 2 j): the words a block adds onto are requested a block AHEAD -- 16 MFMAs hide the round trip; read just in front
+    // of their MFMAs they cost the wave ~150 cycles per block on an LDS the scatters keep 70 % busy (in-kernel stamps:
+    // 5.1 k cycles per half for 3.1 k cycles of MFMAs).  y j reads what x j wrote, so its request follows x j's stores.
+    // x: channel 2 kt + (kq >> 1), voxel (al, b = n & 7, e = 4 (kq & 1) + r);  y: voxel (al, b = 4 (kq & 1) + r, e = n & 7)
+    float* const rbx = xbuf + (kq >> 1) + (n >> 3) * kXPlane + (n & 7) * kXRow + 16 * (kq & 1);
+    float* const rby = xbuf + (kq >> 1) + (n >> 3) * kXPlane + 4 * (kq & 1) * kXRow + (n & 7) * 4;
+    auto rd = [&](float (&o0)[4], float (&o1)[4], const float* rb, int rs) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = rb[rs * r];
+            o1[r] = rb[rs * r + 2];
+        }
+    };
+    auto mm = [&](f32x4& d0, f32x4& d1, const float (&w)[2][8], int t) {
+        d0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        d1 = d0;
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][sp], du.v[t][sp], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1][sp], du.v[t][sp], d1, 0, 0, 0);
+        }
+    };
+    auto wr = [&](float* rb, int rs, const float (&o0)[4], const float (&o1)[4], const f32x4& d0, const f32x4& d1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rb[rs * r] = o0[r] + d0[r];
+            rb[rs * r + 2] = o1[r] + d1[r];
+        }
+        wave_lds_fence();   // (compiler-level: later reads of these words, by other lanes, stay behind the stores)
+    };
+    float ax0[4], ax1[4], bx0[4], bx1[4], ay0[4], ay1[4], by0[4], by1[4];
+    f32x4 d0, d1;
+    rd(ax0, ax1, rbx, 4);                          // x0
+    rd(bx0, bx1, rbx + 2 * kXPlane, 4);            // x1
+    mm(d0, d1, wx, H);
+    wr(rbx, 4, ax0, ax1, d0, d1);
+    rd(ay0, ay1, rby, kXRow);                      // y0 (behind x0's stores)
+    mm(d0, d1, wx, H + 2);
+    wr(rbx + 2 * kXPlane, 4, bx0, bx1, d0, d1);
+    rd(by0, by1, rby + 2 * kXPlane, kXRow);        // y1 (behind x1's stores)
+    mm(d0, d1, wy, H);
+    wr(rby, kXRow, ay0, ay1, d0, d1);
+    mm(d0, d1, wy, H + 2);
+    wr(rby + 2 * kXPlane, kXRow, by0, by1, d0, d1);
+}
+
+struct RmwStep {   // what a lane needs for one step: its voxel's dX (4 channels), the weight of its corner, the byte offset of its row
+    f32x2 d01, d23;
+    float w;
+    unsigned o;
+};
+
+template <int H, int S>
+__device__ __forceinline__ void rmw_step_load(RmwStep& st, const float* xl, const float* tw, const unsigned short* to)
+{
+    constexpr int ap = S >> 4, b0 = (S >> 2) & 3, e0 = S & 3;       // step S = (ap, b0, e0)
+    constexpr int t = (ap * 8 + b0) * kCt2BRow + e0 * kCt2Row;
+    constexpr int x = ap * kXPlane + b0 * kXRow + e0 * 4;
+    st.d01 = *reinterpret_cast<const f32x2*>(xl + x);
+    st.d23 = *reinterpret_cast<const f32x2*>(xl + x + 2);
+    st.w = tw[t];
+    st.o = to[t * 2];
+}
+
+template <int H, int S, bool ROT>
+struct RmwSteps {
+    // read-modify-write of step S.  Its operands were requested TWO steps ago (the row address is ready when the step starts);
+    // the operands of step S + 2 are requested behind the image read -- the LDS returns in order, so the image words arrive
+    // first -- and ahead of the write.  One LDS round trip per step is exposed: the image read.
+    static __device__ __forceinline__ void run(const RmwStep& cur, const RmwStep& nxt, const float* xl, const float* tw,
+                                               const unsigned short* to, char* img_ch, int vg)
+    {
+        f32x4* p = reinterpret_cast<f32x4*>(img_ch + cur.o);
+        RmwStep nn;
+        if constexpr (ROT) {
+            const f32x4 c = *p;
+            rmw_step_load<H, (S + 2 < 32 ? S + 2 : 31)>(nn, xl, tw, to);
+            const f32x2 lo = __builtin_elementwise_fma(f32x2{cur.w, cur.w}, cur.d01, f32x2{c[0], c[1]});
+            const f32x2 hi = __builtin_elementwise_fma(f32x2{cur.w, cur.w}, cur.d23, f32x2{c[2], c[3]});
+            *p = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else {   // any other matrix: footprints may overlap -- one voxel per instruction
+            rmw_step_load<H, (S + 2 < 32 ? S + 2 : 31)>(nn, xl, tw, to);
+#pragma unroll 1
+            for (int g = 0; g < 8; ++g) {
+                if (vg == g) {
+                    const f32x4 c = *p;
+                    *p = f32x4{fmaf(cur.w, cur.d01[0], c[0]), fmaf(cur.w, cur.d01[1], c[1]), fmaf(cur.w, cur.d23[0], c[2]),
+                               fmaf(cur.w, cur.d23[1], c[3])};
+                }
+                wave_lds_fence();
+            }
+        }
+        wave_lds_fence();   // the next step's image read stays behind this write (another lane's row may be this lane's next)
+        RmwSteps<H, S + 1, ROT>::run(nxt, nn, xl, tw, to, img_ch, vg);
+    }
+};
+template <int H, bool ROT>
+struct RmwSteps<H, 32, ROT> {
+    static __device__ __forceinline__ void run(const RmwStep&, const RmwStep&, const float*, const float*, const unsigned short*, char*, int) {}
+};
+
+// dV image += trilinear^T dX for half volume H: lane = (plane pair ab, voxel vx of 4, corner c of 8), all four channels of the
+// wave.  A step covers the 8 voxels (depth plane al + 2 ab -- 4 further in z --, b0 + 4 (vx >> 1), e0 + 4 (vx & 1)): 32 steps.
+template <int H>
+__device__ __forceinline__ void rmw_scatter_half(const float* xbuf, const float* ctab, char* img_ch, bool rotation, int lane)
+{
+    const int c = lane & 7, vx = (lane >> 3) & 3, ab = lane >> 5;
+    const float* xl = xbuf + 2 * ab * kXPlane + 4 * (vx >> 1) * kXRow + 16 * (vx & 1);
+    // the lane's voxel of step 0: plane 2 H + 4 ab, y = 4 (vx >> 1), x = 4 (vx & 1)
+    const float* trow = ctab + ((2 * H + 4 * ab) * 8 + 4 * (vx >> 1)) * kCt2BRow + 4 * (vx & 1) * kCt2Row;
+    const float* tw = trow + c;                                    // weight of corner c
+    const unsigned short* to = reinterpret_cast<const unsigned short*>(trow + 8) + c;
+    RmwStep s0, s1;
+    rmw_step_load<H, 0>(s0, xl, tw, to);
+    rmw_step_load<H, 1>(s1, xl, tw, to);
+    if (rotation) RmwSteps<H, 0, true>::run(s0, s1, xl, tw, to, img_ch, lane >> 3);
+    else RmwSteps<H, 0, false>::run(s0, s1, xl, tw, to, img_ch, lane >> 3);
+}
+
+#ifdef AHV_RMW_STAMPS   // diagnostic build (tools/kbench_bwd): shader-clock time per phase, summed per wave
+__device__ unsigned long long g_rmw_stamps[8 * 8];
+#define AHV_RMW_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define AHV_RMW_T(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kRmwThreads, 2) void score_backward_volume_rmw_kernel(
+    const float* __restrict__ R, long r_batch_stride, const float* __restrict__ W1, int B, long N,
+    const float* __restrict__ du_ws, float* __restrict__ grad_vol)
+{
+    __shared__ __attribute__((aligned(16))) float lds_img[2 * kImgWords];        // private fp32 image of dV per slot
+    __shared__ __attribute__((aligned(16))) float lds_x[8 * kXbufWords];         // per wave: dX of its 4 channels, half a volume
+    __shared__ __attribute__((aligned(16))) float lds_ct[2 * kCt2Words];         // per slot: the hypothesis' corner table
+    __shared__ RmwSync lds_sync[2];
+    __shared__ unsigned lds_skew;   // slot 0 has reached its first scatter of this sample
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave >> 2, m = wave & 3;
+    const int kq = lane >> 4, row = lane & 15;
+    float* xbuf = lds_x + wave * kXbufWords;
+    float* ctab = lds_ct + slot * kCt2Words;
+    float* img = lds_img + slot * kImgWords;
+    char* img_ch = reinterpret_cast<char*>(img) + 16 * m;   // this wave's four channels of a voxel row
+    if (tid < 2) lds_sync[tid] = RmwSync{0u, 0u};
+
+    // W1^T fragments of channels 4 m .. 4 m + 3 (A operands; lane (row, kq) holds W1[o = 4 sp + kq][k(row)]):
+    //   x / y: k = 32 m + 16 kt + row (+ 128)            rows = (channel 2 kt + (row >> 3), slab index row & 7)
+    //   z:     k = 256 + (4 m + (row & 3)) * 8 + depth   rows = (plane al = row >> 2, channel row & 3), depth = 2 H + (al & 1) + 4 (al >> 1)
+    float wx[2][8], wy[2][8], wz[2][8];
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) {
+        const float* w = W1 + (4 * sp + kq) * 384;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            wx[kt][sp] = w[32 * m + 16 * kt + row];
+            wy[kt][sp] = w[128 + 32 * m + 16 * kt + row];
+        }
+#pragma unroll
+        for (int H = 0; H < 2; ++H) wz[H][sp] = w[256 + (4 * m + (row & 3)) * 8 + 2 * H + ((row >> 2) & 1) + 4 * (row >> 3)];
+    }
+    const GatherLane glane = gather_lane(lane);
+    const GatherDst gdst = gather_dst_linear(lane);
+
+#ifdef AHV_RMW_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+    const long hstep = (long)gridDim.x * 2;
+    unsigned iter = 0;  // hypotheses this slot has finished (its members count alike)
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        for (int i = tid; i < 2 * kImgWords; i += kRmwThreads) lds_img[i] = 0.0f;
+        if (tid == 0) lds_skew = 0u;
+        __syncthreads();
+        bool first = true;
+        const float* Rb = R + (long)b * r_batch_stride;
+        long h = (long)slot * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        DuRegs du;
+        if (h < N) load_du_regs(du, du_ws + ((long)b * N + h) * 2048, lane);
+        for (; h < N; h += hstep) {
+            float Rm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
+            GatherHyp gh;
+            gather_hyp(gh, Rm, glane);
+            const bool rotation = rmw_rotation_like(Rm);
+            DuRegs nxt;  // the next hypothesis's du travels from HBM / L2 while this one is processed
+            const long hn = (h + hstep < N) ? h + hstep : h;
+            load_du_regs(nxt, du_ws + ((long)b * N + hn) * 2048, lane);
+            // The two slots run in ANTI-PHASE: a scatter is LDS traffic (~3.6 k LDS cycles per half for the slot's four waves), a dX
+            // half is 96 MFMAs per wave (~3.1 k cycles) -- side by side they fill both pipes, in step they take turns idling them
+            // (both slots start a sample at the same barrier and do the same work per hypothesis, so nothing separates them by
+            // itself).  Slot 1 therefore starts a sample when slot 0 starts its first scatter, and the equal periods keep the offset.
+            AHV_RMW_T(0);   // loop head: R, du request
+            if (slot == 1 && first) rmw_wait(&lds_skew, 1u);
+            // the slot's corner table: member m builds quarter m once everybody has finished with the previous table
+            rmw_wait(&lds_sync[slot].done, 4u * iter);
+            AHV_RMW_T(1);   // waiting for the team to finish the previous table
+            if (m == 0) rmw_corners<0>(ctab, gh, gdst);
+            else if (m == 1) rmw_corners<1>(ctab, gh, gdst);
+            else if (m == 2) rmw_corners<2>(ctab, gh, gdst);
+            else rmw_corners<3>(ctab, gh, gdst);
+            rmw_signal(&lds_sync[slot].ready, lane);
+            AHV_RMW_T(2);   // corner table
+            rmw_dx_half<0>(wx, wy, wz, du, xbuf, lane);      // (the first half's MFMAs need no table: they run while the others arrive)
+            AHV_RMW_T(3);   // dX half 0
+            rmw_wait(&lds_sync[slot].ready, 4u * (iter + 1u));
+            if (slot == 0 && first && m == 0 && lane == 0) __hip_atomic_store(&lds_skew, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            first = false;
+            AHV_RMW_T(4);   // waiting for the table
+            AHV_VOL_PRIO(1);   // the scattering wave is latency-bound: it issues first, its SIMD partner streams MFMAs
+            rmw_scatter_half<0>(xbuf, ctab, img_ch, rotation, lane);
+            AHV_VOL_PRIO(0);
+            AHV_RMW_T(5);   // scatter half 0
+            rmw_dx_half<1>(wx, wy, wz, du, xbuf, lane);
+            AHV_RMW_T(6);   // dX half 1
+            AHV_VOL_PRIO(1);
+            rmw_scatter_half<1>(xbuf, ctab, img_ch, rotation, lane);
+            AHV_VOL_PRIO(0);
+            rmw_signal(&lds_sync[slot].done, lane);
+            AHV_RMW_T(7);   // scatter half 1
+            ++iter;
+            du = nxt;
+        }
+        __syncthreads();
+        float* gv = grad_vol + (long)b * (16 * 512);
+        for (int i = tid; i < 16 * 512; i += kRmwThreads) {
+            const int c = i >> 9, v = i & 511;
+            const int w = (v >> 6) * (kImgPlaneBytes / 4) + ((v >> 3) & 7) * (kImgYRowBytes / 4) + (v & 7) * (kImgRowBytes / 4) + c;
+            const float a = lds_img[w] + lds_img[kImgWords + w];
+            if (a != 0.0f) global_add(gv + i, a);   // (NaN != 0: a poisoned sample reports NaN, like autograd)
+        }
+    }
+#ifdef AHV_RMW_STAMPS
+    if (blockIdx.x == 3 && blockIdx.y == 5 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_rmw_stamps[wave * 8 + i] = tsum[i];
+#endif
+}
+
 hipError_t launch_zero_fill(void* const* ptrs, const size_t* bytes, int count, hipStream_t stream);  // ahv_ops.hip
 
 // ---- host-side launcher -------------------------------------------------------------------------------
@@ -978,8 +1361,19 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     hipLaunchKernelGGL(score_backward_w1_reduce_kernel, dim3(32 * 384 / 256, 16), dim3(256), 0, stream, dw1_partials,
                        gx * gy, grad_W1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+#ifdef AHV_BWD_VOLUME_ATOMICS  // rounds 2-5: the scatter as 64-bit fixed-point LDS atomics (kept for A/B builds: tools/kbench_bwd)
     hipLaunchKernelGGL(score_backward_volume_kernel, grid, dim3(kVolThreads), 0, stream, R, (long)r_batch_stride, W1,
                        B, (long)N, du_ws, du_max_bits, grad_vol);
+#else
+    {   // two hypotheses per workgroup at a time: spread a short list over more workgroups
+        int gxv = num_cu / gy;
+        const int64_t need2 = (N + 1) / 2;
+        if (gxv > need2) gxv = (int)need2;
+        if (gxv < 1) gxv = 1;
+        hipLaunchKernelGGL(score_backward_volume_rmw_kernel, dim3(gxv, gy), dim3(kRmwThreads), 0, stream, R, (long)r_batch_stride,
+                           W1, B, (long)N, du_ws, grad_vol);
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -23,11 +23,20 @@
 // cut a forward after k launches -- the marginal cost of every launch with no profiler attached -- and collect an
 // in-kernel timeline of the linear kernels (8 realtime stamps, 100 MHz, per workgroup).
 #ifdef AHV_ENC_PROBE
+#include <string.h>
 static int g_enc_probe_budget = 1 << 30;
 static int g_enc_probe_count = 0;
 static const char* g_enc_probe_names[256];
 static unsigned long long* g_enc_probe_stamps = nullptr;
-#define AHV_ENC_LAUNCH(k, ...) do { if (g_enc_probe_budget-- > 0) { g_enc_probe_names[g_enc_probe_count++ & 255] = #k; hipLaunchKernelGGL(k, __VA_ARGS__); } } while (0)
+// g_enc_probe_dup: every launch that reads weights (the linears and the attention + output projection, all pure functions
+// of their inputs) is issued TWICE: the second one finds its weights in the L2 of the XCDs that need them -- its marginal
+// cost is what a perfect weight prefetch could make of the first (tools/kbench_enc.cpp --each --dup)
+static int g_enc_probe_dup = 0;
+#define AHV_ENC_LAUNCH(k, ...) do { \
+    const int reps_ = (g_enc_probe_dup && (strstr(#k, "linear") || strstr(#k, "attention"))) ? 2 : 1; \
+    for (int r_ = 0; r_ < reps_; ++r_) \
+        if (g_enc_probe_budget-- > 0) { g_enc_probe_names[g_enc_probe_count++ & 255] = r_ ? #k " [again: weights hot]" : #k; hipLaunchKernelGGL(k, __VA_ARGS__); } \
+    } while (0)
 #define AHV_ENC_STAMP_PTR (g_enc_probe_stamps ? g_enc_probe_stamps + (size_t)(g_enc_probe_count & 255) * 8192 : nullptr)
 #define AHV_ENC_STAMP(slot) do { if (a.stamps && threadIdx.x == 0) { \
     a.stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)

@@ -23,7 +23,7 @@ def bwd_roofline(n_hyp, ms):
     HBM traffic is dL/du: 8 KB written once, read twice = 24 KB against 5.5 MFLOP)."""
     ach = n_hyp * FLOPS_BWD / ms / 1e9
     return {"bound": "mfma", "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK, "traffic": None,
-            "kernels": "score_backward_head_kernel + score_backward_w1_kernel (+ reduce) + score_backward_volume_kernel",
+            "kernels": "score_backward_head_kernel + score_backward_w1_kernel (+ reduce) + score_backward_volume_rmw_kernel",
             "algorithmic_flops_per_hypothesis": FLOPS_BWD, "algorithmic_flops_per_kernel": FLOPS_BWD_KERNELS,
             "algorithmic_hbm_bytes_per_hypothesis": 3 * 8192 + 36 + 4,
             "note": "includes the head kernel's recompute of the forward (1 839 104 FLOP): nothing of the forward is kept in HBM"}

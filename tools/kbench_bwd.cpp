@@ -4,6 +4,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I3dahv_amd/csrc -Iinclude tools/kbench_bwd.cpp -o tools/kbench_bwd
 #include "../3dahv_amd/csrc/ahv_backward.hip"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -36,12 +38,12 @@ int main(int argc, char** argv)
                              t * (j * k - i * r), t * (i * k - j * r), t * (j * k + i * r), 1 - t * (i * i + j * j)};
         for (int e = 0; e < 9; ++e) R[n * 9 + e] = (float)m[e];
     }
-    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dgs, *dws, *gvol, *gft, *gW1, *gW2, *gb2, *dpart;
+    float *dvol, *dft, *dR, *dW1, *dW2, *db2, *dgs, *dws, *gvol, *gvol2, *gft, *gW1, *gW2, *gb2, *dpart;
     unsigned* dmax;
     CK(hipMalloc(&dvol, vol.size() * 4)); CK(hipMalloc(&dft, ft.size() * 4)); CK(hipMalloc(&dR, R.size() * 4));
     CK(hipMalloc(&dW1, W1.size() * 4)); CK(hipMalloc(&dW2, W2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4));
     CK(hipMalloc(&dgs, gs.size() * 4)); CK(hipMalloc(&dws, (size_t)B * N * 2048 * 4)); CK(hipMalloc(&dmax, B * 4));
-    CK(hipMalloc(&dpart, (size_t)1024 * 32 * 384 * 4)); CK(hipMalloc(&gvol, vol.size() * 4)); CK(hipMalloc(&gft, ft.size() * 4)); CK(hipMalloc(&gW1, W1.size() * 4));
+    CK(hipMalloc(&dpart, (size_t)1024 * 32 * 384 * 4)); CK(hipMalloc(&gvol, vol.size() * 4)); CK(hipMalloc(&gvol2, vol.size() * 4)); CK(hipMalloc(&gft, ft.size() * 4)); CK(hipMalloc(&gW1, W1.size() * 4));
     CK(hipMalloc(&gW2, W2.size() * 4)); CK(hipMalloc(&gb2, b2.size() * 4));
     CK(hipMemcpy(dvol, vol.data(), vol.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dft, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW1, W1.data(), W1.size() * 4, hipMemcpyHostToDevice));
@@ -51,9 +53,9 @@ int main(int argc, char** argv)
     CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0));
     int gy = B < cu ? B : cu, gx = cu / gy;
     const dim3 grid(gx, gy);
-    hipEvent_t e[4];
+    hipEvent_t e[6];
     for (auto& x : e) CK(hipEventCreate(&x));
-    double t[3] = {0, 0, 0};
+    double t[4] = {0, 0, 0, 0};
     for (int it = -2; it < iters; ++it) {
         CK(hipMemsetAsync(gvol, 0, vol.size() * 4, 0)); CK(hipMemsetAsync(gft, 0, ft.size() * 4, 0));
         CK(hipMemsetAsync(gW1, 0, W1.size() * 4, 0)); CK(hipMemsetAsync(gW2, 0, 4096, 0)); CK(hipMemsetAsync(gb2, 0, 128, 0));
@@ -67,14 +69,41 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e[2], 0));
         hipLaunchKernelGGL(ahv::score_backward_volume_kernel, grid, dim3(ahv::kVolThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, dmax, gvol);
         CK(hipEventRecord(e[3], 0));
-        CK(hipEventSynchronize(e[3]));
+        // round 6: the same gradient without LDS atomics (private fp32 images, read-modify-write), into its own buffer
+        CK(hipMemsetAsync(gvol2, 0, vol.size() * 4, 0));
+        CK(hipEventRecord(e[4], 0));
+        hipLaunchKernelGGL(ahv::score_backward_volume_rmw_kernel, grid, dim3(ahv::kRmwThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, gvol2);
+        CK(hipEventRecord(e[5], 0));
+        CK(hipEventSynchronize(e[5]));
         CK(hipGetLastError());
-        if (it >= 0)
+        if (it >= 0) {
             for (int k = 0; k < 3; ++k) { float ms; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); t[k] += ms; }
+            float ms; CK(hipEventElapsedTime(&ms, e[4], e[5])); t[3] += ms;
+        }
     }
-    std::vector<float> hv(64);
-    CK(hipMemcpy(hv.data(), gvol, 256, hipMemcpyDeviceToHost));
-    printf("B=%d N=%ld: head %.3f ms  dW1 %.3f ms  dV %.3f ms  total %.3f ms   (grad_vol[0..2] = %g %g %g)\n", B, N, t[0] / iters,
+    std::vector<float> hv(vol.size()), hv2(vol.size());
+    CK(hipMemcpy(hv.data(), gvol, vol.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hv2.data(), gvol2, vol.size() * 4, hipMemcpyDeviceToHost));
+    double mx = 0, md = 0;
+    for (size_t i = 0; i < hv.size(); ++i) { mx = std::max(mx, (double)std::fabs(hv[i])); md = std::max(md, (double)std::fabs(hv[i] - hv2[i])); }
+    printf("B=%d N=%ld: head %.3f ms  dW1 %.3f ms  dV %.3f ms (LDS atomics)  total %.3f ms   (grad_vol[0..2] = %g %g %g)\n", B, N, t[0] / iters,
            t[1] / iters, t[2] / iters, (t[0] + t[1] + t[2]) / iters, hv[0], hv[1], hv[2]);
+#ifdef AHV_RMW_STAMPS
+    {
+        unsigned long long hs[64];
+        CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(ahv::g_rmw_stamps), sizeof(hs)));
+        static const char* nm[8] = {"loop head", "wait done", "corners", "dX half 0", "wait ready", "scatter 0", "dX half 1", "scatter 1"};
+        const double nh = (double)N / (2.0 * gx) * ((B + gy - 1) / gy);   // hypotheses per slot of workgroup (3, 5), roughly
+        printf("   workgroup (3, 5): shader-clock cycles per hypothesis and phase (about %.0f hypotheses per slot)\n", nh);
+        for (int w = 0; w < 8; ++w) {
+            printf("   wave %d (slot %d member %d):", w, w >> 2, w & 3);
+            double tot = 0;
+            for (int i = 0; i < 8; ++i) { printf(" %s %.0f |", nm[i], hs[w * 8 + i] / nh); tot += hs[w * 8 + i] / nh; }
+            printf(" total %.0f\n", tot);
+        }
+    }
+#endif
+    printf("           dV read-modify-write kernel %.3f ms  total with it %.3f ms   max |difference| / max |dV| = %.2e\n", t[3] / iters,
+           (t[0] + t[1] + t[3]) / iters, md / mx);
     return 0;
 }

@@ -72,6 +72,7 @@ int main(int argc, char** argv)
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--each")) each = true;
         else if (!strcmp(argv[i], "--stamps")) stamps = true;
+        else if (!strcmp(argv[i], "--dup")) g_enc_probe_dup = 1;  // weight-reading launches twice: cold / hot marginal costs
         else B = atoi(argv[i]);
     }
     hipStream_t s; CK(hipStreamCreate(&s));
@@ -151,6 +152,14 @@ int main(int argc, char** argv)
             prev = t;
         }
         for (auto& kv : agg) printf("{\"kernel\": \"%s\", \"launches\": %d, \"total_us\": %.2f, \"avg_us\": %.2f}\n", kv.first.c_str(), kv.second.first, kv.second.second, kv.second.second / kv.second.first);
+        if (g_enc_probe_dup) {  // what a perfect weight prefetch could save: sum over the weight-reading launches of (cold - hot)
+            double cold = 0, hot = 0;
+            for (auto& kv : agg) {
+                const std::string again = kv.first + " [again: weights hot]";
+                if (agg.count(again)) { cold += kv.second.second; hot += agg[again].second; }
+            }
+            printf("{\"B\": %d, \"weight_reading_launches_cold_us\": %.2f, \"same_launches_weights_hot_us\": %.2f, \"perfect_prefetch_saves_us\": %.2f}\n", B, cold, hot, cold - hot);
+        }
     }
     return 0;
 }
