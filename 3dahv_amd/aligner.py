@@ -550,6 +550,12 @@ class Feature_Aligner(nn.Module):
         W1, W2, b2 = self.head_weights()
         return ops.forward_3d2d(img_feat, W1, W2, b2)  # carries an autograd edge (HIP backward) when one is needed
 
+    def verify_hypotheses(self, img_feat_src, img_feat_tgt, proposals, want_scores=False, **kw):
+        """test_co3d.py:137-145 as ONE launch with this module's head weights -> (scores | None, packed keys); an inference call
+        by the rule of ``_inference_call`` (no_grad, or eval mode).  Same method ``patch.install()`` gives the reference's class."""
+        from .patch import verify_hypotheses
+        return verify_hypotheses(self, img_feat_src, img_feat_tgt, proposals, want_scores=want_scores, **kw)
+
     # ---- once-per-pair encoder replayed from a hipGraph -------------------------------------------
     def graphed_forward_2d3d(self, batch: int = 1):
         """Returns ``fn(layer4_src, layer4_tgt) -> (vol_src, vol_tgt)`` that replays ``forward_2d3d``

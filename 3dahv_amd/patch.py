@@ -63,6 +63,24 @@ def _hip_forward_2d3d(self, img_feat_src, img_feat_tgt, random_mask=True, mask_r
     return hip_forward_2d3d(self, img_feat_src, img_feat_tgt)   # runs under no_grad; fresh tensors, no graph
 
 
+def verify_hypotheses(self, img_feat_src, img_feat_tgt, proposals, want_scores=False, **kw):
+    """INTEGRATION.md option B as a method of the (reference or mirror) ``Feature_Aligner`` -- ``install()`` adds it to the
+    reference's class: lines 137-145 of test_co3d.py as ONE launch (``ops.verify_pair`` with this module's head weights).
+    Returns ``(scores | None, packed keys)``; ``ops.select_rotation(keys, proposals)`` decodes them (lines 145-146).
+    An inference call by the same rule as the patched callables (``_inference_call``: no_grad, or the module in eval mode --
+    the reference scripts never enter no_grad, and ``ops.verify_pair`` on weights that require grad is refused because the
+    fused launch has no autograd edge).  A module in training mode with autograd recording is refused loudly here too."""
+    import torch
+    c1, c2 = self.feature_embedding_2d[0], self.feature_embedding_2d[2]
+    if not _inference_call(self):
+        raise RuntimeError("verify_hypotheses is the inference step (one fused launch, no autograd edge); the module is in "
+                           "training mode with autograd recording -- use rotate_volume / forward_3d2d (differentiable) or "
+                           "ops.score_hypotheses_autograd for the loss")
+    with torch.no_grad():
+        return ops.verify_pair(img_feat_src.detach(), img_feat_tgt.detach(), proposals, c1.weight, c2.weight, c2.bias,
+                               want_scores=want_scores, **kw)[:2]
+
+
 def install(utils_module=None, modules_module=None):
     """Patch the reference's modules (already imported, importable from sys.path, or passed in)."""
     if utils_module is None:
@@ -78,6 +96,9 @@ def install(utils_module=None, modules_module=None):
     modules_module.Feature_Aligner.forward_3d2d = _hip_forward_3d2d
     if "forward_2d3d" in _saved:
         modules_module.Feature_Aligner.forward_2d3d = _hip_forward_2d3d
+    if not hasattr(modules_module.Feature_Aligner, "verify_hypotheses"):
+        modules_module.Feature_Aligner.verify_hypotheses = verify_hypotheses
+        _saved["verify_hypotheses"] = (modules_module.Feature_Aligner, None)
     # scripts that did `from utils import *` / `from utils import rotate_volume` earlier hold their own binding
     for mod in list(sys.modules.values()):
         if mod is not None and getattr(mod, "rotate_volume", None) is _saved["rotate_volume"][1]:
@@ -98,3 +119,7 @@ def uninstall():
     if "forward_2d3d" in _saved:
         cls2, h = _saved.pop("forward_2d3d")
         cls2.forward_2d3d = h
+    if "verify_hypotheses" in _saved:
+        cls3, _ = _saved.pop("verify_hypotheses")
+        if cls3.__dict__.get("verify_hypotheses") is verify_hypotheses:
+            del cls3.verify_hypotheses

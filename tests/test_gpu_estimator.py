@@ -236,6 +236,7 @@ def test_option_a_under_the_reference_scripts_own_conditions(ahv, dev):
         img_feat_src_2_tgt = torch.stack(img_feat_src_2_tgt).reshape(-1, C, D, H, W)
 
         img_feat_src_2_tgt = model.feature_aligner.forward_3d2d(img_feat_src_2_tgt).reshape(B, proposals.shape[0], -1, H*W)
+        img_feat_tgt_vol = img_feat_tgt
         img_feat_tgt = model.feature_aligner.forward_3d2d(img_feat_tgt)
 
         pred_sim = (img_feat_src_2_tgt * img_feat_tgt[:, None]).sum(dim=2).mean(dim=-1)
@@ -246,6 +247,13 @@ def test_option_a_under_the_reference_scripts_own_conditions(ahv, dev):
         # ----
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated(dev) - base
+        # option B under the same conditions: the method install() adds to the reference's class (one fused launch + one select);
+        # the bare op refuses weights that require grad while autograd records -- nothing is detached silently
+        with pytest.raises(RuntimeError, match="no autograd edge"):
+            fe = model.feature_aligner.feature_embedding_2d
+            ahv.ops.verify_pair(img_feat_src, img_feat_tgt_vol, proposals, fe[0].weight, fe[2].weight, fe[2].bias, want_scores=False)
+        _, key = model.feature_aligner.verify_hypotheses(img_feat_src, img_feat_tgt_vol, proposals)
+        b_sim, b_index, b_R = ahv.ops.select_rotation(key, proposals)
     finally:
         ahv.patch.uninstall()
         torch.autograd.set_detect_anomaly(False)
@@ -261,6 +269,7 @@ def test_option_a_under_the_reference_scripts_own_conditions(ahv, dev):
     every = all_sim[0, ::97].cpu().numpy()
     assert np.max(np.abs(every - dg["every97_score"]) / np.abs(dg["every97_score"]).clip(1e-2)) < 1e-4
     assert torch.equal(pred_src_2_tgt_R[0], proposals[int(dg["best_idx"][0])])
+    assert b_index.item() == pred_index.item() and torch.equal(b_R, pred_src_2_tgt_R) and abs(b_sim.item() - pred_sim.item()) < 1e-6
     # (iii) memory: the script's own tensors are the rotated volumes twice (list + torch.stack's copy, 1.64 GB each),
     # the features (0.41 GB) and their product (0.41 GB) = 4.1 GB.  The reference's dataflow needs those AND the
     # sampling grid (0.3 GB), three permuted slab copies + their concatenation (4.9 + 4.9 GB) and the conv / relu /

@@ -366,3 +366,83 @@ if not only or "pairs" in only:
         dt = time.perf_counter() - t0
         print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": "16 sequences per batch, AHV_SCORE_SPLIT_F16 (split-f16, opt-in)",
                           "pairs": len(e), "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))
+
+if "optiona" in only:
+    # INTEGRATION.md option A under the reference script's own conditions (grad mode on, anomaly detection on, model.eval()):
+    # the verbatim per-pair sequence of test_co3d.py:133-152 on a reference-shaped stand-in whose two callables are patched,
+    # beside option B (one fused launch + one select) on the same pairs.  N = 50 000 per pair, one pair at a time.
+    import types
+
+    class RefAligner(ahv.aligner.Feature_Aligner):     # torch-operator forward_2d3d, like the reference's class
+        def forward_2d3d(self, a, b, random_mask=True, mask_ratio=0.25):
+            self.use_hip_encoder = self.att.use_hip = False
+            return super().forward_2d3d(a, b, random_mask, mask_ratio)
+
+        def forward_3d2d(self, x):
+            raise AssertionError("not patched")
+
+    class Estimator(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.feature_aligner = RefAligner(in_channel=768, mid_channel=256, out_channel=32, n_heads=4, depth=4)
+            self.gain = torch.nn.Parameter(torch.ones(()))
+
+        def forward(self, f_src, f_tgt):   # (stands behind the backbone: layer_4 features in, parameters that require grad)
+            return self.feature_aligner.forward_2d3d(f_src * self.gain, f_tgt * self.gain, random_mask=False, mask_ratio=0)
+
+    torch.manual_seed(0)
+    model = Estimator().to(dev)
+    model.eval()
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+    mm.Feature_Aligner = RefAligner
+    proposals = ops.random_rotations(50000, seed=1, device=dev)
+    gt = ops.random_rotations(64, seed=2, device=dev)
+    feats = torch.randn(64, 2, 768, 8, 8, generator=torch.Generator().manual_seed(3)).to(dev)
+    torch.autograd.set_detect_anomaly(True)
+    assert torch.is_grad_enabled()
+
+    def reference_pairs(n_pairs, patched):
+        rotate_volume = um.rotate_volume
+        errs = []
+        for i in range(n_pairs):
+            img_feat_src, img_feat_tgt = model(feats[i % 64, 0][None], feats[i % 64, 1][None])
+            gt_src_2_tgt_R = gt[i % 64][None]
+            if patched == "B":   # INTEGRATION.md option B: the two-line change
+                _, key = model.feature_aligner.verify_hypotheses(img_feat_src, img_feat_tgt, proposals)   # added by patch.install()
+                pred_sim, pred_index, pred_src_2_tgt_R = ops.select_rotation(key, proposals)
+            else:                # test_co3d.py:135-146, verbatim
+                B, C, D, H, W = img_feat_src.shape
+                img_feat_src_2_tgt = [rotate_volume(img_feat[None].expand(proposals.shape[0], -1, -1, -1, -1), proposals) for img_feat in img_feat_src]
+                img_feat_src_2_tgt = torch.stack(img_feat_src_2_tgt).reshape(-1, C, D, H, W)
+                img_feat_src_2_tgt = model.feature_aligner.forward_3d2d(img_feat_src_2_tgt).reshape(B, proposals.shape[0], -1, H*W)
+                img_feat_tgt = model.feature_aligner.forward_3d2d(img_feat_tgt)
+                pred_sim = (img_feat_src_2_tgt * img_feat_tgt[:, None]).sum(dim=2).mean(dim=-1)
+                pred_sim, pred_index = torch.max(pred_sim, dim=1)
+                pred_src_2_tgt_R = proposals[pred_index]
+            sim = (torch.sum(pred_src_2_tgt_R.view(-1, 9) * gt_src_2_tgt_R.view(-1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+            err = torch.arccos(sim) * 180. / np.pi
+            errs.append(err.mean().item())   # the reference's host sync per pair (test_co3d.py:152)
+        return errs
+
+    ahv.patch.install(um, mm)
+    try:
+        rows = {}
+        for mode in ("A", "B"):
+            reference_pairs(8, mode)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            t0 = time.perf_counter()
+            errs = reference_pairs(64, mode)
+            torch.cuda.synchronize()
+            rows[mode] = ((time.perf_counter() - t0) / 64 * 1e3, errs, torch.cuda.max_memory_allocated(dev) / 1e9)
+        calls = dict(ahv.patch.calls)
+    finally:
+        ahv.patch.uninstall()
+        torch.autograd.set_detect_anomaly(False)
+    assert rows["A"][1] == rows["B"][1] or max(abs(a - b) for a, b in zip(rows["A"][1], rows["B"][1])) < 1e-3
+    print(json.dumps({"config": "evaluation loop under the reference script's conditions (grad mode on, anomaly mode on, model.eval()), "
+                                "one pair at a time, N=50000", "option_A_patched_callables_ms_per_pair": rows["A"][0],
+                      "option_B_fused_launch_ms_per_pair": rows["B"][0], "option_A_peak_memory_GB": rows["A"][2],
+                      "option_B_peak_memory_GB": rows["B"][2], "same_predictions": True,
+                      "encoder_calls": {k: v for k, v in calls.items()}}))
