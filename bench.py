@@ -600,16 +600,17 @@ def worker(args):
                 pred = {"note": "t(50 000) / (n * t(50 000 / n)) on ONE GPU, 8 steps per select, no collective: the efficiency an "
                                 "n-GPU strong-scaling run can reach before link latency"}
                 t_ref = {}
+                pred_steps = 96   # independent of --steps: at the driver's 20 steps these legs scattered by +-5 %
                 pred_lanes = (1, 2, 3) if os.environ.get("AHV_BENCH_PRED_THREE_LANES", "0") == "1" else (1, 2)
                 suffix = {1: "", 2: "_two_lanes", 3: "_three_lanes"}
                 for nl in pred_lanes:
-                    _, r = leg(vol_src, vol_tgt, R_all, sec_steps if nl == 1 else 2 * sec_steps, 48, grp=8, lanes=nl)
+                    _, r = leg(vol_src, vol_tgt, R_all, pred_steps if nl == 1 else 2 * pred_steps, 48, grp=8, lanes=nl)
                     t_ref[nl] = r["ms_per_step"]
                 for n in (2, 4, 8):
                     a, b = adist.shard_range(N_HYP, n - 1, n)   # the last rank's shard (offsets included)
                     row = {"n_hyp_per_rank": b - a}
                     for nl in pred_lanes:
-                        _, r = leg(vol_src, vol_tgt, R_all[a:b], 2 * sec_steps, 48, grp=8, lanes=nl, offset=a)
+                        _, r = leg(vol_src, vol_tgt, R_all[a:b], 2 * pred_steps, 48, grp=8, lanes=nl, offset=a)
                         row["ms_per_step" + suffix[nl]] = r["ms_per_step"]
                         row["efficiency" + suffix[nl]] = t_ref[nl] / (n * r["ms_per_step"])
                         # what the driver computes: the N-rank value over N times the ONE-rank, one-lane value

@@ -117,8 +117,11 @@ if not only or "5" in only:
         c2f.buffers[1].copy_(vt)
         ms_in_place = timeit(lambda: c2f(), 200, warm=5)
         assert not (fused and c2f._fused_state.gave_up())
+        # eight steps per replay (run_many): a hipGraphLaunch idles the device ~9 us between two replays, so the gap is paid once
+        ms_many = timeit(lambda: c2f.run_many(steps=8), 25, warm=3) / 8
         print(json.dumps({"config": "5 coarse10k+fine1k", "graph": use_graph, "us_per_step": ms * 1e3,
-                          "us_per_step_inputs_in_place": ms_in_place * 1e3, "launches_per_step": 1 if fused else 5,
+                          "us_per_step_inputs_in_place": ms_in_place * 1e3, "us_per_step_8_steps_per_call": ms_many * 1e3,
+                          "launches_per_step": 1 if fused else 5,
                           "hyp_per_s": 11_000 / ms_in_place * 1e3, "fine_score": out[0].item(), "coarse_score": out[3].item()}))
 
 if not only or "shard" in only:
