@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     // CONV: this thread's token (y, x) inside the sample and the sample's first row
     const int cty = srow >> 3, ctx = srow & 7;
     const float* xs = pr.X + (long)m0 * 256 + 4 * sch;
+    const int zoff = CONV ? (int)((a.zero + 4 * sch) - xs) : 0;   // the zero line, as an offset from this thread's row base
     auto gload = [&](int kt, int st) {  // tile kt -> stage st, 2 NP pieces of 1 KiB per wave
         float* dst = smem + st * STAGE + soff;
         if constexpr (CONV) {
@@ -512,9 +513,12 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
             const int t3 = (tap * 11) >> 5;                   // tap / 3 for tap < 9
             const int dy = t3 - 1, dx = tap - 3 * t3 - 1;
             const int ny = cty + dy, nx = ctx + dx;
-            const bool inside = (unsigned)(ny | nx) < 8u;     // a negative coordinate sets the sign bit of the OR
-            const float* src = inside ? xs + ((ny * 8 + nx) * 256 + ci) : a.zero + 4 * sch;
-            glds16(src, dst);
+            // an arithmetic select on a 32-bit offset (the workspace is far below 8 GB): written as `inside ? p : q` on pointers
+            // hipcc turned the k-step into exec-masked blocks, i.e. a K loop of several basic blocks -- and then waits for
+            // every DMA and fragment read in front of the MFMAs (tests/test_isa_hazard.py checks the loop's shape)
+            const int keep = -(int)((unsigned)(ny | nx) < 8u);   // all ones inside the image (a negative coordinate sets the OR's sign bit)
+            const int off = (((ny * 8 + nx) * 256 + ci) & keep) | (zoff & ~keep);
+            glds16(xs + off, dst);
             glds16(wg[0] + 16 * kt, dst + HALF);
         } else {
 #pragma unroll
