@@ -55,7 +55,7 @@ def test_bench_json_line():
     assert "INSIDE the timed region" in r["kernel_ms_is"] and r["achieved_is"] == "algorithmic flops per launch / kernel_ms"
     assert r["kernel_ms"] <= d["ms_per_step"]
     assert 0.5 * r["kernel_ms"] < r["hypothesis_loop_ms_all_launches_median"] <= r["kernel_ms"]
-    assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= max(r["kernel_ms_per_bracket"]) + 1e-6
+    assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= max(r["kernel_ms_per_bracket"]) + 1e-4   # (the list is rounded to 4 places)
     assert abs(r["kernel_ms_mean"] - r["kernel_ms"]) < 1e-12
     # one rank, one lane, and which GPU it was
     assert d["config"]["lanes"] == 1 and len(d["config"]["ranks"]) == 1
