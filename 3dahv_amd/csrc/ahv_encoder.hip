@@ -1099,7 +1099,20 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
 #ifndef AHV_FFOUT_KS8_MAX_M
 #define AHV_FFOUT_KS8_MAX_M 128
 #endif
-        if (tiled || M > AHV_FFOUT_KS8_MAX_M) {
+        // FF out on tiles: N = 256 gives only 2 column tiles per stream, so the K split has to fill the chip -- 8 ways up to
+        // M = 1024 (B = 16: 256 workgroups instead of 128; forward 1 213 -> 1 117 us), 4 ways from M = 2048 (B = 32: 256
+        // workgroups; 8 ways measured 1.3 % SLOWER there: 16 k-steps per workgroup and an 8-slab LayerNorm)
+#ifndef AHV_FFOUT_TILED_KS8_MAX_M
+#define AHV_FFOUT_TILED_KS8_MAX_M 1024
+#endif
+        if (tiled && M <= AHV_FFOUT_TILED_KS8_MAX_M) {
+            for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].part + (size_t)M * 2048, nullptr, 256};
+            AHV_TRY(launch_linear_tile(sp, 2, 2048, 2048, M, 2048, 8, 0, s, 128), "ff out (tiled, split-K 8)");
+            ln.KS = 8;
+            for (int i = 0; i < 2; ++i)
+                ln.p[i] = LnProb{ws[i].part + (size_t)M * 2048, w[i]->b_ff2, w[i]->ln2_g, w[i]->ln2_b, x[i], out[i]};
+            AHV_ENC_LAUNCH((ln_kernel<false, 8>), dim3((M + 3) / 4, 2), dim3(256), 0, s, ln);
+        } else if (tiled || M > AHV_FFOUT_KS8_MAX_M) {
             // FF out: 4 K-splits x [M][256] = [M][1024] floats: fits the qkv + kv scratch (1280 per row), free by now
             for (int i = 0; i < 2; ++i) sp[i] = LinSpec{ws[i].part, w[i]->w_ff2, ws[i].qkv, nullptr, 256};
             if (tiled) AHV_TRY(launch_linear_tile(sp, 2, 2048, 2048, M, 2048, 4, 0, s, 128), "ff out (tiled, split-K 4)");
