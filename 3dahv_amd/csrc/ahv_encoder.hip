@@ -652,6 +652,11 @@ struct AttnOutArgs {
 // w of W_out (64 MFMAs).  96 dependent MFMAs per wave instead of 192, a quarter of the K / V loads.  The result is
 // one split-K slab PER HEAD, P[h][M][256]; ln_kernel sums the four.
 // -------------------------------------------------------------------------------------------------
+// QT query tiles per workgroup (round 6 experiment, QT = 1 ships): a workgroup can walk several 16-query tiles of its
+// (sample, head) with the K, V and W_out fragments it holds in registers (96 of the ~100 KB a workgroup reads; only Q changes
+// per tile, requested a tile ahead).  At B = 32 it changes nothing (see AHV_ATTN_QT at the launch): the launch is bound by the
+// dependent chain of a tile (16 + 16 + 64 MFMAs, two barriers, a softmax), not by its 100 MB of L2 reads.
+template <int QT>
 __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs a, int M)
 {
     __shared__ float sm[4][16][2];                                   // per wave and query: (max, sum)
@@ -660,9 +665,9 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
     const AttnOutProb pr = a.p[pi];
-    const int it = blockIdx.y, h = blockIdx.z;
+    const int it0 = blockIdx.y * QT, h = blockIdx.z;
     const int c16 = lane & 15, kq = lane >> 4;
-    const float* q = pr.Q + (long)(b * 64 + it * 16 + c16) * pr.ldq + h * 64 + 4 * kq;
+    const float* q = pr.Q + (long)(b * 64 + it0 * 16 + c16) * pr.ldq + h * 64 + 4 * kq;
     const float* k = pr.K + (long)(b * 64 + w * 16 + c16) * pr.ldkv + h * 64 + 4 * kq;
     const float* v = pr.V + (long)(b * 64 + w * 16 + 4 * kq) * pr.ldkv + h * 64 + c16;
     // every operand is requested before the first MFMA
@@ -683,73 +688,86 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
         for (int dt = 0; dt < 4; ++dt)
             wf[nt][dt] = *reinterpret_cast<const f32x4*>(pr.Wo + (long)(w * 64 + nt * 16 + c16) * 256 + h * 64 + 16 * dt + 4 * kq);
     __builtin_amdgcn_sched_barrier(0);
-    // S^T[j = 16 w + 4 kq + r][i = c16]
-    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t = 0; t < QT; ++t) {
+        f32x4 qn[4];   // the next tile's queries travel while this one is processed (the last tile re-reads itself)
+        if (QT > 1) {
+            const float* qq = q + (long)(t + 1 < QT ? t + 1 : t) * 16 * pr.ldq;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds)
+            for (int ds = 0; ds < 4; ++ds) qn[ds] = *reinterpret_cast<const f32x4*>(qq + 16 * ds);
+        }
+        // S^T[j = 16 w + 4 kq + r][i = c16]
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][s], qb[ds][s], st, 0, 0, 0);
-    float m = -INFINITY;
+        for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        st[r] *= a.scale;
-        m = fmaxf(m, st[r]);
+            for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][s], qb[ds][s], st, 0, 0, 0);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[r] *= a.scale;
+            m = fmaxf(m, st[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[r] = expf(st[r] - m);
+            l += st[r];
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (kq == 0) {
+            sm[w][c16][0] = m;
+            sm[w][c16][1] = l;
+        }
+        __syncthreads();
+        float mg = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mg = fmaxf(mg, sm[u][c16][0]);
+        float L = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) L += sm[u][c16][1] * expf(sm[u][c16][0] - mg);
+        const float f = expf(m - mg) / L;
+        // this wave's share of O^T[d = 16 dt + 4 kq + r][i = c16]
+        f32x4 ot[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = st[r] * f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r][dt], p, ot[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&so[w][dt][lane][0]) = ot[dt];
+        __syncthreads();   // (also: everybody has read sm, the next tile may overwrite it; so is rewritten behind the next tile's first barrier)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            ot[dt] = *reinterpret_cast<const f32x4*>(&so[0][dt][lane][0]);
+#pragma unroll
+            for (int u = 1; u < 4; ++u) ot[dt] += *reinterpret_cast<const f32x4*>(&so[u][dt][lane][0]);
+        }
+        // column quarter w of the head's output projection: D^T[n = 64 w + 16 nt + 4 kq + r][q = c16]
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][dt][r], ot[dt][r], acc[nt], 0, 0, 0);
+        float* out = pr.P + ((long)h * M + b * 64 + (it0 + t) * 16 + c16) * 256 + w * 64 + 4 * kq;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(out + nt * 16) = acc[nt];
+        if (QT > 1) {
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) qb[ds] = qn[ds];
+        }
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        st[r] = expf(st[r] - m);
-        l += st[r];
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (kq == 0) {
-        sm[w][c16][0] = m;
-        sm[w][c16][1] = l;
-    }
-    __syncthreads();
-    float mg = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) mg = fmaxf(mg, sm[u][c16][0]);
-    float L = 0.0f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) L += sm[u][c16][1] * expf(sm[u][c16][0] - mg);
-    const float f = expf(m - mg) / L;
-    // this wave's share of O^T[d = 16 dt + 4 kq + r][i = c16]
-    f32x4 ot[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float p = st[r] * f;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r][dt], p, ot[dt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&so[w][dt][lane][0]) = ot[dt];
-    __syncthreads();
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        ot[dt] = *reinterpret_cast<const f32x4*>(&so[0][dt][lane][0]);
-#pragma unroll
-        for (int u = 1; u < 4; ++u) ot[dt] += *reinterpret_cast<const f32x4*>(&so[u][dt][lane][0]);
-    }
-    // column quarter w of the head's output projection: D^T[n = 64 w + 16 nt + 4 kq + r][q = c16]
-    f32x4 acc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][dt][r], ot[dt][r], acc[nt], 0, 0, 0);
-    float* out = pr.P + ((long)h * M + b * 64 + it * 16 + c16) * 256 + w * 64 + 4 * kq;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(out + nt * 16) = acc[nt];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1078,7 +1096,12 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
             ao.p[i] = AttnOutProb{ws[i].qkv, ws[i].kv, ws[i].kv + 256, w[i]->w_out, ws[i].part, 256, 512};
     }
     {   // attention and the output projection in ONE launch (attention_heads_kernel), then norm1 + concat
-        AHV_ENC_LAUNCH(attention_heads_kernel, dim3(2 * B, 4, 4), dim3(256), 0, s, ao, M);
+#ifndef AHV_ATTN_QT   // A/B knob (tools/kbench_enc): query tiles per workgroup at B >= 32.  Measured in round 6: 1 / 2 / 4 tiles per
+#define AHV_ATTN_QT 1   // workgroup give 1 964 / 1 958 / 1 960 us per forward (17.6-18.1 us per launch either way): not the re-reads
+#endif                  // of K, V and W_out bound this launch but the dependent chain of one tile; the one-tile form stays
+        if (B >= 32 && AHV_ATTN_QT == 4) AHV_ENC_LAUNCH(attention_heads_kernel<4>, dim3(2 * B, 1, 4), dim3(256), 0, s, ao, M);
+        else if (B >= 32 && AHV_ATTN_QT == 2) AHV_ENC_LAUNCH(attention_heads_kernel<2>, dim3(2 * B, 2, 4), dim3(256), 0, s, ao, M);
+        else AHV_ENC_LAUNCH(attention_heads_kernel<1>, dim3(2 * B, 4, 4), dim3(256), 0, s, ao, M);
         AHV_TRY(hipGetLastError(), "attention + out projection");
         LnArgs ln;
         ln.KS = 4; ln.M = M;  // one slab per head
