@@ -20,7 +20,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 python3 - <<PY
 import csv, glob, collections, json
 NH = $B * $N
-FLOPS = {"score_backward_head_kernel": 2101248, "score_backward_w1_kernel": 1703936, "score_backward_volume_kernel": 1703936}
+FLOPS = {"score_backward_head_kernel": 2101248, "score_backward_w1_kernel": 1703936, "score_backward_volume_kernel": 1703936,
+         "score_backward_volume_rmw_kernel": 1703936}
+SHIPPED = ("score_backward_head_kernel", "score_backward_w1_kernel", "score_backward_w1_reduce_kernel", "score_backward_volume_rmw_kernel")
 out = {"B": $B, "N": $N, "hypotheses": NH, "command": "tools/kbench_bwd $B $N", "kernels": {}}
 # durations: full-size launches of the kernel trace (the stats pass)
 t = glob.glob("$OUT/trace/*/*_kernel_trace.csv")[0]
@@ -49,9 +51,12 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc_fetch", "pmc_write"):
         for n, v in c.items():
             e.setdefault("counters_per_launch", {})[n] = sum(v) / len(v)
             e.setdefault("counters_per_hypothesis", {})[n] = sum(v) / len(v) / NH
-tot = sum(e.get("avg_us", 0.0) for e in out["kernels"].values())
+# the backward the library launches: head + dW1 (+ reduce) + the read-modify-write dV kernel (kbench_bwd also times the LDS-atomic
+# dV kernel of rounds 2-5 for A/B: listed under "kernels", not part of the sum)
+tot = sum(out["kernels"][k].get("avg_us", 0.0) for k in SHIPPED if k in out["kernels"])
 out["backward_us"] = tot
-out["backward_tflops"] = NH * sum(FLOPS.values()) / tot / 1e6
+out["backward_kernels"] = [k for k in SHIPPED if k in out["kernels"]]
+out["backward_tflops"] = NH * 5509120 / tot / 1e6
 out["backward_frac_fp32_mfma_peak"] = out["backward_tflops"] / 157.3
 for k, e in out["kernels"].items():
     c = e.get("counters_per_launch", {})
