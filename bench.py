@@ -439,12 +439,21 @@ def worker(args):
         (the first launches after an idle period run ~18 % slower), so a step-count warm-up of a
         0.7-ms kernel sits inside the ramp.  Loops until >= min_ms have elapsed AND the last three kernel times
         agree within 1 % (or max_ms).  Returns what it did, for the JSON line."""
-        t0, done, last = time.perf_counter(), 0, []
-        settled = False
-        # (every lane runs at least one whole group here: a lane's first collective creates its communicator, which must
-        # not happen inside the timed region)
+        # every lane runs at least one whole group per batch
         batch = max(batch, loop.group * len(loop.lanes))
-        while min_ms > 0 or (len(loop.lanes) > 1 and done == 0):
+        done, last = 0, []
+        if use_pg:
+            # One batch OUTSIDE the pre-warm's clock: a lane's first collective creates its communicator -- seconds with RCCL
+            # across GPUs, during which the chip idles.  Counted against max_ms it ended the pre-warm at once and left the
+            # timed region of a short run (20 steps of a 0.1-ms shard) inside the clock ramp.
+            loop.run(batch)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            done += batch
+        t0 = time.perf_counter()
+        settled = False
+        while min_ms > 0:
             evs = new_events(batch)
             loop.run(batch, [(i, i, a, b) for i, (a, b) in enumerate(evs)])
             torch.cuda.synchronize()
