@@ -69,6 +69,8 @@ SIGNATURES["ahv_forward_2d3d_f32"] = (_int, [ctypes.POINTER(AlignerWeights), _vp
 SIGNATURES["ahv_score_hypotheses_backward_workspace_bytes"] = (ctypes.c_size_t, [_int, _i64])
 SIGNATURES["ahv_score_hypotheses_backward_f32"] = (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp,
                                                           ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp])
+SIGNATURES["ahv_score_hypotheses_backward_saved_f32"] = SIGNATURES["ahv_score_hypotheses_backward_f32"]
+SIGNATURES["ahv_score_hypotheses_train_f32"] = (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, ctypes.c_size_t, _vp])
 SIGNATURES["ahv_transformer_workspace_bytes"] = (ctypes.c_size_t, [_int])
 SIGNATURES["ahv_transformer_blocks_f32"] = (_int, [ctypes.POINTER(BlockWeights), _int, _vp, _vp, _int, _vp,
                                                    ctypes.c_size_t, _vp])

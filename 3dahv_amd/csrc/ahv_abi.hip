@@ -29,7 +29,7 @@ hipError_t launch_random_rotations(uint64_t, uint64_t, int64_t, float*, hipStrea
 hipError_t launch_so3_grid(int64_t, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_score_backward(const float*, const float*, const float*, int64_t, const float*, const float*,
                                  const float*, int, int64_t, const float*, float*, unsigned*, float*, float*, float*, float*,
-                                 float*, float*, int, hipStream_t);
+                                 float*, float*, int, hipStream_t, bool);
 hipError_t launch_zero_fill(void* const* ptrs, const size_t* bytes, int count, hipStream_t stream);
 size_t transformer_workspace_floats(int B);
 int transformer_blocks(const ahv_block_weights*, int, float*, float*, int, float*, hipStream_t, const char**);
@@ -76,7 +76,7 @@ int cu_count()
 
 extern "C" {
 
-int ahv_abi_version(void) { return (2 << 16) | 2; }
+int ahv_abi_version(void) { return (2 << 16) | 3; }
 
 const char* ahv_last_error(void) { return g_err; }
 
@@ -392,11 +392,61 @@ size_t ahv_score_hypotheses_backward_workspace_bytes(int B, int64_t N)
     return sizeof(float) * (2048 * (size_t)B * (size_t)N + (((size_t)B + 3) & ~(size_t)3) + wgs * 32 * 384);
 }
 
+static int score_backward_common(const float* vol_src, const float* feat_tgt, const float* R,
+                                 int64_t r_batch_stride, const float* W1, const float* W2, const float* b2,
+                                 int B, int64_t N, const float* grad_scores, void* workspace,
+                                 size_t workspace_bytes, float* grad_vol_src, float* grad_feat_tgt,
+                                 float* grad_W1, float* grad_W2, float* grad_b2, void* stream, bool saved_u);
+
 int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tgt, const float* R,
                                       int64_t r_batch_stride, const float* W1, const float* W2, const float* b2,
                                       int B, int64_t N, const float* grad_scores, void* workspace,
                                       size_t workspace_bytes, float* grad_vol_src, float* grad_feat_tgt,
                                       float* grad_W1, float* grad_W2, float* grad_b2, void* stream)
+{
+    return score_backward_common(vol_src, feat_tgt, R, r_batch_stride, W1, W2, b2, B, N, grad_scores, workspace, workspace_bytes,
+                                 grad_vol_src, grad_feat_tgt, grad_W1, grad_W2, grad_b2, stream, false);
+}
+
+int ahv_score_hypotheses_backward_saved_f32(const float* vol_src, const float* feat_tgt, const float* R,
+                                            int64_t r_batch_stride, const float* W1, const float* W2, const float* b2,
+                                            int B, int64_t N, const float* grad_scores, void* workspace,
+                                            size_t workspace_bytes, float* grad_vol_src, float* grad_feat_tgt,
+                                            float* grad_W1, float* grad_W2, float* grad_b2, void* stream)
+{
+    return score_backward_common(vol_src, feat_tgt, R, r_batch_stride, W1, W2, b2, B, N, grad_scores, workspace, workspace_bytes,
+                                 grad_vol_src, grad_feat_tgt, grad_W1, grad_W2, grad_b2, stream, true);
+}
+
+int ahv_score_hypotheses_train_f32(const float* vol_src, const float* feat_tgt, const float* R, int64_t r_batch_stride,
+                                   const float* W1, const float* W2, const float* b2, int B, int64_t N, float* scores,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (B < 0 || N < 0) return fail(AHV_EINVAL, "score_train: negative size");
+    if (B > 65535) return fail(AHV_EINVAL, "score_train: B > 65535");
+    if (B == 0 || N == 0) return AHV_OK;
+    if (!vol_src || !feat_tgt || !R || !W1 || !W2 || !b2 || !scores || !workspace) return fail(AHV_EINVAL, "score_train: null pointer");
+    if (r_batch_stride != 0 && r_batch_stride != N * 9) return fail(AHV_EINVAL, "score_train: r_batch_stride must be 0 or N*9");
+    if (workspace_bytes < ahv_score_hypotheses_backward_workspace_bytes(B, N))
+        return fail(AHV_EINVAL, "score_train: workspace of %zu bytes, need %zu (ahv_score_hypotheses_backward_workspace_bytes)",
+                    workspace_bytes, ahv_score_hypotheses_backward_workspace_bytes(B, N));
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(AHV_EINVAL, "score_train: workspace must be 16-byte aligned");
+    const int cu = cu_count();
+    if (cu <= 0) return fail(AHV_EDEVICE, "score_train: no usable HIP device");
+    ahv::ScoreLaunch a{};
+    a.vol_src = vol_src; a.tgt = feat_tgt; a.tgt_is_volume = false; a.R = R; a.r_batch_stride = r_batch_stride; a.n_offset = 0;
+    a.W1 = W1; a.W2 = W2; a.b2 = b2; a.B = B; a.N = N; a.scores = scores; a.best_key = nullptr; a.feat_tgt_out = nullptr;
+    a.num_cu = cu; a.spare_cu = 0; a.split_f16 = false; a.no_teams = true; a.clock_stamps = nullptr;
+    hipError_t e = ahv::launch_score_hypotheses_train(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail("score_train: launch", e);
+    return AHV_OK;
+}
+
+static int score_backward_common(const float* vol_src, const float* feat_tgt, const float* R,
+                                 int64_t r_batch_stride, const float* W1, const float* W2, const float* b2,
+                                 int B, int64_t N, const float* grad_scores, void* workspace,
+                                 size_t workspace_bytes, float* grad_vol_src, float* grad_feat_tgt,
+                                 float* grad_W1, float* grad_W2, float* grad_b2, void* stream, bool saved_u)
 {
     if (B < 0 || N < 0) return fail(AHV_EINVAL, "score_backward: negative size");
     if (B > 65535) return fail(AHV_EINVAL, "score_backward: B > 65535");
@@ -420,7 +470,7 @@ int ahv_score_hypotheses_backward_f32(const float* vol_src, const float* feat_tg
                                               reinterpret_cast<unsigned*>(static_cast<float*>(workspace) + 2048 * (size_t)B * (size_t)N),
                                               static_cast<float*>(workspace) + 2048 * (size_t)B * (size_t)N + (((size_t)B + 3) & ~(size_t)3),
                                               grad_vol_src, grad_feat_tgt, grad_W1, grad_W2, grad_b2, cu,
-                                              static_cast<hipStream_t>(stream));
+                                              static_cast<hipStream_t>(stream), saved_u);
     if (e != hipSuccess) return hip_fail("score_backward: launch", e);
     return AHV_OK;
 }

@@ -283,6 +283,210 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Kernel 1', round 6: the same backward through score / normalise / GEMM2 / ReLU WITHOUT the forward recompute -- u comes from
+// the workspace, where the training forward (ahv_score_hypotheses_train_f32) left it.  That removes gather + GEMM1 (832 of 960
+// MFMAs and ~900 of 2 547 vector instructions per hypothesis) from the backward for 8 KB more HBM traffic per hypothesis in each
+// direction; what is left of this kernel is bound by those 16 KB.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kernel(
+    const float* __restrict__ feat_tgt, const float* __restrict__ W2, const float* __restrict__ b2,
+    int B, long N, const float* __restrict__ grad_scores, float* __restrict__ du_ws,
+    unsigned* __restrict__ du_max_bits, float* __restrict__ grad_feat_tgt, float* __restrict__ grad_W2, float* __restrict__ grad_b2)
+{
+    __shared__ __attribute__((aligned(16))) float lds_q[4 * kQuarterFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4, row = lane & 15;
+    float* buf = lds_q + wave * kQuarterFloats;
+
+    DualFrags f;
+    load_dual_frags(f, W2, b2, lane);
+    float a2t[2][4][2];  // dr = W2^T dv: A[row = o][k = o2]: [m2][r2][m] = W2[16 m2 + 4 kq + r2][16 m + row]
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a2t[m2][r2][m] = W2[(16 * m2 + 4 * kq + r2) * 32 + 16 * m + row];
+
+    f32x4 dW2[2][2];   // [mt][nt][r]: dW2[16 mt + 4 kq + r][16 nt + n]
+    float db2p[2][4];  // [m2][r]: partial over this lane's columns of db2[16 m2 + 4 kq + r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db2p[i][r] = 0.0f;
+
+    const long hstep = (long)gridDim.x * 4;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        f32x4 tg[4][2], dtg[4][2];
+        {
+            const float* ft = feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tg[t][m2][r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n];
+                        dtg[t][m2][r] = 0.0f;
+                    }
+        }
+        float du_amax = 0.0f;
+        long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
+        // u of the forward (score_hypotheses_train_kernel): [m][t][lane][r] per hypothesis, eight 16-byte loads per lane; the
+        // next hypothesis's travel while this one is processed.  du overwrites the same 8 KB (row-major [32][64], what kernels
+        // 2a / 2b read): every load of a hypothesis is consumed before its first store is issued.
+        f32x4 un[2][4];
+        if (h < N) {
+            const float* up = du_ws + ((long)b * N + h) * 2048 + lane * 4;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) un[m][t] = *reinterpret_cast<const f32x4*>(up + (m * 4 + t) * 256);
+        }
+        for (; h < N; h += hstep) {
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = un[m][t];
+            if (h + hstep < N) {
+                const float* up = du_ws + ((long)b * N + h + hstep) * 2048 + lane * 4;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) un[m][t] = *reinterpret_cast<const f32x4*>(up + (m * 4 + t) * 256);
+            }
+            f32x4 v[2][4];
+            gemm2_dual(v, acc, f);
+
+            // score = 1/64 sum_pos <v / max(|v|, eps), tg>; F.normalize's clamp passes no gradient to the norm
+            // when it is below eps
+            const float g = grad_scores[(long)b * N + h] * (1.0f / 64.0f);
+            f32x4 dv[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float ss = 0.0f, dt = 0.0f;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ss += v[m2][t][r] * v[m2][t][r];
+                        dt += v[m2][t][r] * tg[t][m2][r];
+                    }
+                ss += __shfl_xor(ss, 16, 64); dt += __shfl_xor(dt, 16, 64);
+                ss += __shfl_xor(ss, 32, 64); dt += __shfl_xor(dt, 32, 64);
+                const float nrm = sqrtf(ss);
+                const bool clamped = nrm < 1e-12f;
+                const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+                const float c3 = clamped ? 0.0f : dt * inv * inv * inv;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dv[m2][t][r] = g * (tg[t][m2][r] * inv - c3 * v[m2][t][r]);
+                        dtg[t][m2][r] += g * inv * v[m2][t][r];
+                    }
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) db2p[m2][r] += dv[m2][0][r] + dv[m2][1][r] + dv[m2][2][r] + dv[m2][3][r];
+
+            // dr = W2^T dv (accumulator registers of dv are the B operand), du = dr where u > 0
+            f32x4 du[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) du[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        du[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][0], dv[m2][t][r2], du[0][t], 0, 0, 0);
+                        du[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][1], dv[m2][t][r2], du[1][t], 0, 0, 0);
+                    }
+            float* dst = du_ws + ((long)b * N + h) * 2048;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // (u != u: the forward's exact path saved NaN for a sample with a non-finite voxel or weight)
+                        const float x = acc[m][t][r] > 0.0f ? du[m][t][r] : (acc[m][t][r] == acc[m][t][r] ? 0.0f : acc[m][t][r]);
+                        dst[(16 * m + 4 * kq + r) * 64 + 16 * t + n] = x;
+                        // max |du| of the sample (kernel 2b sizes its fixed-point scale with it); NaN / inf poison it
+                        du_amax = (x == x) ? fmaxf(du_amax, fabsf(x)) : __builtin_inff();
+                    }
+
+            // dW2 += dv relu(u)^T: the contraction runs over positions, so both operands go through the
+            // wave's LDS image once (dv as A, relu(u) as B).
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) buf[dimg(16 * m2 + 4 * kq + r, 16 * t + n)] = dv[m2][t][r];
+            wave_lds_fence();
+            float av[2][16];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) av[mt][s] = buf[dimg(16 * mt + row, 4 * s + kq)];
+            wave_lds_fence();
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) buf[dimg(16 * m + 4 * kq + r, 16 * t + n)] = fmaxf(acc[m][t][r], 0.0f);
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float bv = buf[dimg(16 * nt + n, 4 * s + kq)];
+                    dW2[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][s], bv, dW2[0][nt], 0, 0, 0);
+                    dW2[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][s], bv, dW2[1][nt], 0, 0, 0);
+                }
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) du_amax = fmaxf(du_amax, __shfl_xor(du_amax, sft, 64));
+        if (lane == 0) atomicMax(du_max_bits + b, __float_as_uint(du_amax));  // non-negative floats order like uints
+        float* gft = grad_feat_tgt + (long)b * (32 * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) global_add(gft + (16 * m2 + 4 * kq + r) * 64 + 16 * t + n, dtg[t][m2][r]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) global_add(grad_W2 + (16 * mt + 4 * kq + r) * 32 + 16 * nt + n, dW2[mt][nt][r]);
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = db2p[m2][r];
+#pragma unroll
+            for (int s = 8; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
+            if (n == 0) global_add(grad_b2 + 16 * m2 + 4 * kq + r, x);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Kernels 2a / 2b.  Both walk the hypotheses again with du from the workspace.  They are separate launches
 // because each carries persistent state per wave (2a: the dW1 accumulators, 2b: the W1^T fragments; 96 registers
 // each since the outputs are split over the two waves of a SIMD) next to a gather / scatter that wants ~100 more:
@@ -1335,7 +1539,7 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
                                  const float* W1, const float* W2, const float* b2, int B, int64_t N,
                                  const float* grad_scores, float* du_ws, unsigned* du_max_bits, float* dw1_partials,
                                  float* grad_vol, float* grad_feat_tgt,
-                                 float* grad_W1, float* grad_W2, float* grad_b2, int num_cu, hipStream_t stream)
+                                 float* grad_W1, float* grad_W2, float* grad_b2, int num_cu, hipStream_t stream, bool saved_u)
 {
     hipError_t e;
     {   // accumulation targets (and the running maximum of |du|, bit pattern 0 = 0.0f): one zero-fill launch
@@ -1351,9 +1555,13 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     if (gx > need) gx = (int)need;
     if (gx < 1) gx = 1;
     const dim3 grid(gx, gy);
-    hipLaunchKernelGGL(score_backward_head_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, feat_tgt, R,
-                       (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2,
-                       grad_b2);
+    if (saved_u)   // du_ws holds u of every hypothesis (the training forward); the head kernel turns it into du in place
+        hipLaunchKernelGGL(score_backward_head_saved_kernel, grid, dim3(kBwdThreads), 0, stream, feat_tgt, W2, b2, B, (long)N,
+                           grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2, grad_b2);
+    else
+        hipLaunchKernelGGL(score_backward_head_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, feat_tgt, R,
+                           (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2,
+                           grad_b2);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(score_backward_w1_kernel, grid, dim3(kW1Threads), 0, stream, vol_src, R, (long)r_batch_stride,
                        B, (long)N, du_ws, dw1_partials);

@@ -31,6 +31,8 @@ struct ScorePlan {
 
 ScorePlan plan_score_launch(int B, int64_t N, int num_cu, int spare_cu, bool teams);
 hipError_t launch_score_hypotheses(const ScoreLaunch& a, hipStream_t stream);
+// the training forward: scores [B][N] and, in u_out, 8 KB of pre-activations per hypothesis for the backward
+hipError_t launch_score_hypotheses_train(const ScoreLaunch& a, float* u_out, hipStream_t stream);
 
 // ahv_coarse_to_fine_f32: the verify step on the coarse set (a.coarse, tgt = the target volume, n_offset 0) and, in the
 // same launch, on the refinement set R* D[n] of its winner (coarse_to_fine_kernel, ahv_score.hip)

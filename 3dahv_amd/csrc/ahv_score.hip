@@ -278,7 +278,11 @@ __device__ __attribute__((noinline)) key_t score_share_exact(const float* lds_sr
     return best;
 }
 
-template <bool SPLIT, bool TGT, bool C2F>
+// SAVE_U (round 6, the TRAINING forward: ahv_score_hypotheses_train_f32): every hypothesis also leaves its pre-activations
+// u = W1 slabs(rot(V, R_n)) -- the 32 accumulator registers GEMM1 ends with -- in `feat_tgt_out` (here: the u buffer), 8 KB per
+// hypothesis in the wave's own fragment layout [m][t][lane][r] (eight 16-byte stores per lane, 1 KB contiguous each).  The
+// backward then reads them instead of recomputing gather + GEMM1 (ahv_backward.hip, score_backward_head_saved_kernel).
+template <bool SPLIT, bool TGT, bool C2F, bool SAVE_U = false>
 __device__ __forceinline__ void score_hypotheses_body(
     const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
     long r_batch_stride, long n_offset, const float* __restrict__ W1, const float* __restrict__ W2,
@@ -287,6 +291,7 @@ __device__ __forceinline__ void score_hypotheses_body(
 {
     static_assert(!(SPLIT && TGT), "the split-f16 kernel takes ready-made target features");
     static_assert(!C2F || (TGT && !SPLIT), "the two-stage launch is the fp32 verify kernel");
+    static_assert(!SAVE_U || (!SPLIT && !TGT && !C2F), "u is saved by the fp32 scorer with ready-made target features");
     // The fp32 instances own their SIMDs: touching v255 makes the kernel's register allocation 256 per wave whatever the
     // allocator needs, so the two waves of a SIMD hold all 512 registers and no wave of another kernel can be resident beside
     // them -- which is what keeps hipcc's packed op_sel forms safe here (low_half, ahv_dual.h; tests/test_isa_hazard.py).
@@ -614,9 +619,19 @@ __device__ __forceinline__ void score_hypotheses_body(
             // (re-read rather than kept alive across the call: kept alive, the resident W1 fragments were saved to scratch at
             // their definition -- once per wave and launch, 5 MB of stores -- for a path finite data never takes)
             if constexpr (SPLIT) split_load_resident(w1res, reinterpret_cast<const f16x8*>(lds_w1), lane);
+            if constexpr (SAVE_U) {
+                // the exact path keeps no accumulators: a sample with a non-finite voxel or weight hands NaN pre-activations
+                // to the backward, which turns them into NaN gradients for that sample (like autograd would)
+                const f32x4 qn = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                for (long he = h0; he < N_s; he += hstep) {
+                    float* uo = feat_tgt_out + ((long)b * N_s + he) * 2048 + lane * 4;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(uo + i * 256) = qn;
+                }
+            }
         } else {
 #ifndef AHV_DIAG_TEAMS_LAST
-        if constexpr (!SPLIT) score_remainder_by_teams();
+        if constexpr (!SPLIT && !SAVE_U) score_remainder_by_teams();   // (the training forward runs single waves only: n_main = N)
 #endif
         // Hypothesis h -> (workgroup h % gridDim.x, wave slot (h / gridDim.x) % 8): a partial last round of the persistent
         // grid spreads over ALL CUs with few waves each instead of filling some CUs completely and leaving the rest idle.
@@ -711,6 +726,13 @@ __device__ __forceinline__ void score_hypotheses_body(
                 AHV_TS(9)
                 s = hyp_score_tail(ss, dt);
             } else {
+                if constexpr (SAVE_U) {
+                    float* uo = feat_tgt_out + ((long)b * N_s + h) * 2048 + lane * 4;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(uo + (m * 4 + t) * 256) = acc[m][t];
+                }
                 f32x4 v[2][4];
                 gemm2_dual(v, acc, f);
                 AHV_TS(9)
@@ -838,6 +860,16 @@ __global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_dual_kernel(
                                              feat_tgt_out, clk, C2fArgs{});
 }
 
+// the training forward: scores + the pre-activations of every hypothesis (SAVE_U above); single waves only
+__global__ __launch_bounds__(kDualThreads, 2) void score_hypotheses_train_kernel(
+    const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
+    long r_batch_stride, const float* __restrict__ W1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int B, long N, float* __restrict__ scores, float* __restrict__ u_out)
+{
+    score_hypotheses_body<false, false, false, true>(vol_src, tgt, R, r_batch_stride, 0l, W1, W2, b2, B, N, N, scores, nullptr, u_out,
+                                                     nullptr, C2fArgs{});
+}
+
 // the two-stage launch (C2fArgs above): `tgt` is the target volume, R the coarse set
 __global__ __launch_bounds__(kDualThreads, 2) void coarse_to_fine_kernel(
     const float* __restrict__ vol_src, const float* __restrict__ tgt, const float* __restrict__ R,
@@ -917,6 +949,15 @@ hipError_t launch_score_hypotheses(const ScoreLaunch& a, hipStream_t stream)
                            (long)a.r_batch_stride, (long)a.n_offset, a.W1, a.W2, a.b2, a.B, (long)a.N, (long)p.n_main, a.scores,
                            key, a.feat_tgt_out, clk);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_score_hypotheses_train(const ScoreLaunch& a, float* u_out, hipStream_t stream)
+{
+    if (a.split_f16 || a.tgt_is_volume || a.scores == nullptr || u_out == nullptr) return hipErrorInvalidValue;
+    const ScorePlan p = plan_score_launch(a.B, a.N, a.num_cu, a.spare_cu, /*teams=*/false);
+    hipLaunchKernelGGL(score_hypotheses_train_kernel, dim3(p.gx, p.gy), dim3(kDualThreads), 0, stream, a.vol_src, a.tgt, a.R,
+                       (long)a.r_batch_stride, a.W1, a.W2, a.b2, a.B, (long)a.N, a.scores, u_out);
     return hipGetLastError();
 }
 

@@ -313,10 +313,37 @@ def _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, want_sc
 
 
 @torch.no_grad()
+def score_hypotheses_train(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor,
+                           b2: torch.Tensor):
+    """The training forward: ``scores (B,N)`` as ``score_hypotheses`` computes them, plus the workspace in which the launch
+    left every hypothesis' pre-activations (8 KB each) for ``score_hypotheses_backward(..., workspace=ws)`` -- the backward
+    then skips the recompute of rotate_volume + the first projection (``ahv_score_hypotheses_train_f32``).  Returns
+    ``(scores, workspace)``; the workspace serves ONE backward."""
+    if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
+        raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
+    B = vol_src.shape[0]
+    if tuple(feat_tgt.shape) != (B, 32, 64):
+        raise RuntimeError("feat_tgt must be (B,32,64), got %s" % (tuple(feat_tgt.shape),))
+    N, rstride = _rot_layout(R, B)
+    dev = _need_gpu(vol_src, feat_tgt, R, W1, W2, b2)
+    W1c, W2c, b2c = _head(W1, W2, b2)
+    vs, ft, Rc = (t.detach().contiguous() for t in (vol_src, feat_tgt, R))
+    lib = _lib.load()
+    nbytes = lib.ahv_score_hypotheses_backward_workspace_bytes(B, N)
+    ws = torch.empty((max(nbytes, 16) // 4,), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, N), dtype=torch.float32, device=dev)
+    _call(dev, "ahv_score_hypotheses_train_f32", vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride, W1c.data_ptr(),
+          W2c.data_ptr(), b2c.data_ptr(), B, N, scores.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+    return scores, ws
+
+
+@torch.no_grad()
 def score_hypotheses_backward(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: torch.Tensor, W1: torch.Tensor,
-                              W2: torch.Tensor, b2: torch.Tensor, grad_scores: torch.Tensor):
+                              W2: torch.Tensor, b2: torch.Tensor, grad_scores: torch.Tensor, workspace: torch.Tensor | None = None):
     """Gradients of ``score_hypotheses`` w.r.t. ``(vol_src, feat_tgt, W1, W2, b2)`` given ``dL/dscores (B,N)``
-    (three launches; what ``infoNCE_loss`` back-propagates, modules/model_co3d.py:41-61).  R gets no gradient."""
+    (three launches; what ``infoNCE_loss`` back-propagates, modules/model_co3d.py:41-61).  R gets no gradient.
+    ``workspace``: what ``score_hypotheses_train`` returned for the SAME inputs -- the first kernel then reads the saved
+    pre-activations instead of recomputing the forward (and consumes them: one backward per workspace)."""
     if vol_src.dim() != 5 or tuple(vol_src.shape[1:]) != _VOL:
         raise RuntimeError("vol_src must be (B,16,8,8,8), got %s" % (tuple(vol_src.shape),))
     B = vol_src.shape[0]
@@ -330,13 +357,20 @@ def score_hypotheses_backward(vol_src: torch.Tensor, feat_tgt: torch.Tensor, R: 
     vs, ft, Rc, gs = (t.detach().contiguous() for t in (vol_src, feat_tgt, R, grad_scores))
     lib = _lib.load()
     nbytes = lib.ahv_score_hypotheses_backward_workspace_bytes(B, N)
-    ws = torch.empty((max(nbytes, 16) // 4,), dtype=torch.float32, device=dev)
+    saved = workspace is not None
+    if saved:
+        if workspace.device != dev or workspace.dtype != torch.float32 or workspace.numel() * 4 < nbytes:
+            raise RuntimeError("workspace is not the one score_hypotheses_train returned for these shapes")
+        ws = workspace
+    else:
+        ws = torch.empty((max(nbytes, 16) // 4,), dtype=torch.float32, device=dev)
     g_vol = torch.empty((B,) + _VOL, dtype=torch.float32, device=dev)
     g_ft = torch.empty((B, 32, 64), dtype=torch.float32, device=dev)
     g_W1 = torch.empty((32, 384), dtype=torch.float32, device=dev)
     g_W2 = torch.empty((32, 32), dtype=torch.float32, device=dev)
     g_b2 = torch.empty((32,), dtype=torch.float32, device=dev)
-    _call(dev, "ahv_score_hypotheses_backward_f32", vs.data_ptr(), ft.data_ptr(), Rc.data_ptr(), rstride,
+    _call(dev, "ahv_score_hypotheses_backward_saved_f32" if saved else "ahv_score_hypotheses_backward_f32", vs.data_ptr(),
+          ft.data_ptr(), Rc.data_ptr(), rstride,
           W1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), B, N, gs.data_ptr(), ws.data_ptr(), ws.numel() * 4,
           g_vol.data_ptr(), g_ft.data_ptr(), g_W1.data_ptr(), g_W2.data_ptr(), g_b2.data_ptr())
     return g_vol, g_ft, g_W1, g_W2, g_b2
@@ -380,9 +414,20 @@ class _ScoreFn(torch.autograd.Function):
     """Differentiable fused scorer: forward = one fused launch, backward = ``score_hypotheses_backward``."""
 
     @staticmethod
-    def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2, n_offset=0, best_key=None, reset_best=None, split_f16=None):
-        scores, key = _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, True, best_key, reset_best,
-                                               split_f16, None)
+    def forward(ctx, vol_src, feat_tgt, R, W1, W2, b2, n_offset=0, best_key=None, reset_best=None, split_f16=None, need_key=True):
+        ctx.ws = None
+        plain = n_offset == 0 and best_key is None and not split_f16 and (split_f16 is not None or not _SPLIT_F16.get())
+        if plain:
+            # the training forward: the same scores, and the pre-activations kept for the backward (no recompute there);
+            # the arg-max key of the inference launch is not produced -- callers of the differentiable form use the scores
+            scores, ctx.ws = score_hypotheses_train(vol_src, feat_tgt, R, W1, W2, b2)
+            if need_key:   # (score_hypotheses' contract: the packed arg-max key beside the scores)
+                key = argmax(scores, return_key=True)
+            else:
+                key = torch.full((vol_src.shape[0],), _lib.AHV_KEY_EMPTY, dtype=torch.int64, device=scores.device)
+        else:
+            scores, key = _score_hypotheses_nograd(vol_src, feat_tgt, R, W1, W2, b2, n_offset, True, best_key, reset_best,
+                                                   split_f16, None)
         ctx.save_for_backward(vol_src, feat_tgt, R, W1, W2, b2)
         ctx.mark_non_differentiable(key)
         return scores, key
@@ -390,15 +435,16 @@ class _ScoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_scores, _grad_key):
         vol_src, feat_tgt, R, W1, W2, b2 = ctx.saved_tensors
+        ws, ctx.ws = ctx.ws, None   # one backward per workspace: a second one (retain_graph) recomputes the forward
         g_vol, g_ft, g_W1, g_W2, g_b2 = score_hypotheses_backward(vol_src, feat_tgt, R, W1, W2, b2,
-                                                                  grad_scores.contiguous())
+                                                                  grad_scores.contiguous(), workspace=ws)
         return (g_vol, g_ft, None, g_W1.reshape(W1.shape), g_W2.reshape(W2.shape), g_b2.reshape(b2.shape),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def score_hypotheses_autograd(vol_src, feat_tgt, R, W1, W2, b2) -> torch.Tensor:
     """``scores (B,N)`` with autograd support for vol_src, feat_tgt and the head weights (training path)."""
-    return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2)[0]
+    return _ScoreFn.apply(vol_src, feat_tgt, R, W1, W2, b2, 0, None, None, None, False)[0]
 
 
 class _Forward3d2dFn(torch.autograd.Function):

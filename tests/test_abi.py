@@ -36,7 +36,7 @@ def test_header_symbols_are_exported(lib, ahv):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.ahv_abi_version() == (2 << 16) | 2  # 2.2: non-finite inputs + bit-identical teams in the contract, diag header split
+    assert lib.ahv_abi_version() == (2 << 16) | 3  # 2.3: the training pair (train forward + saved-u backward)
     assert isinstance(lib.ahv_last_error(), bytes)
 
 

@@ -130,6 +130,57 @@ def test_backward_matches_fp64_autograd(ops, ahv, dev, B, N, per_sample):
     assert all(v < GRAD_RTOL for v in errs.values()), (errs, n_amb)
 
 
+@pytest.mark.parametrize("B,N,per_sample", [(1, 1, False), (2, 9, True), (3, 130, True), (2, 1100, False), (5, 2048, True)])
+def test_saved_preactivations_backward_equals_the_recomputing_one(ops, ahv, dev, B, N, per_sample):
+    """The training pair (ABI 2.3): ahv_score_hypotheses_train_f32 leaves every hypothesis' pre-activations in the workspace,
+    ahv_score_hypotheses_backward_saved_f32 reads them instead of recomputing rotate_volume + the first projection.  Same
+    scores as the inference launch bit for bit (the same accumulation chain), and the five gradients of the recomputing
+    backward -- which the other tests hold to the fp64 reference -- to rounding (the head's arithmetic is the same code on
+    the same values; the sums across hypotheses use float atomics in both)."""
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, B, N, per_sample, 31 + B + N)
+    scores, ws = ops.score_hypotheses_train(vs, ft, R, W1, W2, b2)
+    ref_scores, _ = ops.score_hypotheses(vs, ft, R, W1, W2, b2)
+    assert torch.equal(scores, ref_scores)
+    want = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs, workspace=ws)
+    for a, b, name in zip(got, want, ("vol_src", "feat_tgt", "W1", "W2", "b2")):
+        assert relerr(a, b.double()) < 2e-6, (name, relerr(a, b.double()))
+
+
+def test_autograd_function_uses_the_saved_forward_and_survives_a_second_backward(ops, ahv, dev):
+    """ops.score_hypotheses_autograd / ops.score_hypotheses under autograd run the training forward; the workspace serves ONE
+    backward, a second one (retain_graph) falls back on the recomputing kernels -- same gradients either way; the key that
+    score_hypotheses returns beside differentiable scores is still torch.max's."""
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, 2, 300, True, 91)
+    leaves = [t.clone().requires_grad_(True) for t in (vs, ft, W1, W2, b2)]
+    s = ops.score_hypotheses_autograd(leaves[0], leaves[1], R, leaves[2], leaves[3], leaves[4])
+    g1 = torch.autograd.grad(s, leaves, grad_outputs=gs, retain_graph=True)
+    g2 = torch.autograd.grad(s, leaves, grad_outputs=gs)
+    want = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    for a, b, c in zip(g1, g2, want):
+        assert relerr(a, c.reshape(a.shape).double()) < 2e-6 and relerr(b, c.reshape(b.shape).double()) < 2e-6
+    s2, key = ops.score_hypotheses(leaves[0], leaves[1], R, leaves[2], leaves[3], leaves[4])
+    assert s2.requires_grad and torch.equal(s2.detach(), s.detach())
+    val, idx = ops.unpack_best(key)
+    tv, ti = torch.max(s2.detach(), dim=1)
+    assert torch.equal(idx, ti) and torch.equal(val, tv)
+
+
+def test_saved_backward_poisons_a_non_finite_sample_only(ops, ahv, dev):
+    """A sample with a NaN voxel goes through the forward's exact path, which keeps no accumulators: its saved pre-activations
+    are NaN and so are its gradients; the finite sample beside it is untouched."""
+    vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, 2, 200, True, 92)
+    clean = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
+    bad = vs.clone()
+    bad[0, 3, 2, 5, 1] = float("nan")
+    scores, ws = ops.score_hypotheses_train(bad, ft, R, W1, W2, b2)
+    ref_scores, _ = ops.score_hypotheses(bad, ft, R, W1, W2, b2)
+    assert torch.equal(torch.isnan(scores), torch.isnan(ref_scores)) and torch.equal(scores[1], ref_scores[1])
+    got = ops.score_hypotheses_backward(bad, ft, R, W1, W2, b2, gs, workspace=ws)
+    assert torch.isnan(got[0][0]).float().mean().item() > 0.9 and torch.isfinite(got[0][1]).all()
+    assert relerr(got[0][1], clean[0][1].double()) < 2e-6
+
+
 def test_backward_at_integer_sample_coordinates(ops, ahv, dev):
     """identity and the 24 cube rotations put EVERY sample coordinate exactly on an integer -- where the forward's
     point-mirror gather (quarters 3 and 2 reuse the set-up of 0 and 1, csrc/ahv_dual.h hat_mirror) picks the neighbouring

@@ -292,10 +292,23 @@ if "train9000" in only:
     lib = ahv._lib.load()
     ms_fwd = timeit(lambda: ops.score_hypotheses(vs9, ft9, R9, W1, W2, b2), 5)
     ms_bwd = timeit(lambda: ops.score_hypotheses_backward(vs9, ft9, R9, W1, W2, b2, gs9), 5)
+    # the training pair (ABI 2.3): a forward that keeps the pre-activations + a backward that does not recompute them
+    ms_fwd_train = timeit(lambda: ops.score_hypotheses_train(vs9, ft9, R9, W1, W2, b2), 5)
+    def train_pair():
+        _, ws9 = ops.score_hypotheses_train(vs9, ft9, R9, W1, W2, b2)
+        ops.score_hypotheses_backward(vs9, ft9, R9, W1, W2, b2, gs9, workspace=ws9)
+    ms_pair = timeit(train_pair, 5)
     print(json.dumps({"config": "training scorer step, CO3D training size", "B": B, "N": N, "hip_fwd_only_ms": ms_fwd,
                       "hip_bwd_only_ms": ms_bwd, "hyp_per_s_fwd_bwd": B * N / (ms_fwd + ms_bwd) * 1e3,
                       "fwd_frac_fp32_mfma_peak": B * N * FLOPS / ms_fwd / 1e9 / 157.3,
                       "bwd_tflops": B * N * FLOPS_BWD / ms_bwd / 1e9, "roofline": bwd_roofline(B * N, ms_bwd),
+                      "training_pair": {"fwd_keeping_preactivations_ms": ms_fwd_train, "fwd_plus_bwd_ms": ms_pair,
+                                        "bwd_saved_preactivations_ms": ms_pair - ms_fwd_train,
+                                        "against_recomputing_pair_ms": ms_fwd + ms_bwd,
+                                        "algorithmic_flops_per_hypothesis_bwd": FLOPS_BWD - FLOPS,
+                                        "bwd_frac_fp32_mfma_peak": B * N * (FLOPS_BWD - FLOPS) / (ms_pair - ms_fwd_train) / 1e9 / PEAK,
+                                        "note": "the backward without the forward recompute does 3 670 016 FLOP per hypothesis "
+                                                "(dW2 + dr + gather + dW1 + dX + scatter) and moves 16 KB more per hypothesis"},
                       "backward_workspace_GB": lib.ahv_score_hypotheses_backward_workspace_bytes(B, N) / 1e9}))
 
 if not only or "trainstep" in only:
