@@ -412,7 +412,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kern
                         du[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][0], dv[m2][t][r2], du[0][t], 0, 0, 0);
                         du[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][1], dv[m2][t][r2], du[1][t], 0, 0, 0);
                     }
-            float* dst = du_ws + ((long)b * N + h) * 2048;
+            // du leaves through the wave's LDS image as 16-byte rows (row-major [32][64], what kernels 2a / 2b read): written
+            // straight from the accumulator layout it is 32 four-byte stores per lane over four half cache lines each, and
+            // this kernel -- 16 KB of HBM traffic per hypothesis and little else -- ran at 2.1 TB/s
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -421,10 +423,20 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kern
                     for (int r = 0; r < 4; ++r) {
                         // (u != u: the forward's exact path saved NaN for a sample with a non-finite voxel or weight)
                         const float x = acc[m][t][r] > 0.0f ? du[m][t][r] : (acc[m][t][r] == acc[m][t][r] ? 0.0f : acc[m][t][r]);
-                        dst[(16 * m + 4 * kq + r) * 64 + 16 * t + n] = x;
+                        buf[dimg(16 * m + 4 * kq + r, 16 * t + n)] = x;
                         // max |du| of the sample (kernel 2b sizes its fixed-point scale with it); NaN / inf poison it
                         du_amax = (x == x) ? fmaxf(du_amax, fabsf(x)) : __builtin_inff();
                     }
+            wave_lds_fence();
+            {
+                float* dst = du_ws + ((long)b * N + h) * 2048;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = (j * 64 + lane) * 4;   // linear index into [32][64]: row q >> 6, four positions from q & 63
+                    *reinterpret_cast<f32x4*>(dst + q) = *reinterpret_cast<const f32x4*>(&buf[dimg(q >> 6, q & 63)]);
+                }
+            }
+            wave_lds_fence();
 
             // dW2 += dv relu(u)^T: the contraction runs over positions, so both operands go through the
             // wave's LDS image once (dv as A, relu(u) as B).
