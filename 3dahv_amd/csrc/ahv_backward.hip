@@ -28,6 +28,16 @@ namespace ahv {
 
 constexpr int kBwdThreads = 256;  // 4 waves, one per SIMD: 512 registers per wave
 
+// u / du of one hypothesis in the workspace (2 048 floats): the MFMA accumulator layout of the scorer, tile by tile --
+//   word(o, pos) = ((pos >> 4) * 2 + (o >> 4)) * 256 + (((o >> 2) & 3) * 16 + (pos & 15)) * 4 + (o & 3)
+// i.e. [t][m][lane = 16 kq + n][r] for o = 16 m + 4 kq + r, pos = 16 t + n.  A wave writes and reads a (t, m) fragment with
+// one 16-byte access per lane, the training forward's u and the head kernel's du share the words (du overwrites u tile
+// by tile), and a lane that wants du[4 sp + kq][16 t + n] (kernels 2b) finds the 64 lanes' words in one 256-byte run.
+__device__ __forceinline__ int du_word(int o, int pos)
+{
+    return ((pos >> 4) * 2 + (o >> 4)) * 256 + (((o >> 2) & 3) * 16 + (pos & 15)) * 4 + (o & 3);
+}
+
 // du image in LDS: du[o][pos] at o*64 + (pos ^ ((o & 7) << 2)).  The XOR keeps aligned groups of four
 // positions together (float4 fills) and spreads rows over banks for the transposed reads (k = pos).
 __device__ __forceinline__ int dimg(int o, int pos) { return o * 64 + (pos ^ ((o & 7) << 2)); }
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = acc[m][t][r] > 0.0f ? du[m][t][r] : 0.0f;
-                        dst[(16 * m + 4 * kq + r) * 64 + 16 * t + n] = x;
+                        dst[((t * 2 + m) * 64 + lane) * 4 + r] = x;
                         // max |du| of the sample (kernel 2b sizes its fixed-point scale with it); NaN / inf poison it
                         du_amax = (x == x) ? fmaxf(du_amax, fabsf(x)) : __builtin_inff();
                     }
@@ -284,20 +294,31 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel 1', round 6: the same backward through score / normalise / GEMM2 / ReLU WITHOUT the forward recompute -- u comes from
-// the workspace, where the training forward (ahv_score_hypotheses_train_f32) left it.  That removes gather + GEMM1 (832 of 960
-// MFMAs and ~900 of 2 547 vector instructions per hypothesis) from the backward for 8 KB more HBM traffic per hypothesis in each
-// direction; what is left of this kernel is bound by those 16 KB.
+// the workspace, where the training forward (ahv_score_hypotheses_train_f32) left it in the wave's fragment layout
+// [m][t][lane][r].  That removes gather + GEMM1 (832 of 960 MFMAs and ~900 of 2 547 vector instructions per hypothesis) from
+// the backward for 8 KB more HBM traffic per hypothesis in each direction.
+// Everything here is independent per position tile t (16 of the 64 positions): a hypothesis is walked tile by tile with
+// ~90 transient registers (the whole-hypothesis form of kernel 1 keeps 6 x 32 alive and ran one wave per SIMD at 506
+// registers: 2.2 ms at B = 32 x 9 000 for 16 KB of traffic and 192 MFMAs per hypothesis).  The per-sample state that would
+// need a dynamic register index moves to LDS: the target fragments (shared, read-only) and the wave's d feat_tgt accumulator
+// (lane-linear 16-byte read-modify-writes).  512 threads: two waves per SIMD.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kernel(
+constexpr int kSavedThreads = 512;
+
+__global__ __launch_bounds__(kSavedThreads, 2) void score_backward_head_saved_kernel(
     const float* __restrict__ feat_tgt, const float* __restrict__ W2, const float* __restrict__ b2,
     int B, long N, const float* __restrict__ grad_scores, float* __restrict__ du_ws,
     unsigned* __restrict__ du_max_bits, float* __restrict__ grad_feat_tgt, float* __restrict__ grad_W2, float* __restrict__ grad_b2)
 {
-    __shared__ __attribute__((aligned(16))) float lds_q[4 * kQuarterFloats];
+    __shared__ __attribute__((aligned(16))) float lds_tg[4 * 2 * 64 * 4];        // target fragments [t][m2][lane][r]
+    __shared__ __attribute__((aligned(16))) float lds_dtg[8 * 4 * 2 * 64 * 4];   // per wave: d feat_tgt, same layout
+    __shared__ __attribute__((aligned(16))) float lds_tr[8 * 2 * 32 * 20];       // per wave: dv tile and relu(u) tile, [o][16 pos + 4 pad]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4, row = lane & 15;
-    float* buf = lds_q + wave * kQuarterFloats;
+    float* dtg = lds_dtg + wave * (4 * 2 * 64 * 4) + lane * 4;
+    float* trd = lds_tr + wave * (2 * 32 * 20);   // dv tile
+    float* tru = trd + 32 * 20;                   // relu(u) tile
 
     DualFrags f;
     load_dual_frags(f, W2, b2, lane);
@@ -308,7 +329,6 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kern
         for (int r2 = 0; r2 < 4; ++r2)
 #pragma unroll
             for (int m = 0; m < 2; ++m) a2t[m2][r2][m] = W2[(16 * m2 + 4 * kq + r2) * 32 + 16 * m + row];
-
     f32x4 dW2[2][2];   // [mt][nt][r]: dW2[16 mt + 4 kq + r][16 nt + n]
     float db2p[2][4];  // [m2][r]: partial over this lane's columns of db2[16 m2 + 4 kq + r]
 #pragma unroll
@@ -320,155 +340,134 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kern
 #pragma unroll
         for (int r = 0; r < 4; ++r) db2p[i][r] = 0.0f;
 
-    const long hstep = (long)gridDim.x * 4;
+    const long hstep = (long)gridDim.x * 8;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
-        f32x4 tg[4][2], dtg[4][2];
-        {
+        __syncthreads();
+        {   // target fragments of the sample: tg[t][m2][r] = ft[16 m2 + 4 kq + r][16 t + n], one (t, m2) per wave
             const float* ft = feat_tgt + (long)b * (32 * 64);
+            const int t = wave >> 1, m2 = wave & 1;
+            f32x4 x;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 4; ++r) x[r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n];
+            *reinterpret_cast<f32x4*>(lds_tg + ((t * 2 + m2) * 64 + lane) * 4) = x;
 #pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        tg[t][m2][r] = ft[(16 * m2 + 4 * kq + r) * 64 + 16 * t + n];
-                        dtg[t][m2][r] = 0.0f;
-                    }
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(dtg + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        __syncthreads();
         float du_amax = 0.0f;
         long h = (long)wave * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
-        // u of the forward (score_hypotheses_train_kernel): [m][t][lane][r] per hypothesis, eight 16-byte loads per lane; the
-        // next hypothesis's travel while this one is processed.  du overwrites the same 8 KB (row-major [32][64], what kernels
-        // 2a / 2b read): every load of a hypothesis is consumed before its first store is issued.
-        f32x4 un[2][4];
+        // u of (hypothesis, tile): two 16-byte loads per lane, requested a tile ahead (the last tile requests the next
+        // hypothesis' first).  du overwrites u tile by tile, word for word (du_word): a tile's loads are consumed before its
+        // stores are issued, and the other tiles live in other words.
+        f32x4 un0 = f32x4{0.f, 0.f, 0.f, 0.f}, un1 = un0;
         if (h < N) {
             const float* up = du_ws + ((long)b * N + h) * 2048 + lane * 4;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) un[m][t] = *reinterpret_cast<const f32x4*>(up + (m * 4 + t) * 256);
+            un0 = *reinterpret_cast<const f32x4*>(up);
+            un1 = *reinterpret_cast<const f32x4*>(up + 256);
         }
         for (; h < N; h += hstep) {
-            f32x4 acc[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[m][t] = un[m][t];
-            if (h + hstep < N) {
-                const float* up = du_ws + ((long)b * N + h + hstep) * 2048 + lane * 4;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) un[m][t] = *reinterpret_cast<const f32x4*>(up + (m * 4 + t) * 256);
-            }
-            f32x4 v[2][4];
-            gemm2_dual(v, acc, f);
-
-            // score = 1/64 sum_pos <v / max(|v|, eps), tg>; F.normalize's clamp passes no gradient to the norm
-            // when it is below eps
             const float g = grad_scores[(long)b * N + h] * (1.0f / 64.0f);
-            f32x4 dv[2][4];
-#pragma unroll
+            float* dst = du_ws + ((long)b * N + h) * 2048;
+#pragma unroll 1
             for (int t = 0; t < 4; ++t) {
+                const f32x4 a0 = un0, a1 = un1;   // u[16 m + 4 kq + r][16 t + n], m = 0 / 1
+                {
+                    const bool last = t == 3;
+                    const long hn = last ? (h + hstep < N ? h + hstep : h) : h;
+                    const float* up = du_ws + ((long)b * N + hn) * 2048 + lane * 4 + (last ? 0 : t + 1) * 512;
+                    if (!last || hn != h) {   // (never re-read this hypothesis' first tile: it already holds du)
+                        un0 = *reinterpret_cast<const f32x4*>(up);
+                        un1 = *reinterpret_cast<const f32x4*>(up + 256);
+                    }
+                }
+                // v = W2 relu(u) + b2 for this tile
+                f32x4 v0 = f.bias[0], v1 = f.bias[1];
+                const f32x4 ru0 = relu4(a0), ru1 = relu4(a1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[0][r][0], ru0[r], v0, 0, 0, 0);
+                    v1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[0][r][1], ru0[r], v1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[1][r][0], ru1[r], v0, 0, 0, 0);
+                    v1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2[1][r][1], ru1[r], v1, 0, 0, 0);
+                }
+                // score = 1/64 sum_pos <v / max(|v|, eps), tg>; F.normalize's clamp passes no gradient to the norm below eps
+                const f32x4 tg0 = *reinterpret_cast<const f32x4*>(lds_tg + ((t * 2 + 0) * 64 + lane) * 4);
+                const f32x4 tg1 = *reinterpret_cast<const f32x4*>(lds_tg + ((t * 2 + 1) * 64 + lane) * 4);
                 float ss = 0.0f, dt = 0.0f;
 #pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ss += v[m2][t][r] * v[m2][t][r];
-                        dt += v[m2][t][r] * tg[t][m2][r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    ss += v0[r] * v0[r] + v1[r] * v1[r];
+                    dt += v0[r] * tg0[r] + v1[r] * tg1[r];
+                }
                 ss += __shfl_xor(ss, 16, 64); dt += __shfl_xor(dt, 16, 64);
                 ss += __shfl_xor(ss, 32, 64); dt += __shfl_xor(dt, 32, 64);
                 const float nrm = sqrtf(ss);
                 const bool clamped = nrm < 1e-12f;
                 const float inv = 1.0f / fmaxf(nrm, 1e-12f);
                 const float c3 = clamped ? 0.0f : dt * inv * inv * inv;
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dv[m2][t][r] = g * (tg[t][m2][r] * inv - c3 * v[m2][t][r]);
-                        dtg[t][m2][r] += g * inv * v[m2][t][r];
-                    }
-            }
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) db2p[m2][r] += dv[m2][0][r] + dv[m2][1][r] + dv[m2][2][r] + dv[m2][3][r];
-
-            // dr = W2^T dv (accumulator registers of dv are the B operand), du = dr where u > 0
-            f32x4 du[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) du[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                for (int r2 = 0; r2 < 4; ++r2)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        du[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][0], dv[m2][t][r2], du[0][t], 0, 0, 0);
-                        du[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[m2][r2][1], dv[m2][t][r2], du[1][t], 0, 0, 0);
-                    }
-            // du leaves through the wave's LDS image as 16-byte rows (row-major [32][64], what kernels 2a / 2b read): written
-            // straight from the accumulator layout it is 32 four-byte stores per lane over four half cache lines each, and
-            // this kernel -- 16 KB of HBM traffic per hypothesis and little else -- ran at 2.1 TB/s
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
+                f32x4 dv0, dv1;
+                {
+                    f32x4 d0 = *reinterpret_cast<const f32x4*>(dtg + (t * 2 + 0) * 256);
+                    f32x4 d1 = *reinterpret_cast<const f32x4*>(dtg + (t * 2 + 1) * 256);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        // (u != u: the forward's exact path saved NaN for a sample with a non-finite voxel or weight)
-                        const float x = acc[m][t][r] > 0.0f ? du[m][t][r] : (acc[m][t][r] == acc[m][t][r] ? 0.0f : acc[m][t][r]);
-                        buf[dimg(16 * m + 4 * kq + r, 16 * t + n)] = x;
-                        // max |du| of the sample (kernel 2b sizes its fixed-point scale with it); NaN / inf poison it
-                        du_amax = (x == x) ? fmaxf(du_amax, fabsf(x)) : __builtin_inff();
+                        dv0[r] = g * (tg0[r] * inv - c3 * v0[r]);
+                        dv1[r] = g * (tg1[r] * inv - c3 * v1[r]);
+                        d0[r] += g * inv * v0[r];
+                        d1[r] += g * inv * v1[r];
+                        db2p[0][r] += dv0[r];
+                        db2p[1][r] += dv1[r];
                     }
-            wave_lds_fence();
-            {
-                float* dst = du_ws + ((long)b * N + h) * 2048;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = (j * 64 + lane) * 4;   // linear index into [32][64]: row q >> 6, four positions from q & 63
-                    *reinterpret_cast<f32x4*>(dst + q) = *reinterpret_cast<const f32x4*>(&buf[dimg(q >> 6, q & 63)]);
+                    *reinterpret_cast<f32x4*>(dtg + (t * 2 + 0) * 256) = d0;
+                    *reinterpret_cast<f32x4*>(dtg + (t * 2 + 1) * 256) = d1;
                 }
+                // dr = W2^T dv (the accumulator registers of dv are the B operand), du = dr where u > 0
+                f32x4 du0 = f32x4{0.f, 0.f, 0.f, 0.f}, du1 = du0;
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2) {
+                    du0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[0][r2][0], dv0[r2], du0, 0, 0, 0);
+                    du1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[0][r2][1], dv0[r2], du1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2) {
+                    du0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[1][r2][0], dv1[r2], du0, 0, 0, 0);
+                    du1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2t[1][r2][1], dv1[r2], du1, 0, 0, 0);
+                }
+                f32x4 x0, x1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (u != u: the forward's exact path saved NaN for a sample with a non-finite voxel or weight)
+                    x0[r] = a0[r] > 0.0f ? du0[r] : (a0[r] == a0[r] ? 0.0f : a0[r]);
+                    x1[r] = a1[r] > 0.0f ? du1[r] : (a1[r] == a1[r] ? 0.0f : a1[r]);
+                    // max |du| of the sample (kernel 2b's LDS-atomic form sizes its fixed-point scale with it); NaN / inf poison it
+                    du_amax = (x0[r] == x0[r]) ? fmaxf(du_amax, fabsf(x0[r])) : __builtin_inff();
+                    du_amax = (x1[r] == x1[r]) ? fmaxf(du_amax, fabsf(x1[r])) : __builtin_inff();
+                }
+                *reinterpret_cast<f32x4*>(dst + t * 512 + lane * 4) = x0;        // du over the tile's u, same words
+                *reinterpret_cast<f32x4*>(dst + t * 512 + 256 + lane * 4) = x1;
+                // dW2 += dv relu(u)^T over the tile's 16 positions: both operands through the wave's LDS tiles [o][pos]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    trd[(4 * kq + r) * 20 + n] = dv0[r];
+                    trd[(16 + 4 * kq + r) * 20 + n] = dv1[r];
+                    tru[(4 * kq + r) * 20 + n] = ru0[r];
+                    tru[(16 + 4 * kq + r) * 20 + n] = ru1[r];
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {   // k-step: positions 4 sp + kq
+                    const float av0 = trd[row * 20 + 4 * sp + kq], av1 = trd[(16 + row) * 20 + 4 * sp + kq];
+                    const float bv0 = tru[n * 20 + 4 * sp + kq], bv1 = tru[(16 + n) * 20 + 4 * sp + kq];
+                    dW2[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0, dW2[0][0], 0, 0, 0);
+                    dW2[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv1, dW2[0][1], 0, 0, 0);
+                    dW2[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv0, dW2[1][0], 0, 0, 0);
+                    dW2[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1, dW2[1][1], 0, 0, 0);
+                }
+                wave_lds_fence();
             }
-            wave_lds_fence();
-
-            // dW2 += dv relu(u)^T: the contraction runs over positions, so both operands go through the
-            // wave's LDS image once (dv as A, relu(u) as B).
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) buf[dimg(16 * m2 + 4 * kq + r, 16 * t + n)] = dv[m2][t][r];
-            wave_lds_fence();
-            float av[2][16];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int s = 0; s < 16; ++s) av[mt][s] = buf[dimg(16 * mt + row, 4 * s + kq)];
-            wave_lds_fence();
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) buf[dimg(16 * m + 4 * kq + r, 16 * t + n)] = fmaxf(acc[m][t][r], 0.0f);
-            wave_lds_fence();
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const float bv = buf[dimg(16 * nt + n, 4 * s + kq)];
-                    dW2[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][s], bv, dW2[0][nt], 0, 0, 0);
-                    dW2[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][s], bv, dW2[1][nt], 0, 0, 0);
-                }
-            wave_lds_fence();
         }
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) du_amax = fmaxf(du_amax, __shfl_xor(du_amax, sft, 64));
@@ -477,9 +476,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kern
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dtg + (t * 2 + m2) * 256);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) global_add(gft + (16 * m2 + 4 * kq + r) * 64 + 16 * t + n, dtg[t][m2][r]);
+                for (int r = 0; r < 4; ++r) global_add(gft + (16 * m2 + 4 * kq + r) * 64 + 16 * t + n, d[r]);
+            }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -512,31 +513,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_saved_kern
 // (one address register, immediate offsets) and the MFMA operand reads are at worst 2-way bank conflicts:
 //   X[c][voxel = a0*64 + b*8 + e], kXwStride = 129 floats per channel plane (odd: the z slab's B operand, 16 lanes =
 //   16 channels of one voxel, lands on 16 different banks);
-//   du[o][pos], kDuStride = 68 floats per row (multiple of 4: the image is filled with aligned float4 stores).
+//   du[o][pos], kDuStride = 68 floats per row (rows 4 apart sit 16 banks apart: the fragment-wise fill is conflict-free).
 constexpr int kXwStride = 129;
 constexpr int kXwFloats = 16 * kXwStride;
 constexpr int kDuStride = 68;
 constexpr int kDuFloats = 32 * kDuStride;
-
-struct DuImage {  // one hypothesis's du (2048 floats) as the wave loads it: 8 coalesced float4 per lane
-    f32x4 v[8];
-};
-
-__device__ __forceinline__ void load_du_image(DuImage& d, const float* __restrict__ du_hyp, int lane)
-{
-    const f32x4* src = reinterpret_cast<const f32x4*>(du_hyp);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d.v[i] = __builtin_nontemporal_load(src + i * 64 + lane);
-}
-
-__device__ __forceinline__ void store_du_image(float* dbuf, const DuImage& d, int lane)
-{
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
-        *reinterpret_cast<f32x4*>(dbuf + o * kDuStride + pos) = d.v[i];
-    }
-}
 
 // Kernel 2a runs TWO waves per SIMD.  The 192 accumulator registers of dW1 are what kept it at one wave per
 // SIMD, where every LDS round trip and every VALU burst is exposed (the no-MFMA build of the one-wave kernel still
@@ -757,27 +738,26 @@ __global__ __launch_bounds__(kW1Threads, 2) void score_backward_w1_kernel(
         __syncthreads();
         const float* Rb = R + (long)b * r_batch_stride;
         long h = (long)slot * gridDim.x + xcd_residue(blockIdx.x, gridDim.x, gridDim.y);
-        // this wave's half of du: float4 chunks 4 role .. 4 role + 3 of the hypothesis's 2048 floats = rows 16 role ..
+        // this wave's half of du: the four fragments (t, m = role) of the hypothesis's 2048 floats (du_word) = rows 16 role ..
         f32x4 duh[4];
         if (h < N) {
             const f32x4* src = reinterpret_cast<const f32x4*>(du_ws + ((long)b * N + h) * 2048);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) duh[i] = __builtin_nontemporal_load(src + (4 * role + i) * 64 + lane);
+            for (int i = 0; i < 4; ++i) duh[i] = __builtin_nontemporal_load(src + (2 * i + role) * 64 + lane);
         }
         for (; h < N; h += hstep) {
             float Rm[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rm[i] = Rb[h * 9 + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // this hypothesis's du rows, requested one iteration ago
-                const int idx = 4 * (i * 64 + lane), o = idx >> 6, pos = idx & 63;
-                *reinterpret_cast<f32x4*>(dbuf + o * kDuStride + pos) = duh[i];
-            }
+            for (int i = 0; i < 4; ++i)  // this hypothesis's du rows, requested one iteration ago: fragment (t = i, m = role)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dbuf[(4 * kq + r) * kDuStride + 16 * i + n] = duh[i][r];  // banks 16 kq + n + const
             {   // the next hypothesis's travel meanwhile
                 const long hn = (h + hstep < N) ? h + hstep : h;
                 const f32x4* src = reinterpret_cast<const f32x4*>(du_ws + ((long)b * N + hn) * 2048);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) duh[i] = __builtin_nontemporal_load(src + (4 * role + i) * 64 + lane);
+                for (int i = 0; i < 4; ++i) duh[i] = __builtin_nontemporal_load(src + (2 * i + role) * 64 + lane);
             }
             GatherHyp gh;
             gather_hyp(gh, Rm, glane);
@@ -905,11 +885,12 @@ struct DuRegs {
 
 __device__ __forceinline__ void load_du_regs(DuRegs& d, const float* __restrict__ du_hyp, int lane)
 {
-    const float* p = du_hyp + (lane >> 4) * 64 + (lane & 15);
+    // o = 4 sp + kq = 16 m + 4 kq' + r  =>  m = sp >> 2, kq' = sp & 3, r = kq: word (2 t + m) * 256 + (16 (sp & 3) + n) * 4 + kq
+    const float* p = du_hyp + (lane & 15) * 4 + (lane >> 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) d.v[t][sp] = p[sp * 256 + 16 * t];
+        for (int sp = 0; sp < 8; ++sp) d.v[t][sp] = p[(2 * t + (sp >> 2)) * 256 + (sp & 3) * 64];
 }
 
 // Kernel 2b runs TWO waves per SIMD, split by CHANNEL: wave role r = wave / 4 owns channels 8 r .. 8 r + 7 of
@@ -1568,8 +1549,14 @@ hipError_t launch_score_backward(const float* vol_src, const float* feat_tgt, co
     if (gx < 1) gx = 1;
     const dim3 grid(gx, gy);
     if (saved_u)   // du_ws holds u of every hypothesis (the training forward); the head kernel turns it into du in place
-        hipLaunchKernelGGL(score_backward_head_saved_kernel, grid, dim3(kBwdThreads), 0, stream, feat_tgt, W2, b2, B, (long)N,
-                           grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2, grad_b2);
+    {
+        int gxs = num_cu / gy;                       // eight waves per workgroup, one hypothesis per wave and turn
+        const int64_t need8 = (N + 7) / 8;
+        if (gxs > need8) gxs = (int)need8;
+        if (gxs < 1) gxs = 1;
+        hipLaunchKernelGGL(score_backward_head_saved_kernel, dim3(gxs, gy), dim3(kSavedThreads), 0, stream, feat_tgt, W2, b2, B,
+                           (long)N, grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2, grad_b2);
+    }
     else
         hipLaunchKernelGGL(score_backward_head_kernel, grid, dim3(kBwdThreads), 0, stream, vol_src, feat_tgt, R,
                            (long)r_batch_stride, W1, W2, b2, B, (long)N, grad_scores, du_ws, du_max_bits, grad_feat_tgt, grad_W2,

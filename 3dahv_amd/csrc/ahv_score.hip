@@ -731,7 +731,7 @@ __device__ __forceinline__ void score_hypotheses_body(
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(uo + (m * 4 + t) * 256) = acc[m][t];
+                        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(uo + (t * 2 + m) * 256) = acc[m][t];
                 }
                 f32x4 v[2][4];
                 gemm2_dual(v, acc, f);

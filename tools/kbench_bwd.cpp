@@ -53,9 +53,9 @@ int main(int argc, char** argv)
     CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0));
     int gy = B < cu ? B : cu, gx = cu / gy;
     const dim3 grid(gx, gy);
-    hipEvent_t e[6];
+    hipEvent_t e[7];
     for (auto& x : e) CK(hipEventCreate(&x));
-    double t[4] = {0, 0, 0, 0};
+    double t[5] = {0, 0, 0, 0, 0};
     for (int it = -2; it < iters; ++it) {
         CK(hipMemsetAsync(gvol, 0, vol.size() * 4, 0)); CK(hipMemsetAsync(gft, 0, ft.size() * 4, 0));
         CK(hipMemsetAsync(gW1, 0, W1.size() * 4, 0)); CK(hipMemsetAsync(gW2, 0, 4096, 0)); CK(hipMemsetAsync(gb2, 0, 128, 0));
@@ -74,11 +74,19 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e[4], 0));
         hipLaunchKernelGGL(ahv::score_backward_volume_rmw_kernel, grid, dim3(ahv::kRmwThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, gvol2);
         CK(hipEventRecord(e[5], 0));
-        CK(hipEventSynchronize(e[5]));
+        {   // the training pair's head kernel (u from the workspace; for the clock any 8 KB per hypothesis will do: du stands in)
+            int gxs = cu / gy;
+            if (gxs > (N + 7) / 8) gxs = (int)((N + 7) / 8);
+            hipLaunchKernelGGL(ahv::score_backward_head_saved_kernel, dim3(gxs < 1 ? 1 : gxs, gy), dim3(ahv::kSavedThreads), 0, 0, dft, dW2, db2,
+                               B, N, dgs, dws, dmax, gft, gW2, gb2);
+        }
+        CK(hipEventRecord(e[6], 0));
+        CK(hipEventSynchronize(e[6]));
         CK(hipGetLastError());
         if (it >= 0) {
             for (int k = 0; k < 3; ++k) { float ms; CK(hipEventElapsedTime(&ms, e[k], e[k + 1])); t[k] += ms; }
             float ms; CK(hipEventElapsedTime(&ms, e[4], e[5])); t[3] += ms;
+            CK(hipEventElapsedTime(&ms, e[5], e[6])); t[4] += ms;
         }
     }
     std::vector<float> hv(vol.size()), hv2(vol.size());
@@ -105,5 +113,7 @@ int main(int argc, char** argv)
 #endif
     printf("           dV read-modify-write kernel %.3f ms  total with it %.3f ms   max |difference| / max |dV| = %.2e\n", t[3] / iters,
            (t[0] + t[1] + t[3]) / iters, md / mx);
+    printf("           head kernel of the training pair (u saved by the forward) %.3f ms  total with it %.3f ms\n", t[4] / iters,
+           (t[4] + t[1] + t[3]) / iters);
     return 0;
 }
