@@ -294,8 +294,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel 1', round 6: the same backward through score / normalise / GEMM2 / ReLU WITHOUT the forward recompute -- u comes from
-// the workspace, where the training forward (ahv_score_hypotheses_train_f32) left it in the wave's fragment layout
-// [m][t][lane][r].  That removes gather + GEMM1 (832 of 960 MFMAs and ~900 of 2 547 vector instructions per hypothesis) from
+// the workspace, where the training forward (ahv_score_hypotheses_train_f32) left it in the fragment layout
+// [t][m][lane][r] (du_word).  That removes gather + GEMM1 (832 of 960 MFMAs and ~900 of 2 547 vector instructions per hypothesis) from
 // the backward for 8 KB more HBM traffic per hypothesis in each direction.
 // Everything here is independent per position tile t (16 of the 64 positions): a hypothesis is walked tile by tile with
 // ~90 transient registers (the whole-hypothesis form of kernel 1 keeps 6 x 32 alive and ran one wave per SIMD at 506

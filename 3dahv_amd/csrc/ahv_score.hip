@@ -280,7 +280,7 @@ __device__ __attribute__((noinline)) key_t score_share_exact(const float* lds_sr
 
 // SAVE_U (round 6, the TRAINING forward: ahv_score_hypotheses_train_f32): every hypothesis also leaves its pre-activations
 // u = W1 slabs(rot(V, R_n)) -- the 32 accumulator registers GEMM1 ends with -- in `feat_tgt_out` (here: the u buffer), 8 KB per
-// hypothesis in the wave's own fragment layout [m][t][lane][r] (eight 16-byte stores per lane, 1 KB contiguous each).  The
+// hypothesis in the wave's own fragment layout [t][m][lane][r] (ahv_backward.hip::du_word) (eight 16-byte stores per lane, 1 KB contiguous each).  The
 // backward then reads them instead of recomputing gather + GEMM1 (ahv_backward.hip, score_backward_head_saved_kernel).
 template <bool SPLIT, bool TGT, bool C2F, bool SAVE_U = false>
 __device__ __forceinline__ void score_hypotheses_body(
