@@ -70,51 +70,39 @@ struct LinArgs {
 #endif
 };
 
-// GELU(g) = g/2 (1 + erf(g / sqrt 2)), exact-erf form (nn.GELU() default, attention.py:81-88), for a PAIR of values on the
-// packed fp32 pipe.  libdevice's erff is a branch between two polynomials (35 vector instructions per value behind
-// s_cbranch_execz: a 128 x 128 GEGLU tile spends as long in it as in 300 MFMAs, and fp32 MFMAs do not overlap VALU work on
-// gfx950); here both ranges of N. Juffa's single-precision erf (< 1 ulp each: |x| <= 0.9277 an odd polynomial, beyond it
-// 1 - exp(p(|x|)) with a two-term log2(e) so that v_exp_f32 sees an exact argument) are evaluated for both values with
-// v_pk_fma_f32 and selected: 18 instructions per value, no branch.  Differs from erff by <= 2 ulp (G7 measures 2e-6 either way).
+// GELU(g) = g Phi(g), exact form (nn.GELU() default = 0.5 g (1 + erf(g / sqrt 2)), attention.py:81-88), for a PAIR of values
+// on the packed fp32 pipe.  A 128 x 128 GEGLU tile ends in 64 of them per lane, and fp32 MFMAs do not overlap VALU work on
+// gfx950: libdevice's erff (a branch between two polynomials, 35 vector instructions per value) cost the FF-in launch as
+// much as 300 MFMAs per wave and tile, both ranges of a < 1-ulp erf on v_pk_fma_f32 (round 6, first form) 18 per value.
+// This form needs 8:  GELU(g) = max(g, 0) - |g| Phi(-|g|)  with  Phi(-t) = exp2(p(t)),  p(t) = -1 + c1 t + ... + c8 t^8
+// -- log2 of the normal tail is smooth on t >= 0, so ONE polynomial serves every t, c8 < 0 and p falls monotonically
+// beyond the fitted [0, 6], so large |g| need no clamp (exp2 -> 0), and nothing cancels: for g > 0 the tail is subtracted
+// from g, for g < 0 it IS the result (0.5 g (1 + erf) loses digits there).  tools/fit_gelu.py regenerates the
+// coefficients and the error with fp32 rounding after every operation: |gelu_pk - fp64| <= 2.6e-7 on [-300, 300], where
+// the expression torch evaluates in fp32 is off by up to 4.5e-7; relative to max(|GELU|, 1e-3) 1.7e-5 against 8.3e-5.
+// (g = +inf gives NaN here -- inf * 0 -- and inf there; LayerNorm turns either into NaN one launch later.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define AHV_PK(c) (f32x2{c, c})
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-__device__ __forceinline__ f32x2 erf_pk(f32x2 a)
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 g)
 {
-    const f32x2 t = __builtin_elementwise_abs(a);
-    const f32x2 s = a * a;
-    f32x2 r = pk_fma(AHV_PK(-1.72853470e-5f), t, AHV_PK(3.83197126e-4f));
-    const f32x2 u = pk_fma(AHV_PK(-3.88396438e-3f), t, AHV_PK(2.42546219e-2f));
-    r = pk_fma(r, s, u);
-    r = pk_fma(r, t, AHV_PK(-1.06777877e-1f));
-    r = pk_fma(r, t, AHV_PK(-6.34846687e-1f));
-    r = pk_fma(r, t, AHV_PK(-1.28717512e-1f));
-    r = pk_fma(r, t, -t);
-    const f32x2 ph = r * AHV_PK(1.44269502e+0f);                                              // r log2(e), head
-    const f32x2 pl = pk_fma(r, AHV_PK(1.44269502e+0f), -ph) + r * AHV_PK(1.92596299e-8f);     // ... and tail
-    f32x2 e = {__builtin_amdgcn_exp2f(ph[0]), __builtin_amdgcn_exp2f(ph[1])};
-    e = pk_fma(e, pl * AHV_PK(0.693147181f), e);
-    const f32x2 big = AHV_PK(1.0f) - e;
-    f32x2 q = AHV_PK(-5.96761703e-4f);
-    q = pk_fma(q, s, AHV_PK(4.99119423e-3f));
-    q = pk_fma(q, s, AHV_PK(-2.67681349e-2f));
-    q = pk_fma(q, s, AHV_PK(1.12819925e-1f));
-    q = pk_fma(q, s, AHV_PK(-3.76125336e-1f));
-    q = pk_fma(q, s, AHV_PK(1.28379166e-1f));
-    q = pk_fma(q, a, a);
-    f32x2 out;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) out[k] = t[k] > 0.927734375f ? __builtin_copysignf(big[k], a[k]) : q[k];
-    return out;
+    const f32x2 t = __builtin_elementwise_abs(g);
+    f32x2 r = pk_fma(AHV_PK(-2.357509857e-06f), t, AHV_PK(3.389861013e-05f));
+    r = pk_fma(r, t, AHV_PK(-1.614213979e-04f));
+    r = pk_fma(r, t, AHV_PK(-1.932584128e-04f));
+    r = pk_fma(r, t, AHV_PK(7.131781429e-03f));
+    r = pk_fma(r, t, AHV_PK(-5.253926665e-02f));
+    r = pk_fma(r, t, AHV_PK(-4.591956735e-01f));
+    r = pk_fma(r, t, AHV_PK(-1.151106358e+00f));
+    r = pk_fma(r, t, AHV_PK(-1.0f));
+    const f32x2 tail = {__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};   // Phi(-|g|)
+    const f32x2 pos = {fmaxf(g[0], 0.0f), fmaxf(g[1], 0.0f)};
+    return pk_fma(-t, tail, pos);
 }
 
 // (v0, v1) * GELU(g0, g1)
-__device__ __forceinline__ f32x2 geglu_pk(f32x2 v, f32x2 g)
-{
-    const f32x2 half = g * AHV_PK(0.5f);
-    return v * pk_fma(half, erf_pk(g * AHV_PK(0.70710678118654752f)), half);
-}
+__device__ __forceinline__ f32x2 geglu_pk(f32x2 v, f32x2 g) { return v * gelu_pk(g); }
 
 __device__ __forceinline__ float wave_sum(float x)
 {
