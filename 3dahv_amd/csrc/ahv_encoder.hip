@@ -628,6 +628,9 @@ struct AttnOutArgs {
     AttnOutProb p[2];
     int B;
     float scale;
+#ifdef AHV_ENC_PROBE
+    unsigned long long* stamps;
+#endif
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -644,6 +647,9 @@ struct AttnOutArgs {
 // (sample, head) with the K, V and W_out fragments it holds in registers (96 of the ~100 KB a workgroup reads; only Q changes
 // per tile, requested a tile ahead).  At B = 32 it changes nothing (see AHV_ATTN_QT at the launch): the launch is bound by the
 // dependent chain of a tile (16 + 16 + 64 MFMAs, two barriers, a softmax), not by its 100 MB of L2 reads.
+#ifndef AHV_ATTN_PAIR_MIN_WGS
+#define AHV_ATTN_PAIR_MIN_WGS 256
+#endif
 template <int QT>
 __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs a, int M)
 {
@@ -658,6 +664,7 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
     const float* q = pr.Q + (long)(b * 64 + it0 * 16 + c16) * pr.ldq + h * 64 + 4 * kq;
     const float* k = pr.K + (long)(b * 64 + w * 16 + c16) * pr.ldkv + h * 64 + 4 * kq;
     const float* v = pr.V + (long)(b * 64 + w * 16 + 4 * kq) * pr.ldkv + h * 64 + c16;
+    AHV_ENC_STAMP(0);
     // every operand is requested before the first MFMA
     f32x4 ka[4], qb[4], wf[4][4];
     float va[4][4];  // [r][dt]: V[16 w + 4 kq + r][16 dt + c16]
@@ -690,6 +697,7 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
         for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
             for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[ds][s], qb[ds][s], st, 0, 0, 0);
+        if (t == 0) AHV_ENC_STAMP(1);
         float m = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -710,7 +718,9 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
             sm[w][c16][0] = m;
             sm[w][c16][1] = l;
         }
+        if (t == 0) AHV_ENC_STAMP(2);
         __syncthreads();
+        if (t == 0) AHV_ENC_STAMP(3);
         float mg = -INFINITY;
 #pragma unroll
         for (int u = 0; u < 4; ++u) mg = fmaxf(mg, sm[u][c16][0]);
@@ -730,6 +740,7 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&so[w][dt][lane][0]) = ot[dt];
+        if (t == 0) AHV_ENC_STAMP(4);
         __syncthreads();   // (also: everybody has read sm, the next tile may overwrite it; so is rewritten behind the next tile's first barrier)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -749,13 +760,153 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
                 for (int nt = 0; nt < 4; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][dt][r], ot[dt][r], acc[nt], 0, 0, 0);
         float* out = pr.P + ((long)h * M + b * 64 + (it0 + t) * 16 + c16) * 256 + w * 64 + 4 * kq;
+        if (t == 0) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); AHV_ENC_STAMP(5); }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(out + nt * 16) = acc[nt];
+        if (t == QT - 1) AHV_ENC_STAMP(6);
         if (QT > 1) {
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) qb[ds] = qn[ds];
         }
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The same launch for MANY samples (B >= 32, round 6): one workgroup per (sample, head), wave w owns the 16 queries of
+// tile w against ALL 64 keys.  The in-kernel timeline of the kernel above at B = 32 (tools/kbench_enc.bin 32 --stamps) showed
+// what its 17.9 us are: 1 024 workgroups of ~150 registers run three per CU, so a quarter of them waits 11 us for a slot;
+// every workgroup spends its first 4.2 us waiting for 100 KB of operands (64 KB of them W_out, 64 MB over the grid for a
+// 256 KB matrix: ~20 TB/s of L2 traffic) and then 6.3 us in a chain of 96 MFMAs, two barriers and a softmax whose every
+// vector instruction queues behind the other waves' MFMAs.  Here a wave has whole softmax rows (no merge, no barrier before
+// the output projection), four independent MFMA chains in every phase (64 + 64 + 256 MFMAs per wave), and W_out's head
+// slice comes ONCE per workgroup, by LDS-DMA in fragment order ([n-tile][d-tile][lane][4]: lane-linear 16-byte reads),
+// while scores and softmax run: 256 workgroups at B = 32, one per CU, 25 MB of operand traffic.
+// Same math as above (softmax over the 64 keys in one pass: p = exp2((s - max) scale log2 e) / sum), same output: one
+// split-K slab per head.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOutArgs a, int M)
+{
+    __shared__ __attribute__((aligned(1024))) float wo[16 * 4 * 64 * 4];   // W_out[256][64 h .. 64 h + 63] as MFMA A fragments
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
+    const AttnOutProb pr = a.p[pi];
+    const int h = blockIdx.y;
+    const int c16 = lane & 15, kq = lane >> 4;
+    AHV_ENC_STAMP(0);
+    // 36 + 16 requests per lane, all of them 16 bytes: Q and K (scores), V, and -- behind the scores -- W_out.
+    // The head dimension is walked in two orders: d = 16 ds + 4 kq + s for Q K^T (a lane's four consecutive d are MFMA
+    // k-steps) and d = 16 kq + 4 r + dt for P V and the projection (a lane's four consecutive d are the four d-TILES: tile
+    // dt = {d : d mod 4 = dt}), so that V and W_out are 16-byte loads as well -- any order serves a contraction as long as
+    // both operands use it.
+    const float* q = pr.Q + (long)(b * 64 + 16 * w + c16) * pr.ldq + h * 64 + 4 * kq;
+    const float* k = pr.K + (long)(b * 64 + c16) * pr.ldkv + h * 64 + 4 * kq;
+    const float* v = pr.V + (long)(b * 64 + 4 * kq) * pr.ldkv + h * 64 + 4 * c16;
+    f32x4 qb[4], ka[4][4], va[4][4];   // va[j][r][dt] = V[key 16 j + 4 kq + r][d = 4 c16 + dt]
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+        qb[ds] = *reinterpret_cast<const f32x4*>(q + 16 * ds);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ka[j][ds] = *reinterpret_cast<const f32x4*>(k + (long)j * 16 * pr.ldkv + 16 * ds);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (issue order = the order the waits below count on)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) va[j][r] = *reinterpret_cast<const f32x4*>(v + (long)(16 * j + r) * pr.ldkv);
+    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the loads to their uses)
+    // S^T[key = 16 j + 4 kq + r][query = c16], four independent chains
+    f32x4 st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j][ds][sx], qb[ds][sx], st[j], 0, 0, 0);
+    // W_out fragments [n-tile][r][lane][dt] = W_out[16 nt + c16][64 h + 16 kq + 4 r + dt]; wave w fetches n-tiles 4 w .. 4 w + 3
+    // (16 pieces of 1 KiB).  Requested HERE, behind the scores and with V already in its registers: hipcc answers any wait for
+    // a plain load with vmcnt(0) while LDS-DMA pieces are in flight, so nothing may be waited for between this point and the
+    // barrier in front of the projection -- the pieces travel while softmax and P V run.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(va[j][r]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nt = 4 * w + i;
+            glds16(pr.Wo + (long)(16 * nt + c16) * 256 + h * 64 + 16 * kq + 4 * r, wo + ((nt * 4 + r) * 64 + lane) * 4);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    AHV_ENC_STAMP(1);
+    const float c = a.scale * 1.44269504088896341f;
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[j][r] *= c;
+            m = fmaxf(m, st[j][r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[j][r] = __builtin_amdgcn_exp2f(st[j][r] - m);
+            l += st[j][r];
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    AHV_ENC_STAMP(2);
+    // O^T[d = 4 (4 kq + r) + dt][query = c16] in tile dt
+    f32x4 ot[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = st[j][r] * inv;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j][r][dt], p, ot[dt], 0, 0, 0);
+        }
+    AHV_ENC_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);    // (MFMAs on registers would otherwise be free to move across the barrier)
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's W_out pieces are in LDS
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    AHV_ENC_STAMP(4);
+    // the head's output projection for this wave's 16 queries: D^T[n = 16 nt + 4 kq + r][query = c16], four n-tiles at a time;
+    // k-step (dt, r) contracts d = 16 kq + 4 r + dt: B = ot[dt][r], A = component dt of fragment (nt, r)
+    float* out = pr.P + ((long)h * M + b * 64 + 16 * w + c16) * 256 + 4 * kq;
+#pragma unroll
+    for (int ng = 0; ng < 4; ++ng) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wo + (((4 * ng + i) * 4 + r) * 64 + lane) * 4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][dt], ot[dt][r], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(out + 16 * (4 * ng + i)) = acc[i];
+    }
+    AHV_ENC_STAMP(6);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1087,7 +1238,12 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
 #ifndef AHV_ATTN_QT   // A/B knob (tools/kbench_enc): query tiles per workgroup at B >= 32.  Measured in round 6: 1 / 2 / 4 tiles per
 #define AHV_ATTN_QT 1   // workgroup give 1 964 / 1 958 / 1 960 us per forward (17.6-18.1 us per launch either way): not the re-reads
 #endif                  // of K, V and W_out bound this launch but the dependent chain of one tile; the one-tile form stays
-        if (B >= 32 && AHV_ATTN_QT == 4) AHV_ENC_LAUNCH(attention_heads_kernel<4>, dim3(2 * B, 1, 4), dim3(256), 0, s, ao, M);
+#ifdef AHV_ENC_PROBE
+        ao.stamps = AHV_ENC_STAMP_PTR;
+#endif
+        // from 256 (sample, head) pairs on: one workgroup per pair (attention_sample_head_kernel)
+        if (2 * B * 4 >= AHV_ATTN_PAIR_MIN_WGS) AHV_ENC_LAUNCH(attention_sample_head_kernel, dim3(2 * B, 4), dim3(256), 0, s, ao, M);
+        else if (B >= 32 && AHV_ATTN_QT == 4) AHV_ENC_LAUNCH(attention_heads_kernel<4>, dim3(2 * B, 1, 4), dim3(256), 0, s, ao, M);
         else if (B >= 32 && AHV_ATTN_QT == 2) AHV_ENC_LAUNCH(attention_heads_kernel<2>, dim3(2 * B, 2, 4), dim3(256), 0, s, ao, M);
         else AHV_ENC_LAUNCH(attention_heads_kernel<1>, dim3(2 * B, 4, 4), dim3(256), 0, s, ao, M);
         AHV_TRY(hipGetLastError(), "attention + out projection");

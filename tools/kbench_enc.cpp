@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -127,6 +128,27 @@ int main(int argc, char** argv)
             for (int g = 0; g < 1024; ++g) if (st[g * 8]) { if (st[g * 8] < t0) t0 = st[g * 8]; nwg = g + 1; }
             if (!nwg) continue;
             printf("launch %2d %-48s %d workgroups\n", k + 1, g_enc_probe_names[k], nwg);
+            if (strstr(g_enc_probe_names[k], "attention")) {   // slots: entry, scores, softmax share, merge barrier, O share, projection, exit
+                std::vector<double> ent, ex;
+                for (int g = 0; g < nwg; ++g) if (st[g * 8]) { ent.push_back((st[g * 8] - t0) * 0.01); ex.push_back((st[g * 8 + 6] - t0) * 0.01); }
+                std::sort(ent.begin(), ent.end()); std::sort(ex.begin(), ex.end());
+                printf("    entry time deciles:");
+                for (int d = 0; d <= 10; ++d) printf(" %.2f", ent[std::min(ent.size() - 1, d * ent.size() / 10)]);
+                printf("\n    exit time deciles: ");
+                for (int d = 0; d <= 10; ++d) printf(" %.2f", ex[std::min(ex.size() - 1, d * ex.size() / 10)]);
+                printf("\n");
+                static const char* an_tile[7] = {"entry", "scores done", "softmax share", "merge barrier", "O share done", "projection done", "exit"};
+                static const char* an_pair[7] = {"entry", "scores done", "softmax done", "P V done", "W_out in LDS", "-", "exit"};
+                const char* const* an = strstr(g_enc_probe_names[k], "sample_head") ? an_pair : an_tile;
+                double prevs = 0;
+                for (int sl = 1; sl < 7; ++sl) {
+                    double sum = 0; int c = 0;
+                    for (int g = 0; g < nwg; ++g) if (st[g * 8] && st[g * 8 + sl]) { sum += (double)(st[g * 8 + sl] - st[g * 8]) * 0.01; ++c; }
+                    if (c) printf("    %-16s +%6.2f us after entry (phase %5.2f)\n", an[sl], sum / c, sum / c - prevs);
+                    if (c) prevs = sum / c;
+                }
+                continue;
+            }
             for (int sl = 0; sl < 7; ++sl) {
                 double mn = 1e30, mx = 0, sum = 0; int c = 0;
                 for (int g = 0; g < nwg; ++g) {
