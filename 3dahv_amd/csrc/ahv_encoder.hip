@@ -773,20 +773,23 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
 
 // -------------------------------------------------------------------------------------------------
 // The same launch for MANY samples (B >= 32, round 6): one workgroup per (sample, head), wave w owns the 16 queries of
-// tile w against ALL 64 keys.  The in-kernel timeline of the kernel above at B = 32 (tools/kbench_enc.bin 32 --stamps) showed
-// what its 17.9 us are: 1 024 workgroups of ~150 registers run three per CU, so a quarter of them waits 11 us for a slot;
-// every workgroup spends its first 4.2 us waiting for 100 KB of operands (64 KB of them W_out, 64 MB over the grid for a
-// 256 KB matrix: ~20 TB/s of L2 traffic) and then 6.3 us in a chain of 96 MFMAs, two barriers and a softmax whose every
-// vector instruction queues behind the other waves' MFMAs.  Here a wave has whole softmax rows (no merge, no barrier before
-// the output projection), four independent MFMA chains in every phase (64 + 64 + 256 MFMAs per wave), and W_out's head
-// slice comes ONCE per workgroup, by LDS-DMA in fragment order ([n-tile][d-tile][lane][4]: lane-linear 16-byte reads),
-// while scores and softmax run: 256 workgroups at B = 32, one per CU, 25 MB of operand traffic.
+// tile w against ALL 64 keys.  The in-kernel timeline of the kernel above at B = 32 (tools/kbench_enc.bin 32 --stamps,
+// profiles/r06_attention_timeline_b32.txt) showed what its 17.9 us are: 1 024 workgroups of ~150 registers run three per CU,
+// so a quarter of them waits 11 us for a slot; every workgroup spends its first 4.2 us fetching 100 KB of operands with
+// fragment-shaped loads (64 KB of them W_out: 64 MB over the grid for a 256 KB matrix) and then 6.3 us in a chain of 96
+// MFMAs, two barriers and a softmax whose every vector instruction queues behind the other waves' MFMAs.  Here a wave has
+// whole softmax rows (no merge, no barrier between scores and P V), four independent MFMA chains in every phase (64 + 64 +
+// 256 MFMAs per wave), every operand arrives ONCE per workgroup as full 256-byte rows by LDS-DMA, and W_out's head slice
+// travels while softmax and P V run: 256 workgroups at B = 32, one per CU, 29 MB of operand traffic.
 // Same math as above (softmax over the 64 keys in one pass: p = exp2((s - max) scale log2 e) / sum), same output: one
 // split-K slab per head.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOutArgs a, int M)
 {
-    __shared__ __attribute__((aligned(1024))) float wo[16 * 4 * 64 * 4];   // W_out[256][64 h .. 64 h + 63] as MFMA A fragments
+    // ONE LDS object (see linear_tile_kernel): row-major images [row][64 d] of the head's Q, K, V (64 rows each) and W_out
+    // slice (256 rows), 16-byte chunks XOR-swizzled per row on the SOURCE side (the images are filled by LDS-DMA: lane-linear)
+    constexpr int kQ = 0, kK = 64 * 64, kV = 2 * 64 * 64, kW = 3 * 64 * 64;
+    __shared__ __attribute__((aligned(1024))) float img[kW + 256 * 64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pi = (int)blockIdx.x / a.B, b = (int)blockIdx.x - pi * a.B;
@@ -794,27 +797,44 @@ __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOu
     const int h = blockIdx.y;
     const int c16 = lane & 15, kq = lane >> 4;
     AHV_ENC_STAMP(0);
-    // 36 + 16 requests per lane, all of them 16 bytes: Q and K (scores), V, and -- behind the scores -- W_out.
-    // The head dimension is walked in two orders: d = 16 ds + 4 kq + s for Q K^T (a lane's four consecutive d are MFMA
-    // k-steps) and d = 16 kq + 4 r + dt for P V and the projection (a lane's four consecutive d are the four d-TILES: tile
-    // dt = {d : d mod 4 = dt}), so that V and W_out are 16-byte loads as well -- any order serves a contraction as long as
-    // both operands use it.
-    const float* q = pr.Q + (long)(b * 64 + 16 * w + c16) * pr.ldq + h * 64 + 4 * kq;
-    const float* k = pr.K + (long)(b * 64 + c16) * pr.ldkv + h * 64 + 4 * kq;
-    const float* v = pr.V + (long)(b * 64 + 4 * kq) * pr.ldkv + h * 64 + 4 * c16;
+    // Every operand comes through LDS in 1 KiB pieces of four 256-byte rows (lane -> row lane / 16, chunk lane % 16): the
+    // fragment-shaped loads of the kernel above put 16 lanes on 16 different rows (16 quads x 4 segments = 64 cycles of the
+    // CU's address unit per instruction; with 36 of them per wave the first 3.5 us of the workgroup), these take 16.
+    // Chunk swizzles (conflict-free for the ds_read_b128 lane groups, checked in DESIGN 4.3): Q, K: c ^ (row % 16);
+    // V: c ^ (row % 4); W_out: c ^ rot(row % 16), rot = the nibble's two bit pairs exchanged.
+    const int prow = lane >> 4, pch = lane & 15;
+    {
+        const long r0 = b * 64 + 16 * w;   // wave w fetches rows 16 w .. 16 w + 15 of Q, K and V
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + prow;   // row % 16
+            glds16(pr.Q + (r0 + row) * pr.ldq + h * 64 + 4 * (pch ^ row), img + kQ + (16 * w + 4 * i) * 64 + 4 * lane);
+            glds16(pr.K + (r0 + row) * pr.ldkv + h * 64 + 4 * (pch ^ row), img + kK + (16 * w + 4 * i) * 64 + 4 * lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + prow;
+            glds16(pr.V + (r0 + row) * pr.ldkv + h * 64 + 4 * (pch ^ (row & 3)), img + kV + (16 * w + 4 * i) * 64 + 4 * lane);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 qb[4], ka[4][4], va[4][4];   // va[j][r][dt] = V[key 16 j + 4 kq + r][d = 4 c16 + dt]
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
-        qb[ds] = *reinterpret_cast<const f32x4*>(q + 16 * ds);
+        qb[ds] = *reinterpret_cast<const f32x4*>(img + kQ + (16 * w + c16) * 64 + 4 * ((4 * ds + kq) ^ c16));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ka[j][ds] = *reinterpret_cast<const f32x4*>(k + (long)j * 16 * pr.ldkv + 16 * ds);
+        for (int j = 0; j < 4; ++j) ka[j][ds] = *reinterpret_cast<const f32x4*>(img + kK + (16 * j + c16) * 64 + 4 * ((4 * ds + kq) ^ c16));
     }
-    __builtin_amdgcn_sched_barrier(0);   // (issue order = the order the waits below count on)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) va[j][r] = *reinterpret_cast<const f32x4*>(v + (long)(16 * j + r) * pr.ldkv);
-    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the loads to their uses)
+        for (int r = 0; r < 4; ++r) va[j][r] = *reinterpret_cast<const f32x4*>(img + kV + (16 * j + 4 * kq + r) * 64 + 4 * (c16 ^ r));
+    // The head dimension is walked in two orders: d = 16 ds + 4 kq + s for Q K^T (a lane's four consecutive d are MFMA
+    // k-steps) and d = 16 kq + 4 r + dt for P V and the projection (a lane's four consecutive d are the four d-TILES: tile
+    // dt = {d : d mod 4 = dt}) -- any order serves a contraction as long as both operands use it.
     // S^T[key = 16 j + 4 kq + r][query = c16], four independent chains
     f32x4 st[4];
 #pragma unroll
@@ -825,10 +845,9 @@ __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOu
         for (int sx = 0; sx < 4; ++sx)
 #pragma unroll
             for (int j = 0; j < 4; ++j) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j][ds][sx], qb[ds][sx], st[j], 0, 0, 0);
-    // W_out fragments [n-tile][r][lane][dt] = W_out[16 nt + c16][64 h + 16 kq + 4 r + dt]; wave w fetches n-tiles 4 w .. 4 w + 3
-    // (16 pieces of 1 KiB).  Requested HERE, behind the scores and with V already in its registers: hipcc answers any wait for
-    // a plain load with vmcnt(0) while LDS-DMA pieces are in flight, so nothing may be waited for between this point and the
-    // barrier in front of the projection -- the pieces travel while softmax and P V run.
+    // W_out rows 64 w .. 64 w + 63 of the head's slice (16 pieces).  Requested HERE, with every fragment of Q, K and V in
+    // registers: hipcc drains LDS-DMA in front of any ds_read of the same object, so nothing is read between this point and
+    // the barrier in front of the projection -- the pieces travel while softmax and P V run.
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -836,12 +855,10 @@ __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOu
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(va[j][r]));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int nt = 4 * w + i;
-            glds16(pr.Wo + (long)(16 * nt + c16) * 256 + h * 64 + 16 * kq + 4 * r, wo + ((nt * 4 + r) * 64 + lane) * 4);
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int row = 64 * w + 4 * i + prow, r16 = row & 15;
+        glds16(pr.Wo + (long)row * 256 + h * 64 + 4 * (pch ^ (((r16 & 3) << 2) | (r16 >> 2))), img + kW + (64 * w + 4 * i) * 64 + 4 * lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     AHV_ENC_STAMP(1);
     const float c = a.scale * 1.44269504088896341f;
@@ -886,8 +903,10 @@ __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOu
     __builtin_amdgcn_sched_barrier(0);
     AHV_ENC_STAMP(4);
     // the head's output projection for this wave's 16 queries: D^T[n = 16 nt + 4 kq + r][query = c16], four n-tiles at a time;
-    // k-step (dt, r) contracts d = 16 kq + 4 r + dt: B = ot[dt][r], A = component dt of fragment (nt, r)
+    // k-step (dt, r) contracts d = 16 kq + 4 r + dt: B = ot[dt][r], A = component dt of W_out[16 nt + c16][16 kq + 4 r ..]
     float* out = pr.P + ((long)h * M + b * 64 + 16 * w + c16) * 256 + 4 * kq;
+    const float* wrow = img + kW + c16 * 64;
+    const int wsw = ((c16 & 3) << 2) | (c16 >> 2);
 #pragma unroll
     for (int ng = 0; ng < 4; ++ng) {
         f32x4 acc[4];
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOu
         for (int r = 0; r < 4; ++r) {
             f32x4 wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wo + (((4 * ng + i) * 4 + r) * 64 + lane) * 4);
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (4 * ng + i) * 64 + 4 * ((4 * kq + r) ^ wsw));
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
