@@ -14,7 +14,7 @@ generation, host logic tests) never touch the GPU library.
 import importlib as _importlib
 
 __version__ = "0.1.0"
-_SUBMODULES = ("rotations", "_lib", "ops", "aligner", "estimator", "dist", "harness", "checkpoint", "patch", "refine", "co3d")
+_SUBMODULES = ("rotations", "_lib", "ops", "aligner", "estimator", "dist", "harness", "checkpoint", "patch", "deferred", "refine", "co3d")
 
 
 def __getattr__(name):

@@ -1,0 +1,286 @@
+"""Deferred hypothesis tensors: the UNCHANGED score lines of the reference's evaluation loop as ONE fused launch.
+
+test_co3d.py:137-146 (the same lines are in test_linemod.py / test_objaverse.py) spell the hot loop as separate torch calls:
+
+    rot  = [rotate_volume(v[None].expand(N, -1, -1, -1, -1), proposals) for v in img_feat_src]      # (N,16,8,8,8): 1.6 GB at N = 50 000
+    rot  = torch.stack(rot).reshape(-1, C, D, H, W)
+    f    = model.feature_aligner.forward_3d2d(rot).reshape(B, N, -1, H * W)                         # (B,N,32,64): 0.4 GB
+    sim  = (f * img_feat_tgt[:, None]).sum(dim=2).mean(dim=-1)                                      # (B,N)
+    pred_sim, pred_index = torch.max(sim, dim=1)
+
+With ``patch.install()`` each of these can run as its own HIP kernel (INTEGRATION.md option A as of round 5: the tensors
+above are materialised exactly as the reference materialises them, 2.4 ms and 3.5 GB per pair).  This module removes the
+materialisation without touching the script: the patched ``rotate_volume`` of an inference call returns a
+``DeferredHypotheses`` -- a ``torch.Tensor`` subclass that has the shape, dtype and device of the rotated volumes but no
+storage, only (volume, rotations) -- and the subclass's ``__torch_function__`` recognises exactly the chain above:
+
+    rotated --stack / reshape--> rotated --forward_3d2d (patched)--> features --reshape--> features
+            --mul by (B,1,32,64)--> product --sum(dim=2)--> channel sum --mean(dim=-1)--> ONE ``ops.score_hypotheses`` launch
+
+and returns the ordinary ``(B, N)`` score tensor the script's ``torch.max`` consumes.  ANY other use of a deferred tensor (another
+operator, another argument, printing, ``.cpu()``, indexing, an in-place write ...) materialises it first with the op-level
+kernels -- the same tensors option A produced before -- and carries on with plain torch: the deferral can cost time, never a
+result.  Nothing here touches autograd: deferral is only entered for volumes that carry no gradient (``patch`` decides).
+
+The arithmetic lives behind a three-function backend (``rotate_volume``, ``forward_3d2d``, ``score_hypotheses``): the HIP
+``ops`` in production (there is no CPU fallback: ``ops`` raises without the library), a stock-torch backend in the CPU tests
+of the bookkeeping (``tests/test_deferred_cpu.py``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, replace
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch.utils._pytree import tree_map
+
+_VOL = (16, 8, 8, 8)
+_FEAT = (32, 64)
+
+counters = {"deferred_rotations": 0, "deferred_forward_3d2d": 0, "fused_score_launches": 0, "materialised": 0}
+
+
+@dataclass(frozen=True)
+class Backend:
+    rotate_volume: Callable       # (volume (N,16,8,8,8) -- may be a stride-0 expand --, R (N,3,3)) -> (N,16,8,8,8)
+    forward_3d2d: Callable        # (vol (M,16,8,8,8), W1, W2, b2) -> (M,32,64)
+    score_hypotheses: Callable    # (vol_src (B,16,8,8,8), feat_tgt (B,32,64), R (N,3,3), W1, W2, b2) -> scores (B,N)
+    device_type: str = "cuda"
+
+
+def _hip_backend() -> Backend:
+    from . import ops
+    return Backend(rotate_volume=ops.rotate_volume, forward_3d2d=ops.forward_3d2d,
+                   score_hypotheses=lambda v, t, R, W1, W2, b2: ops.score_hypotheses(v, t, R, W1, W2, b2)[0])
+
+
+_backend: Optional[Backend] = None
+
+
+def backend() -> Backend:
+    global _backend
+    if _backend is None:
+        _backend = _hip_backend()
+    return _backend
+
+
+def set_backend(b: Optional[Backend]) -> Optional[Backend]:
+    """Install another backend (tests); ``None`` restores the HIP one.  Returns the previous backend."""
+    global _backend
+    prev, _backend = _backend, b
+    return prev
+
+
+@dataclass(frozen=True)
+class _State:
+    kind: str                       # "rotated" | "features" | "product" | "channel_sum"
+    vols: torch.Tensor              # (Bv,16,8,8,8) source volumes, real
+    R: torch.Tensor                 # (N,3,3), real, shared by the Bv volumes
+    head: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None    # forward_3d2d's weights (features onwards)
+    tgt: Optional[torch.Tensor] = None                                       # (Bv,32,64) target features (product onwards)
+    backend: Optional[Backend] = None
+    R_key: tuple = ()               # identity of the caller's rotation tensor (storage, layout, version): same key = same set
+
+
+def _trailing(kind: str) -> Tuple[int, ...]:
+    return {"rotated": _VOL, "features": _FEAT, "product": _FEAT, "channel_sum": (_FEAT[1],)}[kind]
+
+
+# attribute getters and methods that only look at a tensor's metadata: answered by the wrapper itself
+_META_GETTERS = {"shape", "dtype", "device", "ndim", "is_cuda", "requires_grad", "layout", "grad", "grad_fn", "is_leaf",
+                 "names", "is_sparse", "is_quantized", "is_meta", "is_cpu", "is_nested", "itemsize", "nbytes", "_version",
+                 "output_nr", "is_mkldnn", "is_xpu", "is_mps", "is_xla", "is_sparse_csr", "retains_grad"}
+_META_METHODS = {"dim", "size", "numel", "nelement", "ndimension", "__len__", "is_floating_point", "is_complex",
+                 "element_size", "get_device", "is_contiguous", "is_signed", "is_inference", "is_shared", "is_pinned",
+                 "has_names", "is_conj", "is_neg", "_is_view", "is_same_size"}
+
+
+class DeferredHypotheses(torch.Tensor):
+    """See the module docstring.  Construct through ``defer_rotate_volume`` / ``with_head``."""
+
+    @staticmethod
+    def __new__(cls, shape, state: _State):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=state.vols.device,
+                                                requires_grad=False)
+        t._ahv = state
+        t._real = None
+        return t
+
+    # ---- bookkeeping ------------------------------------------------------------------------------------
+    @property
+    def deferred_kind(self) -> Optional[str]:
+        """The stage of the recognised chain this tensor stands for; None once it has been materialised."""
+        return None if self._real is not None else self._ahv.kind
+
+    def _meta_shape(self) -> Tuple[int, ...]:
+        with torch._C.DisableTorchFunctionSubclass():
+            return tuple(self.shape)
+
+    def _counts(self) -> Tuple[int, int]:
+        return self._ahv.vols.shape[0], self._ahv.R.shape[0]
+
+    def _valid_lead(self, lead: Tuple[int, ...]) -> bool:
+        Bv, N = self._counts()
+        return lead == (Bv * N,) or lead == (Bv, N) or (Bv == 1 and lead == (N,))
+
+    def with_head(self, W1, W2, b2) -> "DeferredHypotheses":
+        """``forward_3d2d`` of deferred rotated volumes: (M,16,8,8,8) -> (M,32,64), still deferred."""
+        assert self.deferred_kind == "rotated"
+        shape = self._meta_shape()
+        if len(shape) != 5:
+            raise RuntimeError("forward_3d2d expects (M,16,8,8,8), got %s" % (shape,))
+        counters["deferred_forward_3d2d"] += 1
+        return DeferredHypotheses(shape[:1] + _FEAT, replace(self._ahv, kind="features", head=(W1, W2, b2)))
+
+    def materialise(self) -> torch.Tensor:
+        """The real tensor this object stands for, by the op-level kernels (cached: later uses see the same storage)."""
+        if self._real is not None:
+            return self._real
+        st, be = self._ahv, self._ahv.backend or backend()
+        Bv, N = self._counts()
+        counters["materialised"] += 1
+        with torch.no_grad():
+            rot = torch.stack([be.rotate_volume(v[None].expand(N, -1, -1, -1, -1), st.R) for v in st.vols])   # (Bv,N,16,8,8,8)
+            if st.kind == "rotated":
+                out = rot
+            else:
+                out = be.forward_3d2d(rot.reshape(-1, *_VOL), *st.head).reshape(Bv, N, *_FEAT)
+                del rot
+                if st.kind in ("product", "channel_sum"):
+                    out = out * st.tgt[:, None]
+                if st.kind == "channel_sum":
+                    out = out.sum(dim=2)
+            self._real = out.reshape(self._meta_shape())
+        return self._real
+
+    def _scores(self) -> torch.Tensor:
+        st, be = self._ahv, self._ahv.backend or backend()
+        counters["fused_score_launches"] += 1
+        with torch.no_grad():
+            return be.score_hypotheses(st.vols.contiguous(), st.tgt.contiguous(), st.R, *st.head)
+
+    # ---- the recognised chain ---------------------------------------------------------------------------
+    def _lazy_reshape(self, shape) -> Optional["DeferredHypotheses"]:
+        if self._ahv.kind not in ("rotated", "features"):
+            return None
+        shape = list(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else list(shape)
+        if not all(isinstance(s, int) for s in shape):
+            return None
+        numel = math.prod(self._meta_shape())
+        if shape.count(-1) == 1:
+            known = -math.prod(shape)
+            if known <= 0 or numel % known:
+                return None
+            shape[shape.index(-1)] = numel // known
+        if any(s < 0 for s in shape) or math.prod(shape) != numel:
+            return None
+        tr = _trailing(self._ahv.kind)
+        lead, tail = tuple(shape[:len(shape) - len(tr)]), tuple(shape[len(shape) - len(tr):])
+        if tail != tr or not self._valid_lead(lead):
+            return None
+        return DeferredHypotheses(shape, self._ahv)
+
+    def _lazy_mul(self, other) -> Optional["DeferredHypotheses"]:
+        Bv, N = self._counts()
+        if (self._ahv.kind != "features" or self._meta_shape() != (Bv, N) + _FEAT or not isinstance(other, torch.Tensor)
+                or isinstance(other, DeferredHypotheses) or tuple(other.shape) != (Bv, 1) + _FEAT
+                or other.dtype != torch.float32 or other.device != self._ahv.vols.device
+                or (torch.is_grad_enabled() and other.requires_grad)):
+            return None
+        return DeferredHypotheses((Bv, N) + _FEAT, replace(self._ahv, kind="product", tgt=other.detach()[:, 0]))
+
+    @staticmethod
+    def _reduction_dim(args, kwargs, ndim):
+        """The single ``dim`` of a ``sum`` / ``mean`` call with no other option set, normalised; else None."""
+        rest = list(args)
+        dim = kwargs.get("dim", kwargs.get("axis", rest.pop(0) if rest else None))
+        if rest or set(kwargs) - {"dim", "axis", "keepdim"} or kwargs.get("keepdim", False):
+            return None
+        if isinstance(dim, (tuple, list)) and len(dim) == 1:
+            dim = dim[0]
+        if not isinstance(dim, int):
+            return None
+        return dim % ndim
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        owner = getattr(getattr(func, "__self__", None), "__name__", None)   # attribute getters: <getset 'shape'>.__get__
+        if (name == "__get__" and owner in _META_GETTERS) or name in _META_METHODS:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        out = cls._try_lazy(name, args, kwargs)
+        if out is not None:
+            return out
+        real = lambda x: x.materialise() if isinstance(x, DeferredHypotheses) else x
+        args, kwargs = tree_map(real, (tuple(args), dict(kwargs)))
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # the safety net below __torch_function__ (an operator reached from C++ without passing it): the same fallback
+        real = lambda x: x.materialise() if isinstance(x, DeferredHypotheses) else x
+        args, kwargs = tree_map(real, (tuple(args), dict(kwargs or {})))
+        return func(*args, **kwargs)
+
+    @classmethod
+    def _try_lazy(cls, name, args, kwargs):
+        if name == "stack":
+            seq = args[0] if args else kwargs.get("tensors")
+            dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
+            if (isinstance(seq, (list, tuple)) and seq and dim == 0 and len(args) <= 2 and not (set(kwargs) - {"tensors", "dim"})
+                    and all(isinstance(t, DeferredHypotheses) and t.deferred_kind == "rotated" and t._counts()[0] == 1
+                            and len(t._meta_shape()) == 5 for t in seq)):
+                f = seq[0]._ahv
+                if all(t._ahv.R_key == f.R_key and t._ahv.backend is f.backend for t in seq):
+                    vols = f.vols if len(seq) == 1 else torch.cat([t._ahv.vols for t in seq])
+                    return DeferredHypotheses((len(seq), f.R.shape[0]) + _VOL, replace(f, vols=vols))
+            return None
+        self = args[0] if args else None
+        if not isinstance(self, DeferredHypotheses) or self._real is not None:
+            other = args[1] if len(args) > 1 else None
+            if name in ("mul", "__mul__", "__rmul__", "multiply") and isinstance(other, DeferredHypotheses) and other._real is None \
+                    and len(args) == 2 and not kwargs:
+                return other._lazy_mul(self)          # real * deferred
+            return None
+        if name in ("reshape", "view") and not kwargs:
+            return self._lazy_reshape(args[1:])
+        if name in ("mul", "__mul__", "__rmul__", "multiply") and len(args) == 2 and not kwargs:
+            return self._lazy_mul(args[1])
+        if name == "sum" and self._ahv.kind == "product":
+            if cls._reduction_dim(args[1:], kwargs, 4) == 2:
+                Bv, N = self._counts()
+                return DeferredHypotheses((Bv, N, _FEAT[1]), replace(self._ahv, kind="channel_sum"))
+            return None
+        if name == "mean" and self._ahv.kind == "channel_sum":
+            if cls._reduction_dim(args[1:], kwargs, 3) == 2:
+                return self._scores()
+            return None
+        return None
+
+    def __repr__(self):   # (never materialise for a debugger's sake)
+        if self._real is not None:
+            return "DeferredHypotheses(materialised, shape=%s)" % (self._meta_shape(),)
+        Bv, N = self._counts()
+        return "DeferredHypotheses(%s, shape=%s, volumes=%d, rotations=%d)" % (self._ahv.kind, self._meta_shape(), Bv, N)
+
+
+def defer_rotate_volume(volume: torch.Tensor, R: torch.Tensor, be: Optional[Backend] = None) -> Optional[DeferredHypotheses]:
+    """A deferred ``rotate_volume(volume, R)`` if the call has the shape of the evaluation loop's -- ONE (16,8,8,8) volume
+    expanded over N rotations, fp32, on the backend's device, nothing that needs a gradient -- else None (the caller then
+    runs the kernel).  The deferred tensor holds a VIEW of the volume: like the lazily evaluated expression it stands for,
+    it sees writes to the volume that happen before the scores are taken (the reference's loop has none)."""
+    be = be or backend()
+    if (not isinstance(volume, torch.Tensor) or isinstance(volume, DeferredHypotheses) or volume.dim() != 5
+            or tuple(volume.shape[1:]) != _VOL or volume.dtype != torch.float32 or volume.device.type != be.device_type
+            or R.dim() != 3 or tuple(R.shape) != (volume.shape[0], 3, 3) or R.dtype != torch.float32 or R.device != volume.device
+            or (volume.shape[0] > 1 and volume.stride(0) != 0)
+            or (torch.is_grad_enabled() and (volume.requires_grad or R.requires_grad))):
+        return None
+    counters["deferred_rotations"] += 1
+    st = _State(kind="rotated", vols=volume.detach()[:1], R=R.detach().contiguous(), backend=be,
+                R_key=(R.data_ptr(), tuple(R.shape), tuple(R.stride()), R._version))
+    return DeferredHypotheses(tuple(volume.shape), st)

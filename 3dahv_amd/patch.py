@@ -1,4 +1,4 @@
-"""Run the UNCHANGED reference scripts on the HIP kernels by rebinding the two callables on the hot
+"""Run the UNCHANGED reference scripts on the HIP kernels by rebinding the callables on the hot
 path (option A):
 
     utils.rotate_volume                          -> 3dahv_amd.ops.rotate_volume        (utils.py:113-131)
@@ -9,17 +9,23 @@ Usage from the reference's checkout, before the script's own imports bind the na
 
     import ahv_amd; ahv_amd.patch.install()      # then: from utils import rotate_volume  (now the HIP one)
 
-The op-level kernels materialise exactly the tensors the reference materialises; the fused
-single-launch path needs the three-line change shown in INTEGRATION.md, option B.
+Inference calls of the evaluation loop's shape (one (16,8,8,8) volume expanded over N rotations, nothing that needs a
+gradient) are DEFERRED (round 6, ``deferred.py``): ``rotate_volume`` returns a tensor subclass without storage, the patched
+``forward_3d2d`` passes it on, and the script's own ``(f * f_tgt[:, None]).sum(dim=2).mean(dim=-1)`` becomes ONE fused
+``score_hypotheses`` launch -- the unchanged lines test_co3d.py:137-146 at the speed and memory of the three-line change of
+option B.  Any other use of such a tensor materialises it with the op-level kernels, exactly what ``install(defer=False)``
+(or ``AHV_PATCH_DEFER=0``) runs for every call.
 """
 from __future__ import annotations
 
 import importlib
+import os
 import sys
 
-from . import ops
+from . import deferred, ops
 
 _saved = {}
+_defer = True
 
 
 def _inference_call(module) -> bool:
@@ -34,12 +40,29 @@ def _inference_call(module) -> bool:
     return (not torch.is_grad_enabled()) or (not module.training)
 
 
-calls = {"forward_2d3d_hip": 0, "forward_2d3d_reference": 0, "forward_3d2d_inference": 0, "forward_3d2d_autograd": 0}
+calls = {"forward_2d3d_hip": 0, "forward_2d3d_reference": 0, "forward_3d2d_inference": 0, "forward_3d2d_autograd": 0,
+         "forward_3d2d_deferred": 0, "rotate_volume_deferred": 0, "rotate_volume_kernel": 0}
+
+
+def _hip_rotate_volume(volume, rotation_matrix, padding_mode="zeros"):
+    """``utils.rotate_volume`` (utils.py:113-131).  The evaluation loop's call -- a stride-0 expand of one detached volume --
+    comes back deferred (``deferred.DeferredHypotheses``: same shape, dtype, device; materialised by the kernel below the
+    moment anything but the recognised score chain touches it); every other call runs ``ops.rotate_volume`` at once."""
+    if _defer and padding_mode == "zeros":
+        d = deferred.defer_rotate_volume(volume, rotation_matrix)
+        if d is not None:
+            calls["rotate_volume_deferred"] += 1
+            return d
+    calls["rotate_volume_kernel"] += 1
+    return ops.rotate_volume(volume, rotation_matrix, padding_mode)
 
 
 def _hip_forward_3d2d(self, img_feat):
     import torch
     c1, c2 = self.feature_embedding_2d[0], self.feature_embedding_2d[2]
+    if isinstance(img_feat, deferred.DeferredHypotheses) and img_feat.deferred_kind == "rotated" and _inference_call(self):
+        calls["forward_3d2d_deferred"] += 1
+        return img_feat.with_head(c1.weight.detach(), c2.weight.detach(), c2.bias.detach())
     if _inference_call(self):
         calls["forward_3d2d_inference"] += 1
         with torch.no_grad():
@@ -81,8 +104,11 @@ def verify_hypotheses(self, img_feat_src, img_feat_tgt, proposals, want_scores=F
                                want_scores=want_scores, **kw)[:2]
 
 
-def install(utils_module=None, modules_module=None):
-    """Patch the reference's modules (already imported, importable from sys.path, or passed in)."""
+def install(utils_module=None, modules_module=None, defer=None):
+    """Patch the reference's modules (already imported, importable from sys.path, or passed in).  ``defer``: run the
+    evaluation loop's score lines as one fused launch (module docstring); default: on unless ``AHV_PATCH_DEFER=0``."""
+    global _defer
+    _defer = (os.environ.get("AHV_PATCH_DEFER", "1") != "0") if defer is None else bool(defer)
     if utils_module is None:
         utils_module = sys.modules.get("utils") or importlib.import_module("utils")
     if modules_module is None:
@@ -92,7 +118,7 @@ def install(utils_module=None, modules_module=None):
         _saved["forward_3d2d"] = (modules_module.Feature_Aligner, modules_module.Feature_Aligner.forward_3d2d)
         if hasattr(modules_module.Feature_Aligner, "forward_2d3d"):
             _saved["forward_2d3d"] = (modules_module.Feature_Aligner, modules_module.Feature_Aligner.forward_2d3d)
-    utils_module.rotate_volume = ops.rotate_volume
+    utils_module.rotate_volume = _hip_rotate_volume
     modules_module.Feature_Aligner.forward_3d2d = _hip_forward_3d2d
     if "forward_2d3d" in _saved:
         modules_module.Feature_Aligner.forward_2d3d = _hip_forward_2d3d
@@ -102,7 +128,7 @@ def install(utils_module=None, modules_module=None):
     # scripts that did `from utils import *` / `from utils import rotate_volume` earlier hold their own binding
     for mod in list(sys.modules.values()):
         if mod is not None and getattr(mod, "rotate_volume", None) is _saved["rotate_volume"][1]:
-            setattr(mod, "rotate_volume", ops.rotate_volume)
+            setattr(mod, "rotate_volume", _hip_rotate_volume)
     return utils_module, modules_module
 
 
@@ -111,7 +137,7 @@ def uninstall():
         return
     um, f = _saved.pop("rotate_volume")
     for mod in list(sys.modules.values()):
-        if mod is not None and getattr(mod, "rotate_volume", None) is ops.rotate_volume and mod is not ops:
+        if mod is not None and getattr(mod, "rotate_volume", None) is _hip_rotate_volume:
             setattr(mod, "rotate_volume", f)
     um.rotate_volume = f
     cls, g = _saved.pop("forward_3d2d")

@@ -130,8 +130,8 @@ def test_patch_install_rebinds_reference_callables(ahv):
     sys.modules["fake_script"] = script
     try:
         ahv.patch.install(utils_mod, mm)
-        assert utils_mod.rotate_volume is ahv.ops.rotate_volume
-        assert script.rotate_volume is ahv.ops.rotate_volume
+        assert utils_mod.rotate_volume is ahv.patch._hip_rotate_volume     # (ops.rotate_volume behind the deferral check)
+        assert script.rotate_volume is ahv.patch._hip_rotate_volume
         assert Feature_Aligner.forward_3d2d is not None and Feature_Aligner().forward_3d2d.__func__ is ahv.patch._hip_forward_3d2d
         ahv.patch.uninstall()
         assert utils_mod.rotate_volume is ref_fn and script.rotate_volume is ref_fn
