@@ -28,7 +28,9 @@ of the bookkeeping (``tests/test_deferred_cpu.py``).
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import weakref
 from dataclasses import dataclass, replace
 from typing import Callable, Optional, Tuple
 
@@ -39,20 +41,25 @@ _VOL = (16, 8, 8, 8)
 _FEAT = (32, 64)
 
 counters = {"deferred_rotations": 0, "deferred_forward_3d2d": 0, "fused_score_launches": 0, "materialised": 0}
+_pending: list = []   # weak references to per-sample score tensors that have not been evaluated yet (see _evaluate_pending)
 
 
 @dataclass(frozen=True)
 class Backend:
     rotate_volume: Callable       # (volume (N,16,8,8,8) -- may be a stride-0 expand --, R (N,3,3)) -> (N,16,8,8,8)
     forward_3d2d: Callable        # (vol (M,16,8,8,8), W1, W2, b2) -> (M,32,64)
-    score_hypotheses: Callable    # (vol_src (B,16,8,8,8), feat_tgt (B,32,64), R (N,3,3), W1, W2, b2) -> scores (B,N)
+    score_hypotheses: Callable    # (vol_src (B,16,8,8,8), feat_tgt (B,32,64), R (N,3,3) or (B,N,3,3), W1, W2, b2) -> scores (B,N)
     device_type: str = "cuda"
 
 
 def _hip_backend() -> Backend:
     from . import ops
-    return Backend(rotate_volume=ops.rotate_volume, forward_3d2d=ops.forward_3d2d,
-                   score_hypotheses=lambda v, t, R, W1, W2, b2: ops.score_hypotheses(v, t, R, W1, W2, b2)[0])
+
+    def score(v, t, R, W1, W2, b2):
+        if torch.is_grad_enabled() and any(x.requires_grad for x in (v, t, W1, W2, b2)):
+            return ops.score_hypotheses_autograd(v, t, R, W1, W2, b2)     # the training pair: HIP forward + backward
+        return ops.score_hypotheses(v, t, R, W1, W2, b2)[0]
+    return Backend(rotate_volume=ops.rotate_volume, forward_3d2d=ops.forward_3d2d, score_hypotheses=score)
 
 
 _backend: Optional[Backend] = None
@@ -74,17 +81,19 @@ def set_backend(b: Optional[Backend]) -> Optional[Backend]:
 
 @dataclass(frozen=True)
 class _State:
-    kind: str                       # "rotated" | "features" | "product" | "channel_sum"
+    kind: str                       # "rotated" | "features" | "product" | "channel_sum" | "scores"
     vols: torch.Tensor              # (Bv,16,8,8,8) source volumes, real
     R: torch.Tensor                 # (N,3,3), real, shared by the Bv volumes
     head: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None    # forward_3d2d's weights (features onwards)
     tgt: Optional[torch.Tensor] = None                                       # (Bv,32,64) target features (product onwards)
     backend: Optional[Backend] = None
     R_key: tuple = ()               # identity of the caller's rotation tensor (storage, layout, version): same key = same set
+    grad: bool = False              # an operand needs a gradient: the launches run under the caller's grad mode (autograd edges)
+    inference: bool = False         # forward_3d2d was an inference call: later operands are detached, nothing records a graph
 
 
 def _trailing(kind: str) -> Tuple[int, ...]:
-    return {"rotated": _VOL, "features": _FEAT, "product": _FEAT, "channel_sum": (_FEAT[1],)}[kind]
+    return {"rotated": _VOL, "features": _FEAT, "product": _FEAT, "channel_sum": (_FEAT[1],), "scores": ()}[kind]
 
 
 # attribute getters and methods that only look at a tensor's metadata: answered by the wrapper itself
@@ -124,23 +133,36 @@ class DeferredHypotheses(torch.Tensor):
         Bv, N = self._counts()
         return lead == (Bv * N,) or lead == (Bv, N) or (Bv == 1 and lead == (N,))
 
-    def with_head(self, W1, W2, b2) -> "DeferredHypotheses":
-        """``forward_3d2d`` of deferred rotated volumes: (M,16,8,8,8) -> (M,32,64), still deferred."""
+    def with_head(self, W1, W2, b2, detach: bool = False) -> "DeferredHypotheses":
+        """``forward_3d2d`` of deferred rotated volumes: (M,16,8,8,8) -> (M,32,64), still deferred.  ``detach``: an inference
+        call (patch._inference_call) -- nothing downstream records a graph, whatever the operands' flags say."""
         assert self.deferred_kind == "rotated"
         shape = self._meta_shape()
         if len(shape) != 5:
             raise RuntimeError("forward_3d2d expects (M,16,8,8,8), got %s" % (shape,))
         counters["deferred_forward_3d2d"] += 1
-        return DeferredHypotheses(shape[:1] + _FEAT, replace(self._ahv, kind="features", head=(W1, W2, b2)))
+        st = self._ahv
+        if detach:
+            st = replace(st, vols=st.vols.detach(), grad=False, inference=True)
+            W1, W2, b2 = W1.detach(), W2.detach(), b2.detach()
+        else:
+            st = replace(st, grad=st.grad or (torch.is_grad_enabled() and any(w.requires_grad for w in (W1, W2, b2))))
+        return DeferredHypotheses(shape[:1] + _FEAT, replace(st, kind="features", head=(W1, W2, b2)))
+
+    def _mode(self):
+        return contextlib.nullcontext() if self._ahv.grad else torch.no_grad()
 
     def materialise(self) -> torch.Tensor:
         """The real tensor this object stands for, by the op-level kernels (cached: later uses see the same storage)."""
         if self._real is not None:
             return self._real
         st, be = self._ahv, self._ahv.backend or backend()
+        if st.kind == "scores":
+            _evaluate_pending(self)
+            return self._real
         Bv, N = self._counts()
         counters["materialised"] += 1
-        with torch.no_grad():
+        with self._mode():
             rot = torch.stack([be.rotate_volume(v[None].expand(N, -1, -1, -1, -1), st.R) for v in st.vols])   # (Bv,N,16,8,8,8)
             if st.kind == "rotated":
                 out = rot
@@ -157,8 +179,9 @@ class DeferredHypotheses(torch.Tensor):
     def _scores(self) -> torch.Tensor:
         st, be = self._ahv, self._ahv.backend or backend()
         counters["fused_score_launches"] += 1
-        with torch.no_grad():
-            return be.score_hypotheses(st.vols.contiguous(), st.tgt.contiguous(), st.R, *st.head)
+        with self._mode():
+            s = be.score_hypotheses(st.vols.contiguous(), st.tgt.contiguous(), st.R, *st.head)     # (Bv,N)
+        return s.reshape(self._meta_shape()[:-1])
 
     # ---- the recognised chain ---------------------------------------------------------------------------
     def _lazy_reshape(self, shape) -> Optional["DeferredHypotheses"]:
@@ -182,13 +205,21 @@ class DeferredHypotheses(torch.Tensor):
         return DeferredHypotheses(shape, self._ahv)
 
     def _lazy_mul(self, other) -> Optional["DeferredHypotheses"]:
+        """features * target features: (Bv,N,32,64) * (Bv,1,32,64) (test_co3d.py:143) or, for one volume, (N,32,64) * (1,32,64)
+        (the per-sample form of infoNCE_loss, modules/model_co3d.py:54)."""
         Bv, N = self._counts()
-        if (self._ahv.kind != "features" or self._meta_shape() != (Bv, N) + _FEAT or not isinstance(other, torch.Tensor)
-                or isinstance(other, DeferredHypotheses) or tuple(other.shape) != (Bv, 1) + _FEAT
-                or other.dtype != torch.float32 or other.device != self._ahv.vols.device
-                or (torch.is_grad_enabled() and other.requires_grad)):
+        shape = self._meta_shape()
+        if (self._ahv.kind != "features" or not isinstance(other, torch.Tensor) or isinstance(other, DeferredHypotheses)
+                or other.dtype != torch.float32 or other.device != self._ahv.vols.device):
             return None
-        return DeferredHypotheses((Bv, N) + _FEAT, replace(self._ahv, kind="product", tgt=other.detach()[:, 0]))
+        if shape == (Bv, N) + _FEAT and tuple(other.shape) == (Bv, 1) + _FEAT:
+            tgt = other[:, 0]
+        elif Bv == 1 and shape == (N,) + _FEAT and tuple(other.shape) == (1,) + _FEAT:
+            tgt = other
+        else:
+            return None
+        grad = (not self._ahv.inference) and (self._ahv.grad or (torch.is_grad_enabled() and other.requires_grad))
+        return DeferredHypotheses(shape, replace(self._ahv, kind="product", tgt=tgt if grad else tgt.detach(), grad=grad))
 
     @staticmethod
     def _reduction_dim(args, kwargs, ndim):
@@ -251,12 +282,19 @@ class DeferredHypotheses(torch.Tensor):
         if name in ("mul", "__mul__", "__rmul__", "multiply") and len(args) == 2 and not kwargs:
             return self._lazy_mul(args[1])
         if name == "sum" and self._ahv.kind == "product":
-            if cls._reduction_dim(args[1:], kwargs, 4) == 2:
-                Bv, N = self._counts()
-                return DeferredHypotheses((Bv, N, _FEAT[1]), replace(self._ahv, kind="channel_sum"))
+            shape = self._meta_shape()
+            if cls._reduction_dim(args[1:], kwargs, len(shape)) == len(shape) - 2:       # the channel axis
+                return DeferredHypotheses(shape[:-2] + shape[-1:], replace(self._ahv, kind="channel_sum"))
             return None
         if name == "mean" and self._ahv.kind == "channel_sum":
-            if cls._reduction_dim(args[1:], kwargs, 3) == 2:
+            shape = self._meta_shape()
+            if cls._reduction_dim(args[1:], kwargs, len(shape)) == len(shape) - 1:       # the position axis
+                if len(shape) == 2:
+                    # the per-sample form (infoNCE_loss builds `sim` as a list over the batch, modules/model_co3d.py:54): the
+                    # scores stay deferred until the first of them is used, and ALL samples' scores are then one launch
+                    d = DeferredHypotheses(shape[:1], replace(self._ahv, kind="scores"))
+                    _pending.append(weakref.ref(d))
+                    return d
                 return self._scores()
             return None
         return None
@@ -268,19 +306,48 @@ class DeferredHypotheses(torch.Tensor):
         return "DeferredHypotheses(%s, shape=%s, volumes=%d, rotations=%d)" % (self._ahv.kind, self._meta_shape(), Bv, N)
 
 
-def defer_rotate_volume(volume: torch.Tensor, R: torch.Tensor, be: Optional[Backend] = None) -> Optional[DeferredHypotheses]:
-    """A deferred ``rotate_volume(volume, R)`` if the call has the shape of the evaluation loop's -- ONE (16,8,8,8) volume
-    expanded over N rotations, fp32, on the backend's device, nothing that needs a gradient -- else None (the caller then
-    runs the kernel).  The deferred tensor holds a VIEW of the volume: like the lazily evaluated expression it stands for,
-    it sees writes to the volume that happen before the scores are taken (the reference's loop has none)."""
+def _evaluate_pending(first: "DeferredHypotheses") -> None:
+    """Evaluate ``first`` and every other pending per-sample score tensor of the same batch -- same head weights (the module's
+    parameters: identity), same number of rotations, same backend and grad mode -- in ONE fused launch with per-sample rotation
+    sets (B,N,3,3); each tensor then stands for its row.  A tensor evaluated alone is the B = 1 case of the same call."""
+    st = first._ahv
+    same = lambda o: (o._real is None and o._ahv.kind == "scores" and o._ahv.backend is st.backend and o._ahv.grad == st.grad
+                      and all(a is b for a, b in zip(o._ahv.head, st.head)) and o._ahv.R.shape == st.R.shape
+                      and o._ahv.vols.device == st.vols.device)
+    live = [r() for r in _pending]
+    group = [o for o in live if o is not None and o is not first and same(o)]
+    group.insert(0, first)
+    _pending[:] = [weakref.ref(o) for o in live if o is not None and not any(o is g for g in group)]
+    be = st.backend or backend()
+    counters["fused_score_launches"] += 1
+    with first._mode():
+        if len(group) == 1:
+            s = be.score_hypotheses(st.vols.contiguous(), st.tgt.contiguous(), st.R, *st.head)
+        else:
+            s = be.score_hypotheses(torch.cat([o._ahv.vols for o in group]), torch.cat([o._ahv.tgt for o in group]),
+                                    torch.stack([o._ahv.R for o in group]), *st.head)
+        for i, o in enumerate(group):
+            o._real = s[i]
+
+
+def defer_rotate_volume(volume: torch.Tensor, R: torch.Tensor, be: Optional[Backend] = None,
+                        allow_grad: bool = False) -> Optional[DeferredHypotheses]:
+    """A deferred ``rotate_volume(volume, R)`` if the call has the shape of the reference's hot loops -- ONE (16,8,8,8) volume
+    expanded over N rotations, fp32, on the backend's device -- else None (the caller then runs the kernel).  A volume that
+    needs a gradient is deferred only with ``allow_grad`` (the chain then ends in the differentiable fused scorer, and every
+    fallback runs the differentiable op-level kernels under the caller's grad mode); rotations that need one never are.
+    The deferred tensor holds a VIEW of the volume: like the lazily evaluated expression it stands for, it sees writes to the
+    volume that happen before the scores are taken (the reference's loops have none)."""
     be = be or backend()
     if (not isinstance(volume, torch.Tensor) or isinstance(volume, DeferredHypotheses) or volume.dim() != 5
             or tuple(volume.shape[1:]) != _VOL or volume.dtype != torch.float32 or volume.device.type != be.device_type
             or R.dim() != 3 or tuple(R.shape) != (volume.shape[0], 3, 3) or R.dtype != torch.float32 or R.device != volume.device
-            or (volume.shape[0] > 1 and volume.stride(0) != 0)
-            or (torch.is_grad_enabled() and (volume.requires_grad or R.requires_grad))):
+            or (volume.shape[0] > 1 and volume.stride(0) != 0)):
+        return None
+    grad = torch.is_grad_enabled() and volume.requires_grad
+    if (torch.is_grad_enabled() and R.requires_grad) or (grad and not allow_grad):
         return None
     counters["deferred_rotations"] += 1
-    st = _State(kind="rotated", vols=volume.detach()[:1], R=R.detach().contiguous(), backend=be,
-                R_key=(R.data_ptr(), tuple(R.shape), tuple(R.stride()), R._version))
+    st = _State(kind="rotated", vols=(volume if grad else volume.detach())[:1], R=R.detach().contiguous(), backend=be,
+                R_key=(R.data_ptr(), tuple(R.shape), tuple(R.stride()), R._version), grad=grad)
     return DeferredHypotheses(tuple(volume.shape), st)

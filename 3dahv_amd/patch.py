@@ -9,12 +9,13 @@ Usage from the reference's checkout, before the script's own imports bind the na
 
     import ahv_amd; ahv_amd.patch.install()      # then: from utils import rotate_volume  (now the HIP one)
 
-Inference calls of the evaluation loop's shape (one (16,8,8,8) volume expanded over N rotations, nothing that needs a
-gradient) are DEFERRED (round 6, ``deferred.py``): ``rotate_volume`` returns a tensor subclass without storage, the patched
-``forward_3d2d`` passes it on, and the script's own ``(f * f_tgt[:, None]).sum(dim=2).mean(dim=-1)`` becomes ONE fused
-``score_hypotheses`` launch -- the unchanged lines test_co3d.py:137-146 at the speed and memory of the three-line change of
-option B.  Any other use of such a tensor materialises it with the op-level kernels, exactly what ``install(defer=False)``
-(or ``AHV_PATCH_DEFER=0``) runs for every call.
+Calls of the hot loops' shape (one (16,8,8,8) volume expanded over N rotations) are DEFERRED (round 6, ``deferred.py``):
+``rotate_volume`` returns a tensor subclass without storage, the patched ``forward_3d2d`` passes it on, and the script's own
+``(f * f_tgt[:, None]).sum(dim=2).mean(dim=-1)`` becomes ONE fused ``score_hypotheses`` launch -- the unchanged lines
+test_co3d.py:137-146 at the speed and memory of the two-line change of option B; in training mode the per-sample form of
+``infoNCE_loss`` (modules/model_co3d.py:49-54) ends in the differentiable fused scorer instead (HIP forward that keeps its
+pre-activations + HIP backward).  Any other use of such a tensor materialises it with the op-level kernels, exactly what
+``install(defer=False)`` (or ``AHV_PATCH_DEFER=0``) runs for every call.
 """
 from __future__ import annotations
 
@@ -49,7 +50,7 @@ def _hip_rotate_volume(volume, rotation_matrix, padding_mode="zeros"):
     comes back deferred (``deferred.DeferredHypotheses``: same shape, dtype, device; materialised by the kernel below the
     moment anything but the recognised score chain touches it); every other call runs ``ops.rotate_volume`` at once."""
     if _defer and padding_mode == "zeros":
-        d = deferred.defer_rotate_volume(volume, rotation_matrix)
+        d = deferred.defer_rotate_volume(volume, rotation_matrix, allow_grad=True)
         if d is not None:
             calls["rotate_volume_deferred"] += 1
             return d
@@ -60,9 +61,10 @@ def _hip_rotate_volume(volume, rotation_matrix, padding_mode="zeros"):
 def _hip_forward_3d2d(self, img_feat):
     import torch
     c1, c2 = self.feature_embedding_2d[0], self.feature_embedding_2d[2]
-    if isinstance(img_feat, deferred.DeferredHypotheses) and img_feat.deferred_kind == "rotated" and _inference_call(self):
+    if isinstance(img_feat, deferred.DeferredHypotheses) and img_feat.deferred_kind == "rotated":
+        # inference: everything downstream is detached; training: the chain ends in the differentiable fused scorer
         calls["forward_3d2d_deferred"] += 1
-        return img_feat.with_head(c1.weight.detach(), c2.weight.detach(), c2.bias.detach())
+        return img_feat.with_head(c1.weight, c2.weight, c2.bias, detach=_inference_call(self))
     if _inference_call(self):
         calls["forward_3d2d_inference"] += 1
         with torch.no_grad():

@@ -15,8 +15,9 @@ N = 9
 
 
 def fused(v, t, R, W1, W2, b2):
-    rot = torch.stack([tr.rotate_volume(x[None].expand(R.shape[0], -1, -1, -1, -1), R) for x in v])
-    f = tr.forward_3d2d(rot.reshape(-1, 16, 8, 8, 8), W1, W2, b2).reshape(v.shape[0], R.shape[0], 32, 64)
+    n = R.shape[-3]
+    rot = torch.stack([tr.rotate_volume(x[None].expand(n, -1, -1, -1, -1), R if R.dim() == 3 else R[i]) for i, x in enumerate(v)])
+    f = tr.forward_3d2d(rot.reshape(-1, 16, 8, 8, 8), W1, W2, b2).reshape(v.shape[0], n, 32, 64)
     return (f * t[:, None]).sum(2).mean(-1)
 
 
@@ -154,3 +155,75 @@ def test_what_is_not_deferred(be, data):
     with torch.no_grad():
         assert D.defer_rotate_volume(v[None].expand(N, -1, -1, -1, -1), R) is not None
     assert D.defer_rotate_volume(vols[:1], R[:1]) is not None                          # N = 1
+
+
+def infonce(rotate_volume, forward_3d2d, img_feat_1, img_feat_2, sampled_R, pos):
+    """The tensor expressions of modules/model_co3d.py:49-59 (per-sample lists; `pos`: the positives' mask)."""
+    bs, n = sampled_R.shape[:2]
+    warp = [rotate_volume(img_feat_1[i:i + 1].expand(n, -1, -1, -1, -1), sampled_R[i]) for i in range(bs)]
+    warp = [forward_3d2d(w) for w in warp]
+    f2 = forward_3d2d(img_feat_2)
+    sim = [(warp[i] * f2[i:i + 1]).sum(dim=1).mean(dim=-1) for i in range(bs)]
+    positive = torch.stack([torch.exp(sim[i][pos[i]] / 0.1).sum(dim=0) for i in range(bs)])
+    both = torch.exp(torch.stack(sim) / 0.1).sum(dim=-1)
+    return -torch.log(positive / both.clamp(min=1e-8)).mean()
+
+
+def test_the_training_chain_is_one_differentiable_fused_call_per_batch(be, data):
+    vols, tgt, R, head = data
+    g = torch.Generator().manual_seed(8)
+    Rs = torch.stack([R, torch.linalg.qr(torch.randn(N, 3, 3, generator=g))[0]])
+    pos = torch.zeros(2, N, dtype=torch.bool)
+    pos[:, :2] = True
+
+    def run(deferred):
+        leaves = [t.clone().requires_grad_(True) for t in (vols, tgt) + head]
+        v, t, W1, W2, b2 = leaves
+
+        def rotate_volume(x, Rm):
+            d = D.defer_rotate_volume(x, Rm, allow_grad=True) if deferred else None
+            return d if d is not None else tr.rotate_volume(x, Rm)
+
+        def forward_3d2d(x):
+            if isinstance(x, D.DeferredHypotheses) and x.deferred_kind == "rotated":
+                return x.with_head(W1, W2, b2)
+            return tr.forward_3d2d(x, W1, W2, b2)
+        loss = infonce(rotate_volume, forward_3d2d, v, t, Rs, pos)
+        loss.backward()
+        return loss.detach(), [x.grad for x in leaves]
+    before = dict(D.counters)
+    loss_d, grads_d = run(True)
+    assert be["fused"] == 1 and be["rotate"] == 0 and D.counters["materialised"] == before["materialised"]   # ONE launch for both samples
+    loss_e, grads_e = run(False)
+    assert torch.allclose(loss_d, loss_e, atol=1e-6)
+    for a, b in zip(grads_d, grads_e):
+        assert a is not None and torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    # an inference call of forward_3d2d (with_head(detach=True)) cuts every edge, whatever the operands' flags say
+    v = vols[:1].clone().requires_grad_(True)
+    d = D.defer_rotate_volume(v[0][None].expand(N, -1, -1, -1, -1), R, allow_grad=True)
+    W1 = head[0].clone().requires_grad_(True)
+    f2 = tr.forward_3d2d(tgt[:1], W1, *head[1:])
+    s = (d.with_head(W1, *head[1:], detach=True).reshape(1, N, 32, 64) * f2[:, None]).sum(dim=2).mean(dim=-1)
+    assert not s.requires_grad
+    # ... and a volume that needs a gradient is only deferred on request
+    assert D.defer_rotate_volume(v[0][None].expand(N, -1, -1, -1, -1), R) is None
+
+
+def test_pending_scores_are_grouped_by_batch_and_survive_odd_orders(be, data):
+    vols, tgt, R, head = data
+    f2 = tr.forward_3d2d(tgt, *head)
+    other_head = tuple(h.clone() for h in head)
+
+    def sample(i, hd, n=N):
+        d = D.defer_rotate_volume(vols[i][None].expand(n, -1, -1, -1, -1), R[:n]).with_head(*hd)
+        return (d * f2[i:i + 1]).sum(dim=1).mean(dim=-1)
+    eager = lambda i, hd, n=N: fused(vols[i:i + 1], f2[i:i + 1], R[:n], *hd)[0]
+    a, b, c, d_ = sample(0, head), sample(1, head), sample(0, other_head), sample(1, head, n=N - 2)
+    assert all(x.deferred_kind == "scores" and x.shape[0] in (N, N - 2) for x in (a, b, c, d_)) and be["fused"] == 0
+    assert torch.allclose(b + 0.0, eager(1, head), atol=1e-6)        # first use: a and b (same weights, same N) in one launch
+    assert be["fused"] == 1 and a.deferred_kind is None and c.deferred_kind == "scores" and d_.deferred_kind == "scores"
+    assert torch.allclose(a[2:5], eager(0, head)[2:5], atol=1e-6) and be["fused"] == 1
+    assert torch.allclose(torch.stack([c]), eager(0, other_head)[None], atol=1e-6) and be["fused"] == 2
+    del d_                                                           # never used: nothing is launched for it
+    e = sample(1, head)
+    assert torch.allclose(e.exp(), eager(1, head).exp(), atol=1e-6) and be["fused"] == 3

@@ -88,6 +88,83 @@ def test_patched_reference_shaped_infonce_backpropagates_on_hip(ahv, dev):
         assert rel(a.cpu(), b) < 2e-4, (name, rel(a.cpu(), b))
 
 
+def ref_infonce_verbatim(rotate_volume, forward_3d2d, img_feat_1, img_feat_2, sampled_R, gt_delta_R, acc_thr, num_rota):
+    """modules/model_co3d.py:41-61 expression for expression (per-sample lists, `sim[idx][posi_indices[idx]]`)."""
+    bs = gt_delta_R.shape[0]
+    with torch.no_grad():
+        gt_sim = (torch.sum(sampled_R.flatten(2) * gt_delta_R.view(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+        gt_dis = torch.arccos(gt_sim) / np.pi
+        posi_indices = [torch.nonzero(180 * gt_dis[i] <= acc_thr).squeeze(-1) for i in range(bs)]
+    img_feat_warp = [rotate_volume(img_feat_1[idx:idx + 1].expand(num_rota, -1, -1, -1, -1), sampled_R[idx]) for idx in range(bs)]
+    img_feat_warp = [forward_3d2d(img_feat) for img_feat in img_feat_warp]
+    img_feat_2 = forward_3d2d(img_feat_2)
+    sim = [(img_feat_warp[idx] * img_feat_2[idx:idx + 1]).sum(dim=1).mean(dim=-1) for idx in range(bs)]
+    positive_sim = torch.stack([torch.exp(sim[idx][posi_indices[idx]] / 0.1).sum(dim=0) for idx in range(bs)])
+    positive_negative_sim = (torch.exp(torch.stack(sim) / 0.1)).sum(dim=-1)
+    return -torch.log(positive_sim / positive_negative_sim.clamp(min=1e-8)).mean()
+
+
+@pytest.mark.parametrize("defer", [True, False])
+def test_unchanged_infonce_lines_in_training_mode(ahv, dev, defer):
+    """The reference's infoNCE_loss lines under patch.install() with the module in TRAINING mode: with the deferral (the
+    default) all samples' `rotate_volume` .. `.mean(dim=-1)` chains are ONE differentiable fused launch (the training pair: HIP
+    forward that keeps its pre-activations + HIP backward; the per-sample score tensors stay pending until the first is
+    used) and nothing is materialised; without it every line is its own differentiable op-level kernel.  Either way: the loss and all five gradients of fp64 autograd through the stock-operator
+    restatement."""
+    from oracle import torch_ref
+    g = load_golden("score_n128")
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+
+    class Feature_Aligner(torch.nn.Module):  # noqa: N801
+        def __init__(self):
+            super().__init__()
+            self.feature_embedding_2d = torch.nn.Sequential(torch.nn.Conv2d(384, 32, 1, bias=False), torch.nn.ReLU(),
+                                                            torch.nn.Conv2d(32, 32, 1))
+
+        def forward_3d2d(self, x):
+            raise AssertionError("not patched")
+    mm.Feature_Aligner = Feature_Aligner
+    fa = Feature_Aligner().to(dev).train()
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).to(dev)
+    with torch.no_grad():
+        fa.feature_embedding_2d[0].weight.copy_(T("W1").reshape(32, 384, 1, 1))
+        fa.feature_embedding_2d[2].weight.copy_(T("W2").reshape(32, 32, 1, 1))
+        fa.feature_embedding_2d[2].bias.copy_(T("b2"))
+    rng = np.random.RandomState(11)
+    B, N = 3, 40
+    v1 = torch.tensor((rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32), device=dev, requires_grad=True)
+    v2 = torch.tensor((rng.standard_normal((B, 16, 8, 8, 8)) * 1.1).astype(np.float32), device=dev, requires_grad=True)
+    gt = torch.from_numpy(ahv.rotations.haar_rotations_np(B, 5)).to(dev)
+    R = torch.from_numpy(ahv.rotations.haar_rotations_np(B * N, 6)).reshape(B, N, 3, 3).to(dev).clone()
+    R[:, 0] = gt
+    ahv.patch.install(um, mm, defer=defer)
+    before, dbefore = dict(ahv.patch.calls), dict(ahv.deferred.counters)
+    try:
+        loss = ref_infonce_verbatim(um.rotate_volume, fa.forward_3d2d, v1, v2, R, gt, 30.0, N)
+        loss.backward()
+    finally:
+        ahv.patch.uninstall()
+    ran = {k: ahv.patch.calls[k] - before[k] for k in before}
+    dran = {k: ahv.deferred.counters[k] - dbefore[k] for k in dbefore}
+    if defer:
+        assert dran == {"deferred_rotations": B, "deferred_forward_3d2d": B, "fused_score_launches": 1, "materialised": 0}, dran   # ONE launch pair for the batch
+        assert ran["forward_3d2d_autograd"] == 1 and ran["rotate_volume_kernel"] == 0 and ran["forward_3d2d_inference"] == 0, ran
+    else:
+        assert dran == {k: 0 for k in dran} and ran["forward_3d2d_autograd"] == B + 1 and ran["rotate_volume_kernel"] == B, (ran, dran)
+    W1, W2, b2 = fa.feature_embedding_2d[0].weight, fa.feature_embedding_2d[2].weight, fa.feature_embedding_2d[2].bias
+    got = [v1.grad, v2.grad, W1.grad.reshape(32, 384), W2.grad.reshape(32, 32), b2.grad]
+    d = lambda t: t.detach().double().cpu().requires_grad_(True)
+    r1, r2, rW1, rW2, rb2 = d(v1), d(v2), d(W1.reshape(32, 384)), d(W2.reshape(32, 32)), d(b2)
+    ref_loss = ref_infonce_verbatim(torch_ref.rotate_volume, lambda x: torch_ref.forward_3d2d(x, rW1, rW2, rb2), r1, r2,
+                                    R.double().cpu(), gt.double().cpu(), 30.0, N)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    for name, a, b in zip(["vol_src", "vol_tgt", "W1", "W2", "b2"], got, [r1.grad, r2.grad, rW1.grad, rW2.grad, rb2.grad]):
+        assert a is not None and a.abs().max().item() > 0, name
+        assert rel(a.cpu(), b) < 2e-4, (name, rel(a.cpu(), b))
+
+
 @pytest.mark.parametrize("shape,shared", [((16, 8, 8, 8), True), ((16, 8, 8, 8), False), ((3, 4, 5, 6), True),
                                           ((3, 4, 5, 6), False)])
 def test_rotate_volume_adjoint_matches_grid_sample_autograd(ahv, dev, shape, shared):

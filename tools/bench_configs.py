@@ -383,6 +383,82 @@ if not only or "pairs" in only:
         print(json.dumps({"config": "evaluation loop, N=50000 per pair", "mode": "16 sequences per batch, AHV_SCORE_SPLIT_F16 (split-f16, opt-in)",
                           "pairs": len(e), "ms_per_pair": dt / len(e) * 1e3, "pairs_per_s": len(e) / dt, "mean_err_deg": float(np.mean(e))}))
 
+if "trainlines" in only:
+    # The reference's infoNCE_loss lines (modules/model_co3d.py:41-61) under patch.install() with the module in training mode,
+    # forward + backward: every sample's rotate_volume .. mean(dim=-1) deferred into ONE differentiable fused launch (default)
+    # against every line as its own differentiable op-level kernel (install(defer=False)), and the mirror's batched training
+    # pair (one launch pair for all samples) for scale.
+    import types
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+
+    class Feature_Aligner(torch.nn.Module):  # noqa: N801
+        def __init__(self):
+            super().__init__()
+            self.feature_embedding_2d = torch.nn.Sequential(torch.nn.Conv2d(384, 32, 1, bias=False), torch.nn.ReLU(),
+                                                            torch.nn.Conv2d(32, 32, 1))
+
+        def forward_3d2d(self, x):
+            raise AssertionError("not patched")
+    mm.Feature_Aligner = Feature_Aligner
+    fa = Feature_Aligner().to(dev).train()
+    with torch.no_grad():
+        fa.feature_embedding_2d[0].weight.copy_(W1.reshape(32, 384, 1, 1))
+        fa.feature_embedding_2d[2].weight.copy_(W2.reshape(32, 32, 1, 1))
+        fa.feature_embedding_2d[2].bias.copy_(b2)
+
+    def infonce(rotate_volume, img_feat_1, img_feat_2, sampled_R, gt_delta_R, num_rota, acc_thr=30.0):
+        bs = gt_delta_R.shape[0]
+        with torch.no_grad():
+            gt_sim = (torch.sum(sampled_R.flatten(2) * gt_delta_R.view(-1, 1, 9), dim=-1).clamp(-1, 3) - 1) / 2
+            gt_dis = torch.arccos(gt_sim) / np.pi
+            posi_indices = [torch.nonzero(180 * gt_dis[i] <= acc_thr).squeeze(-1) for i in range(bs)]
+        img_feat_warp = [rotate_volume(img_feat_1[idx:idx+1].expand(num_rota, -1, -1, -1, -1), sampled_R[idx]) for idx in range(bs)]
+        img_feat_warp = [fa.forward_3d2d(img_feat) for img_feat in img_feat_warp]
+        img_feat_2 = fa.forward_3d2d(img_feat_2)
+        sim = [(img_feat_warp[idx] * img_feat_2[idx:idx+1]).sum(dim=1).mean(dim=-1) for idx in range(bs)]
+        positive_sim = torch.stack([torch.exp(sim[idx][posi_indices[idx]] / 0.1).sum(dim=0) for idx in range(bs)])
+        positive_negative_sim = (torch.exp(torch.stack(sim) / 0.1)).sum(dim=-1)
+        return -torch.log(positive_sim / positive_negative_sim.clamp(min=1e-8)).mean()
+
+    for B, N in ((12, 3000), (32, 9000)):
+        gT = torch.Generator().manual_seed(21)
+        v1 = (torch.randn(B, 16, 8, 8, 8, generator=gT) * 1.15).to(dev).requires_grad_(True)
+        v2 = (torch.randn(B, 16, 8, 8, 8, generator=gT) * 1.15).to(dev).requires_grad_(True)
+        gt = ops.random_rotations(B, seed=5, device=dev)
+        Rs = ops.random_rotations(B * N, seed=6, device=dev).reshape(B, N, 3, 3).clone()
+        Rs[:, 0] = gt
+        row = {"config": "unchanged infoNCE_loss lines, module in training mode, forward + backward", "B": B, "N": N}
+        losses = {}
+        for mode in ("deferred", "op_level"):
+            ahv.patch.install(um, mm, defer=(mode == "deferred"))
+            try:
+                def step():
+                    for p_ in list(fa.parameters()) + [v1, v2]:
+                        p_.grad = None
+                    loss = infonce(um.rotate_volume, v1, v2, Rs, gt, N)
+                    loss.backward()
+                    return loss
+                step()
+                torch.cuda.synchronize()
+                torch.cuda.reset_peak_memory_stats(dev)
+                row[mode + "_ms"] = timeit(step, 3, warm=1)
+                row[mode + "_peak_memory_GB"] = torch.cuda.max_memory_allocated(dev) / 1e9
+                losses[mode] = step().item()
+            finally:
+                ahv.patch.uninstall()
+        row["same_loss"] = abs(losses["deferred"] - losses["op_level"]) < 1e-5 * max(1.0, abs(losses["op_level"]))
+        # the mirror's batched form: one training pair for all samples
+        P = [W1.clone().requires_grad_(True), W2.clone().requires_grad_(True), b2.clone().requires_grad_(True)]
+        gs = torch.randn(B, N, device=dev)
+
+        def batched():
+            ft = ops.forward_3d2d_autograd(v2, *P)
+            s = ops.score_hypotheses_autograd(v1, ft, Rs, *P)
+            return torch.autograd.grad(s, [v1, v2] + P, grad_outputs=gs)
+        row["batched_training_pair_ms"] = timeit(batched, 3, warm=1)
+        print(json.dumps(row), flush=True)
+
 if "optiona" in only:
     # INTEGRATION.md option A under the reference script's own conditions (grad mode on, anomaly detection on, model.eval()):
     # the verbatim per-pair sequence of test_co3d.py:133-152 on a reference-shaped stand-in whose two callables are patched,
