@@ -1,6 +1,6 @@
 """Deferred hypothesis tensors: the UNCHANGED score lines of the reference's evaluation loop as ONE fused launch.
 
-test_co3d.py:137-146 (the same lines are in test_linemod.py / test_objaverse.py) spell the hot loop as separate torch calls:
+test_co3d.py:137-146 (the same lines are in test_linemod.py:49-63 and modules/model.py:186-196) spell the hot loop as separate torch calls:
 
     rot  = [rotate_volume(v[None].expand(N, -1, -1, -1, -1), proposals) for v in img_feat_src]      # (N,16,8,8,8): 1.6 GB at N = 50 000
     rot  = torch.stack(rot).reshape(-1, C, D, H, W)
@@ -18,9 +18,21 @@ storage, only (volume, rotations) -- and the subclass's ``__torch_function__`` r
             --mul by (B,1,32,64)--> product --sum(dim=2)--> channel sum --mean(dim=-1)--> ONE ``ops.score_hypotheses`` launch
 
 and returns the ordinary ``(B, N)`` score tensor the script's ``torch.max`` consumes.  ANY other use of a deferred tensor (another
-operator, another argument, printing, ``.cpu()``, indexing, an in-place write ...) materialises it first with the op-level
-kernels -- the same tensors option A produced before -- and carries on with plain torch: the deferral can cost time, never a
-result.  Nothing here touches autograd: deferral is only entered for volumes that carry no gradient (``patch`` decides).
+operator, another argument, printing a value, ``.cpu()``, indexing, an in-place write ...) materialises it first with the
+op-level kernels -- the same tensors option A produced before -- and carries on with plain torch: the deferral can cost time,
+never a result.
+
+Training (``infoNCE_loss``, modules/model_co3d.py:49-54) spells the same chain per sample, with operands that need gradients:
+
+    warp = [rotate_volume(img_feat_1[i:i+1].expand(N, ...), sampled_R[i]) for i in range(bs)]
+    warp = [forward_3d2d(w) for w in warp]                       # patched; module in training mode: parameters stay attached
+    sim  = [(warp[i] * img_feat_2[i:i+1]).sum(dim=1).mean(dim=-1) for i in range(bs)]
+
+Here ``mean`` returns one more deferred tensor per sample (kind "scores", shape (N,)); the first use of any of them evaluates
+ALL pending ones of the batch -- same head parameters, same N -- in ONE launch of the backend's scorer with per-sample
+rotation sets, under the caller's grad mode: with the HIP backend that is ``ops.score_hypotheses_autograd``, the training pair
+of DESIGN 4.4, and ``loss.backward()`` runs its HIP backward once for the batch.  Fallbacks of a chain that needs gradients run
+the differentiable op-level kernels.  An inference call of ``forward_3d2d`` (``with_head(detach=True)``) cuts every edge.
 
 The arithmetic lives behind a three-function backend (``rotate_volume``, ``forward_3d2d``, ``score_hypotheses``): the HIP
 ``ops`` in production (there is no CPU fallback: ``ops`` raises without the library), a stock-torch backend in the CPU tests

@@ -17,6 +17,7 @@ echo "== pairs" && timeout -k 10 600 python3 tools/bench_configs.py pairs > $O/p
 echo "== option A / B under the reference's conditions" && timeout -k 10 300 python3 tools/bench_configs.py optiona > $O/optiona.jsonl 2> $O/optiona.err; echo rc=$?
 echo "== enc" && timeout -k 10 300 python3 tools/bench_configs.py enc enchost > $O/enc.jsonl 2> $O/enc.err; echo rc=$?
 echo "== train" && timeout -k 10 600 python3 tools/bench_configs.py train train9000 trainstep > $O/train.jsonl 2> $O/train.err; echo rc=$?
+echo "== unchanged infoNCE lines (training mode)" && timeout -k 10 600 python3 tools/bench_configs.py trainlines > $O/trainlines.jsonl 2> $O/trainlines.err; echo rc=$?
 echo "== kbench_enc" && timeout -k 10 300 tools/kbench_enc.bin 1 --each > $O/enc_marginal.txt 2>&1; echo rc=$?
 echo "== kbench_bwd" && timeout -k 10 200 tools/kbench_bwd 32 9000 5 > $O/kbench_bwd.txt 2>&1; echo rc=$?
 echo "== profile backward (PMC)" && timeout -k 10 600 bash tools/profile_kbench_bwd.sh ${1:-eor} 32 9000 > $O/profile_bwd.log 2>&1; echo rc=$?
