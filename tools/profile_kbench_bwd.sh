@@ -21,7 +21,8 @@ python3 - <<PY
 import csv, glob, collections, json
 NH = $B * $N
 FLOPS = {"score_backward_head_kernel": 2101248, "score_backward_w1_kernel": 1703936, "score_backward_volume_kernel": 1703936,
-         "score_backward_volume_rmw_kernel": 1703936}
+         "score_backward_volume_rmw_kernel": 1703936,
+         "score_backward_head_saved_kernel": 393216}   # GEMM2 again from the saved u + dr + dW2 (3 x 2*64*32*32)
 SHIPPED = ("score_backward_head_kernel", "score_backward_w1_kernel", "score_backward_w1_reduce_kernel", "score_backward_volume_rmw_kernel")
 out = {"B": $B, "N": $N, "hypotheses": NH, "command": "tools/kbench_bwd $B $N", "kernels": {}}
 # durations: full-size launches of the kernel trace (the stats pass)
@@ -58,6 +59,14 @@ out["backward_us"] = tot
 out["backward_kernels"] = [k for k in SHIPPED if k in out["kernels"]]
 out["backward_tflops"] = NH * 5509120 / tot / 1e6
 out["backward_frac_fp32_mfma_peak"] = out["backward_tflops"] / 157.3
+# the training pair's backward (what autograd runs): the head kernel that starts from the forward's saved pre-activations
+PAIR = ("score_backward_head_saved_kernel",) + SHIPPED[1:]
+if all(k in out["kernels"] for k in PAIR):
+    tp = sum(out["kernels"][k].get("avg_us", 0.0) for k in PAIR)
+    out["training_pair_backward_us"] = tp
+    out["training_pair_backward_kernels"] = list(PAIR)
+    out["training_pair_backward_executed_flops_per_hypothesis"] = 393216 + 2 * 1703936
+    out["training_pair_backward_frac_fp32_mfma_peak"] = NH * (393216 + 2 * 1703936) / tp / 1e6 / 157.3
 for k, e in out["kernels"].items():
     c = e.get("counters_per_launch", {})
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:   # MI355X_MICROARCH.md, gfx950 correction: (2 FETCH + WRITE) KiB
