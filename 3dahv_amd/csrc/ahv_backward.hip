@@ -28,6 +28,13 @@ namespace ahv {
 
 constexpr int kBwdThreads = 256;  // 4 waves, one per SIMD: 512 registers per wave
 
+// max |du| per sample is what the LDS-atomic dV kernel of rounds 2-5 sizes its fixed-point scale with.  The shipped dV kernel
+// (read-modify-write in fp32, round 6) does not need it, so the head kernels only compute it for the builds that launch the
+// atomic kernel (-DAHV_BWD_VOLUME_ATOMICS, tools/kbench_bwd): ~30 vector instructions per position tile otherwise spent for nothing.
+#if defined(AHV_BWD_VOLUME_ATOMICS) && !defined(AHV_BWD_DU_AMAX)
+#define AHV_BWD_DU_AMAX 1
+#endif
+
 // u / du of one hypothesis in the workspace (2 048 floats): the MFMA accumulator layout of the scorer, tile by tile --
 //   word(o, pos) = ((pos >> 4) * 2 + (o >> 4)) * 256 + (((o >> 2) & 3) * 16 + (pos & 15)) * 4 + (o & 3)
 // i.e. [t][m][lane = 16 kq + n][r] for o = 16 m + 4 kq + r, pos = 16 t + n.  A wave writes and reads a (t, m) fragment with
@@ -229,7 +236,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
                         const float x = acc[m][t][r] > 0.0f ? du[m][t][r] : 0.0f;
                         dst[((t * 2 + m) * 64 + lane) * 4 + r] = x;
                         // max |du| of the sample (kernel 2b sizes its fixed-point scale with it); NaN / inf poison it
+#ifdef AHV_BWD_DU_AMAX
                         du_amax = (x == x) ? fmaxf(du_amax, fabsf(x)) : __builtin_inff();
+#endif
                     }
 
             // dW2 += dv relu(u)^T: the contraction runs over positions, so both operands go through the
@@ -264,9 +273,13 @@ __global__ __launch_bounds__(kBwdThreads, 1) void score_backward_head_kernel(
                 }
             wave_lds_fence();
         }
+#ifdef AHV_BWD_DU_AMAX
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) du_amax = fmaxf(du_amax, __shfl_xor(du_amax, sft, 64));
         if (lane == 0) atomicMax(du_max_bits + b, __float_as_uint(du_amax));  // non-negative floats order like uints
+#else
+        (void)du_amax; (void)du_max_bits;
+#endif
         float* gft = grad_feat_tgt + (long)b * (32 * 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -443,8 +456,10 @@ __global__ __launch_bounds__(kSavedThreads, 2) void score_backward_head_saved_ke
                     x0[r] = a0[r] > 0.0f ? du0[r] : (a0[r] == a0[r] ? 0.0f : a0[r]);
                     x1[r] = a1[r] > 0.0f ? du1[r] : (a1[r] == a1[r] ? 0.0f : a1[r]);
                     // max |du| of the sample (kernel 2b's LDS-atomic form sizes its fixed-point scale with it); NaN / inf poison it
+#ifdef AHV_BWD_DU_AMAX
                     du_amax = (x0[r] == x0[r]) ? fmaxf(du_amax, fabsf(x0[r])) : __builtin_inff();
                     du_amax = (x1[r] == x1[r]) ? fmaxf(du_amax, fabsf(x1[r])) : __builtin_inff();
+#endif
                 }
                 *reinterpret_cast<f32x4*>(dst + t * 512 + lane * 4) = x0;        // du over the tile's u, same words
                 *reinterpret_cast<f32x4*>(dst + t * 512 + 256 + lane * 4) = x1;
@@ -469,9 +484,13 @@ __global__ __launch_bounds__(kSavedThreads, 2) void score_backward_head_saved_ke
                 wave_lds_fence();
             }
         }
+#ifdef AHV_BWD_DU_AMAX
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) du_amax = fmaxf(du_amax, __shfl_xor(du_amax, sft, 64));
         if (lane == 0) atomicMax(du_max_bits + b, __float_as_uint(du_amax));  // non-negative floats order like uints
+#else
+        (void)du_amax; (void)du_max_bits;
+#endif
         float* gft = grad_feat_tgt + (long)b * (32 * 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t)

@@ -15,5 +15,6 @@ timeout 900 hipcc $F -DAHV_DIAG_NO_EXACT tools/kbench.cpp -o tools/kbench_noexac
 timeout 900 hipcc $F -DAHV_DIAG_TEAMS_LAST tools/kbench.cpp -o tools/kbench_teams_last
 timeout 900 hipcc $F -DAHV_DIAG_NO_FP32_LOW_HALF tools/kbench_bwd.cpp -o tools/kbench_bwd_nolowhalf   # the backward kernels WITHOUT it (they ship with it)
 timeout 900 hipcc $F tools/kbench_bwd.cpp -o tools/kbench_bwd
+timeout 900 hipcc $F -DAHV_BWD_DU_AMAX tools/kbench_bwd.cpp -o tools/kbench_bwd_atomics   # + the LDS-atomic dV kernel of rounds 2-5 for A/B
 # forward_2d3d from a replayed hipGraph with per-launch marginal costs (tools/gpu_run.sh encoder)
 timeout 900 hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAHV_ENC_PROBE -I3dahv_amd/csrc -Iinclude tools/kbench_enc.cpp -o tools/kbench_enc.bin

@@ -2,6 +2,8 @@
 // size (B = 12 per-sample rotation sets of N = 3000), kernel by kernel, with diagnostic switches
 // (-DAHV_DIAG_NO_ATOMICS, -DAHV_DIAG_NO_DX: wrong results, to price a component).  Not part of the product.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I3dahv_amd/csrc -Iinclude tools/kbench_bwd.cpp -o tools/kbench_bwd
+// (the kernels as the library launches them).  With -DAHV_BWD_DU_AMAX -o tools/kbench_bwd_atomics the head kernels also produce
+// max |du| per sample and the LDS-atomic dV kernel of rounds 2-5 is timed and compared beside the read-modify-write one.
 #include "../3dahv_amd/csrc/ahv_backward.hip"
 
 #include <algorithm>
@@ -67,7 +69,9 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(ahv::score_backward_w1_kernel, grid, dim3(ahv::kW1Threads), 0, 0, dvol, dR, (long)(N * 9), B, N, dws, dpart);
         hipLaunchKernelGGL(ahv::score_backward_w1_reduce_kernel, dim3(32 * 384 / 256, 16), dim3(256), 0, 0, dpart, gx * gy, gW1);
         CK(hipEventRecord(e[2], 0));
+#ifdef AHV_BWD_DU_AMAX   // the LDS-atomic dV kernel of rounds 2-5 (needs max |du| per sample from the head kernel: kbench_bwd_atomics)
         hipLaunchKernelGGL(ahv::score_backward_volume_kernel, grid, dim3(ahv::kVolThreads), 0, 0, dR, (long)(N * 9), dW1, B, N, dws, dmax, gvol);
+#endif
         CK(hipEventRecord(e[3], 0));
         // round 6: the same gradient without LDS atomics (private fp32 images, read-modify-write), into its own buffer
         CK(hipMemsetAsync(gvol2, 0, vol.size() * 4, 0));
@@ -94,8 +98,12 @@ int main(int argc, char** argv)
     CK(hipMemcpy(hv2.data(), gvol2, vol.size() * 4, hipMemcpyDeviceToHost));
     double mx = 0, md = 0;
     for (size_t i = 0; i < hv.size(); ++i) { mx = std::max(mx, (double)std::fabs(hv[i])); md = std::max(md, (double)std::fabs(hv[i] - hv2[i])); }
+#ifdef AHV_BWD_DU_AMAX
     printf("B=%d N=%ld: head %.3f ms  dW1 %.3f ms  dV %.3f ms (LDS atomics)  total %.3f ms   (grad_vol[0..2] = %g %g %g)\n", B, N, t[0] / iters,
            t[1] / iters, t[2] / iters, (t[0] + t[1] + t[2]) / iters, hv[0], hv[1], hv[2]);
+#else
+    printf("B=%d N=%ld: head %.3f ms  dW1 %.3f ms   (grad_vol[0..2] = %g %g %g)\n", B, N, t[0] / iters, t[1] / iters, hv2[0], hv2[1], hv2[2]);
+#endif
 #ifdef AHV_RMW_STAMPS
     {
         unsigned long long hs[64];
@@ -111,8 +119,13 @@ int main(int argc, char** argv)
         }
     }
 #endif
+#ifdef AHV_BWD_DU_AMAX
     printf("           dV read-modify-write kernel %.3f ms  total with it %.3f ms   max |difference| / max |dV| = %.2e\n", t[3] / iters,
            (t[0] + t[1] + t[3]) / iters, md / mx);
+#else
+    (void)md; (void)mx;
+    printf("           dV read-modify-write kernel %.3f ms  recomputing backward %.3f ms\n", t[3] / iters, (t[0] + t[1] + t[3]) / iters);
+#endif
     printf("           head kernel of the training pair (u saved by the forward) %.3f ms  total with it %.3f ms\n", t[4] / iters,
            (t[4] + t[1] + t[3]) / iters);
     return 0;
