@@ -48,6 +48,25 @@ static int g_enc_probe_dup = 0;
 namespace ahv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Output stores of the big launches (experiment knobs, A/B on one box with tools/kbench_enc): non-temporal stores leave less
+// dirty data in the L2s for the write-back at the end of a kernel, which sits between every two launches of this forward.
+#ifndef AHV_TILE_NT_STORES
+#define AHV_TILE_NT_STORES 1
+#endif
+#ifndef AHV_ROW_NT_STORES
+#define AHV_ROW_NT_STORES 0
+#endif
+#if AHV_TILE_NT_STORES
+#define AHV_TILE_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define AHV_TILE_STORE(p, v) (*(p) = (v))
+#endif
+#if AHV_ROW_NT_STORES
+#define AHV_ROW_STORE4(p, v) __builtin_nontemporal_store((v), reinterpret_cast<f32x4*>(p))
+#else
+#define AHV_ROW_STORE4(p, v) (*reinterpret_cast<f32x4*>(p) = (v))
+#endif
+
 
 constexpr int kMaxProb = 4;
 
@@ -411,6 +430,9 @@ struct TileArgs {
     long ldx, ldw;
     int geglu_h;
     const float* zero;    // CONV: 64 bytes of zeros (what a tap outside the 8 x 8 image reads)
+#ifdef AHV_ENC_PROBE
+    unsigned long long* stamps;
+#endif
 };
 
 // K pipeline (round 5): four LDS stages filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write --
@@ -466,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     const LinProb pr = a.p[pi];
     const int tile = (int)blockIdx.x - pr.tile0;
     const int m0 = blockIdx.y * T;
+    AHV_ENC_STAMP(0);
     const int r16 = lane & 15, kq = lane >> 4;
     // staging: thread -> (row = tid / 4 (+64), 16-byte chunk = tid % 4) of both tiles
     const int srow = tid >> 2, sch = tid & 3;
@@ -570,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
     gload(nk > 2 ? 2 : nk - 1, 2);
     __builtin_amdgcn_s_waitcnt(kWait);
     __builtin_amdgcn_s_barrier();
+    AHV_ENC_STAMP(1);
     fread(f0, 0);
     if (AHV_DIAG_TILE & 4) fread(f1, 0);
     // (a wait here, or hipcc carries "f0 pending" into the loop)
@@ -579,6 +603,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
         kstep(kt + 1, f1, f0);
     }
     __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the repeated loads have landed before the LDS is given up
+    AHV_ENC_STAMP(4);
     // D layout: acc[i][j][r] = C[m0 + 16 TM wr + 16 i + 4 kq + r][column 16 TM wc + 16 j + r16 of the tile]: 4-byte stores, four
     // 64-byte row segments per instruction.  (The transposed tiles -- W rows as the A operand, a lane then holds four
     // consecutive columns and stores 16 bytes, sixteen 64-byte row segments per instruction -- measured 1-3 % SLOWER.)
@@ -595,8 +620,8 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
                     const long row = m0 + 64 * wr + 16 * i + 4 * kq + r;
                     const f32x2 y = geglu_pk(f32x2{acc[i][j][r] + bv, acc[i][j][r + 1] + bv},
                                              f32x2{acc[i][j + 2][r] + bg, acc[i][j + 2][r + 1] + bg});
-                    pr.P[row * H + col] = y[0];
-                    pr.P[(row + 1) * H + col] = y[1];
+                    AHV_TILE_STORE(pr.P + row * H + col, y[0]);
+                    AHV_TILE_STORE(pr.P + (row + 1) * H + col, y[1]);
                 }
         }
     } else {
@@ -609,9 +634,10 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(const TileArgs a)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    P[(long)(m0 + 16 * TM * wr + 16 * i + 4 * kq + r) * pr.N + col] = acc[i][j][r] + bias;
+                    AHV_TILE_STORE(P + (long)(m0 + 16 * TM * wr + 16 * i + 4 * kq + r) * pr.N + col, acc[i][j][r] + bias);
         }
     }
+    AHV_ENC_STAMP(6);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -762,7 +788,7 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
         float* out = pr.P + ((long)h * M + b * 64 + (it0 + t) * 16 + c16) * 256 + w * 64 + 4 * kq;
         if (t == 0) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); AHV_ENC_STAMP(5); }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(out + nt * 16) = acc[nt];
+        for (int nt = 0; nt < 4; ++nt) AHV_ROW_STORE4(out + nt * 16, acc[nt]);
         if (t == QT - 1) AHV_ENC_STAMP(6);
         if (QT > 1) {
 #pragma unroll
@@ -923,7 +949,7 @@ __global__ __launch_bounds__(256) void attention_sample_head_kernel(const AttnOu
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][dt], ot[dt][r], acc[i], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(out + 16 * (4 * ng + i)) = acc[i];
+        for (int i = 0; i < 4; ++i) AHV_ROW_STORE4(out + 16 * (4 * ng + i), acc[i]);
     }
     AHV_ENC_STAMP(6);
 }
@@ -969,10 +995,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnArgs a)
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     const f32x4 y = d * rstd * gam + bet;
     if (CONCAT) {
-        *reinterpret_cast<f32x4*>(pr.out + (long)row * 512 + 4 * lane) = xin;
-        *reinterpret_cast<f32x4*>(pr.out + (long)row * 512 + 256 + 4 * lane) = y;
+        AHV_ROW_STORE4(pr.out + (long)row * 512 + 4 * lane, xin);
+        AHV_ROW_STORE4(pr.out + (long)row * 512 + 256 + 4 * lane, y);
     } else {
-        *reinterpret_cast<f32x4*>(pr.out + (long)row * 256 + 4 * lane) = xin + y;
+        AHV_ROW_STORE4(pr.out + (long)row * 256 + 4 * lane, xin + y);
     }
 }
 
@@ -1185,6 +1211,9 @@ static hipError_t launch_linear_tile(const LinSpec* specs, int nprob, long ldx, 
         if (i < nprob) tiles += geglu_h > 0 ? geglu_h / 64 : sp.N / tile;
     }
     a.zero = zero;
+#ifdef AHV_ENC_PROBE
+    a.stamps = AHV_ENC_STAMP_PTR;
+#endif
     const dim3 grid(tiles, M / tile, geglu_h > 0 ? 1 : KS);
     if (zero != nullptr) {  // the 3 x 3 convolution as an implicit GEMM (K = 9 x 256)
         if (tile != 64 || geglu_h > 0 || K != 2304 || ldx != 256) return hipErrorInvalidValue;

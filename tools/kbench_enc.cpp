@@ -128,6 +128,22 @@ int main(int argc, char** argv)
             for (int g = 0; g < 1024; ++g) if (st[g * 8]) { if (st[g * 8] < t0) t0 = st[g * 8]; nwg = g + 1; }
             if (!nwg) continue;
             printf("launch %2d %-48s %d workgroups\n", k + 1, g_enc_probe_names[k], nwg);
+            if (strstr(g_enc_probe_names[k], "linear_tile_kernel")) {   // slots: 0 entry, 1 first tiles landed, 4 K loop done, 6 exit
+                std::vector<double> ent, ex;
+                double pro = 0, kl = 0, epi = 0; int c = 0;
+                for (int g = 0; g < nwg; ++g) if (st[g * 8] && st[g * 8 + 6]) {
+                    ent.push_back((st[g * 8] - t0) * 0.01); ex.push_back((st[g * 8 + 6] - t0) * 0.01);
+                    pro += (st[g * 8 + 1] - st[g * 8]) * 0.01; kl += (st[g * 8 + 4] - st[g * 8 + 1]) * 0.01; epi += (st[g * 8 + 6] - st[g * 8 + 4]) * 0.01; ++c;
+                }
+                if (!c) continue;
+                std::sort(ent.begin(), ent.end()); std::sort(ex.begin(), ex.end());
+                printf("    entry time deciles:");
+                for (int d = 0; d <= 10; ++d) printf(" %.2f", ent[std::min(ent.size() - 1, d * ent.size() / 10)]);
+                printf("\n    exit time deciles: ");
+                for (int d = 0; d <= 10; ++d) printf(" %.2f", ex[std::min(ex.size() - 1, d * ex.size() / 10)]);
+                printf("\n    per workgroup: first tiles landed +%.2f us, K loop %.2f us, epilogue %.2f us\n", pro / c, kl / c, epi / c);
+                continue;
+            }
             if (strstr(g_enc_probe_names[k], "attention")) {   // slots: entry, scores, softmax share, merge barrier, O share, projection, exit
                 std::vector<double> ent, ex;
                 for (int g = 0; g < nwg; ++g) if (st[g * 8]) { ent.push_back((st[g * 8] - t0) * 0.01); ex.push_back((st[g * 8 + 6] - t0) * 0.01); }
