@@ -307,6 +307,18 @@ class VerifyLoop:
         self.out = {"best": best[j], "idx": idx[j], "R_pred": R_pred[j]}
 
 
+def default_lanes(world: int, n_total: int) -> int:
+    """Lanes of the step loop a run takes unless AHV_BENCH_LANES says otherwise.  Two lanes pay when a rank's launch is
+    SHORT -- the ~18 us of drain, launch gap and prologue that do not shrink with N are then worth overlapping -- and cost
+    when it is long: two persistent grids sized for the whole chip then queue for the same CUs.  Measured on one GPU
+    (secondary.predicted_strong_scaling): 6 250 hypotheses per rank 0.0988 against 0.1059 ms per step, 12 500: 0.181 / 0.186,
+    25 000: 0.404 / 0.352, 50 000: 0.716 / 0.687.  So: two lanes from 4 ranks on (<= AHV_BENCH_TWO_LANES_MAX_N = 16 384
+    hypotheses per rank), one lane at 1 and 2 ranks.  The same on every rank (it depends on the world size alone)."""
+    if world <= 1:
+        return 2 if os.environ.get("AHV_BENCH_TWO_LANES_PG", "0") == "1" else 1
+    return 2 if n_total // world <= int(os.environ.get("AHV_BENCH_TWO_LANES_MAX_N", "16384")) else 1
+
+
 def rank_identity(torch, dev, rank, local_rank, backend):
     """What a reader of a multi-rank line looks for first: which physical GPU each rank drove."""
     p = torch.cuda.get_device_properties(dev)
@@ -389,11 +401,12 @@ def worker(args):
     # strong scaling: ONE set of 50 000 hypotheses, this rank's contiguous shard of it
     lo, hi = adist.shard_range(N_HYP, rank, world)
     R, n_offset, n_local = R_all[lo:hi].contiguous(), lo, hi - lo
-    # Lanes: with more than one rank the step loop runs on TWO lanes -- groups of steps alternate between two streams, each
-    # with its own key buffer and its own communicator, so that one step's drain (the wait for the slowest workgroup, the
-    # launch gap, the next prologue: ~18 us that do not shrink with N) overlaps the next step's hypotheses.
+    # Lanes: where a rank's shard is short (4 ranks and more) the step loop runs on TWO lanes -- groups of steps alternate
+    # between two streams, each with its own key buffer and its own communicator, so that one step's drain (the wait for the
+    # slowest workgroup, the launch gap, the next prologue: ~18 us that do not shrink with N) overlaps the next step's
+    # hypotheses (default_lanes above has the measurements behind the rule).
     # One rank: one lane, one stream -- the N = 1 line is the same measurement as in every earlier round.
-    lanes = int(os.environ.get("AHV_BENCH_LANES", "2" if (world > 1 or os.environ.get("AHV_BENCH_TWO_LANES_PG", "0") == "1") else "1"))
+    lanes = int(os.environ.get("AHV_BENCH_LANES", str(default_lanes(world, N_HYP))))
     lanes = max(1, min(lanes, 2))
     loop = VerifyLoop(ops, dist, dev, vol_src, vol_tgt, R, head, n_offset, use_pg, group, split, lanes=lanes)
     ncu = lib.ahv_device_cu_count()
@@ -595,7 +608,7 @@ def worker(args):
             s32, _ = ops.verify_pair(vs32, vt32, R_all, *head, split_f16=split)
             assert torch.equal(lp3.out["idx"], torch.max(s32, dim=1)[1])
             del s32
-            # the other lane count: one rank times two lanes beside its one-stream headline; a multi-rank run (two lanes by
+            # the other lane count: a run on one lane times two lanes beside its headline; a run on two lanes (4 ranks and more by
             # default, each lane its own communicator) times the one-stream loop beside it
             if lanes == 1:
                 lp2, secondary["n50k_b1_two_lanes"] = leg(vol_src, vol_tgt, R_all, 2 * sec_steps, 48, grp=max(group, 4), lanes=2)
@@ -624,6 +637,9 @@ def worker(args):
                         row["efficiency" + suffix[nl]] = t_ref[nl] / (n * r["ms_per_step"])
                         # what the driver computes: the N-rank value over N times the ONE-rank, one-lane value
                         row["efficiency_vs_one_lane_n1" + suffix[nl]] = t_ref[1] / (n * r["ms_per_step"])
+                    # ... for the lane count a --gpus n run takes by default (default_lanes)
+                    row["default_lanes"] = default_lanes(n, N_HYP)
+                    row["efficiency_default"] = row["efficiency_vs_one_lane_n1" + suffix[row["default_lanes"]]]
                     pred["n_gpus_%d" % n] = row
                 pred["ms_per_step_n50k"] = t_ref[1]
                 pred["ms_per_step_n50k_two_lanes"] = t_ref[2]

@@ -86,6 +86,9 @@ def test_bench_json_line():
         row = p["n_gpus_%d" % n]
         assert row["n_hyp_per_rank"] == per and 0.5 < row["efficiency"] <= 1.05 and 0.5 < row["efficiency_two_lanes"] <= 1.1
         assert abs(row["efficiency"] - p["ms_per_step_n50k"] / (n * row["ms_per_step"])) < 1e-9
+        # the lane count a --gpus n run takes by default, and the efficiency the driver would compute for it
+        assert row["default_lanes"] == (1 if n == 2 else 2)
+        assert row["efficiency_default"] == row["efficiency_vs_one_lane_n1" + ("" if n == 2 else "_two_lanes")]
     assert p["n_gpus_2"]["efficiency"] > p["n_gpus_8"]["efficiency"]
 
 
@@ -143,6 +146,9 @@ def test_bench_launches_its_own_ranks():
     """`python3 bench.py --gpus 2` (no external launcher) spawns its two workers before touching the GPU; on this
     1-GPU box the ranks share the device over gloo (a rehearsal of the sharded path, not a measurement)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # (two lanes are the default from 4 ranks on -- shards of at most 16 384 hypotheses; this 2-rank rehearsal raises the bound so
+    # that the path with two communicators per rank is the one that runs)
+    env["AHV_BENCH_TWO_LANES_MAX_N"] = "25000"
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
                           "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
                          timeout=900, cwd=REPO, env=env)
@@ -159,7 +165,7 @@ def test_bench_launches_its_own_ranks():
     assert sec["n50k_b1_collective_per_step"]["steps_per_collective"] == 1 and d["config"]["steps_per_collective"] == 8
     assert sec["weak_n50k_per_rank_b1"]["n_hyp_total"] == 100000 and sec["weak_n50k_per_rank_b1"]["n_hyp_per_rank"] == 50000
     assert sec["configs3_b32_n50k"]["n_hyp_per_rank"] == 25000 and "predicted_strong_scaling" not in sec
-    # more than one rank: two lanes (two communicators) by default, the one-stream loop timed beside it
+    # two lanes (two communicators per rank), the one-stream loop timed beside it
     assert d["config"]["lanes"] == 2 and sec["n50k_b1_one_stream"]["lanes"] == 1 and "n50k_b1_two_lanes" not in sec
     assert "calibration leg" in d["roofline"]["kernel_ms_is"]
     # which GPU each rank drove (here: both ranks on the one device of the box, over gloo)

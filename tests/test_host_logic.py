@@ -160,3 +160,20 @@ def test_estimator_tries_the_reference_backbone_factory(ahv, tmp_path, monkeypat
         sys.modules.pop("hubconf", None)
         if str(midas) in sys.path:
             sys.path.remove(str(midas))
+
+
+def test_bench_lane_rule(monkeypatch):
+    """bench.py default_lanes: one lane at 1 and 2 ranks (25 000 hypotheses per rank: two chip-sized grids would queue for the
+    same CUs), two lanes from 4 ranks on (the fixed ~18 us of a short launch are worth overlapping); the same on every rank."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("AHV_BENCH_TWO_LANES_PG", "AHV_BENCH_TWO_LANES_MAX_N"):
+        monkeypatch.delenv(k, raising=False)
+    assert [bench.default_lanes(w, 50000) for w in (1, 2, 3, 4, 6, 8)] == [1, 1, 1, 2, 2, 2]
+    monkeypatch.setenv("AHV_BENCH_TWO_LANES_MAX_N", "25000")
+    assert bench.default_lanes(2, 50000) == 2 and bench.default_lanes(1, 50000) == 1
+    monkeypatch.setenv("AHV_BENCH_TWO_LANES_PG", "1")
+    assert bench.default_lanes(1, 50000) == 2
