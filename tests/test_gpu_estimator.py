@@ -295,6 +295,70 @@ def test_option_a_under_the_reference_scripts_own_conditions(ahv, dev, defer):
     print("option A (defer=%s) peak memory %.3f GB (the script's own tensors, materialised: %.2f GB)" % (defer, peak / 1e9, own / 1e9))
 
 
+def test_patched_linemod_and_validation_lines_with_a_batch(ahv, dev, g128):
+    """The other two call sites of the chain under patch.install(): test_linemod.py:45-63 (B pairs per step, plus the
+    ground-truth line `rotate_volume(img_feat_src, gt_R)` .. `(f_gt * f_tgt).sum(dim=1).mean(dim=-1)`) and
+    modules/model.py:183-196 (`.reshape(B, self.num_rota, -1, H*W)`), here with B = 2: deferred and op-level runs agree with
+    each other and with the stock-operator restatement; the deferred run is ONE fused launch for the B x N hypotheses."""
+    import types
+    from oracle import torch_ref
+    um, mm = types.ModuleType("utils"), types.ModuleType("modules.modules")
+    um.rotate_volume = lambda *a, **k: None
+
+    class Feature_Aligner(torch.nn.Module):  # noqa: N801
+        def __init__(self):
+            super().__init__()
+            self.feature_embedding_2d = torch.nn.Sequential(torch.nn.Conv2d(384, 32, 1, bias=False), torch.nn.ReLU(),
+                                                            torch.nn.Conv2d(32, 32, 1))
+
+        def forward_3d2d(self, x):
+            raise AssertionError("not patched")
+    mm.Feature_Aligner = Feature_Aligner
+    fa = Feature_Aligner().to(dev).eval()
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(g128[k])).to(dev)
+    with torch.no_grad():
+        fa.feature_embedding_2d[0].weight.copy_(T("W1").reshape(32, 384, 1, 1))
+        fa.feature_embedding_2d[2].weight.copy_(T("W2").reshape(32, 32, 1, 1))
+        fa.feature_embedding_2d[2].bias.copy_(T("b2"))
+    codebook = T("R")
+    img_feat_src = torch.cat([T("vol_src"), T("vol_tgt").flip(2)])          # B = 2
+    img_feat_tgt0 = torch.cat([T("vol_tgt"), T("vol_src").flip(3)])
+    gt_src_2_tgt_R = codebook[[5, 9]]
+
+    def lines(rotate_volume, forward_3d2d):     # test_linemod.py:45-63
+        img_feat_tgt = img_feat_tgt0
+        B, C, D, H, W = img_feat_src.shape
+        img_feat_src_2_tgt = [rotate_volume(img_feat[None].expand(codebook.shape[0], -1, -1, -1, -1), codebook) for img_feat in img_feat_src]
+        img_feat_src_2_tgt = torch.stack(img_feat_src_2_tgt).reshape(-1, C, D, H, W)
+        img_feat_src_2_tgt = forward_3d2d(img_feat_src_2_tgt).reshape(B, codebook.shape[0], -1, H*W)
+        img_feat_src_2_tgt_gt = rotate_volume(img_feat_src, gt_src_2_tgt_R)
+        img_feat_src_2_tgt_gt = forward_3d2d(img_feat_src_2_tgt_gt)
+        img_feat_tgt = forward_3d2d(img_feat_tgt)
+        pred_sim = (img_feat_src_2_tgt * img_feat_tgt[:, None]).sum(dim=2).mean(dim=-1)
+        gt_sim = (img_feat_src_2_tgt_gt * img_feat_tgt).sum(dim=1).mean(dim=-1)
+        pred_index = torch.max(pred_sim, dim=1)[1]
+        return pred_sim, gt_sim, pred_index, codebook[pred_index]
+    out = {}
+    for defer in (True, False):
+        ahv.patch.install(um, mm, defer=defer)
+        before = dict(ahv.deferred.counters)
+        try:
+            out[defer] = lines(um.rotate_volume, fa.forward_3d2d)
+        finally:
+            ahv.patch.uninstall()
+        ran = {k: ahv.deferred.counters[k] - before[k] for k in before}
+        if defer:   # the B x N chain: one launch; the ground-truth line is a batch of materialised volumes: not deferred at all
+            assert ran == {"deferred_rotations": 2, "deferred_forward_3d2d": 1, "fused_score_launches": 1, "materialised": 0}, ran
+        else:
+            assert ran == {k: 0 for k in ran}, ran
+    W = [T("W1"), T("W2"), T("b2")]
+    ref = lines(torch_ref.rotate_volume, lambda x: torch_ref.forward_3d2d(x, *W))
+    for got in out.values():
+        assert torch.allclose(got[0], ref[0], rtol=1e-4, atol=1e-6) and torch.allclose(got[1], ref[1], rtol=1e-4, atol=1e-6)
+        assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6)
+
+
 def test_deferred_hypotheses_fall_back_to_the_op_level_kernels(ahv, dev, g128):
     """Whatever else a script does with the deferred tensors of patch.install(): the values are those of the op-level kernels
     (deferred.py: the deferral can cost time, never a result).  The CPU suite checks the bookkeeping on a torch backend
