@@ -673,8 +673,10 @@ struct AttnOutArgs {
 // (sample, head) with the K, V and W_out fragments it holds in registers (96 of the ~100 KB a workgroup reads; only Q changes
 // per tile, requested a tile ahead).  At B = 32 it changes nothing (see AHV_ATTN_QT at the launch): the launch is bound by the
 // dependent chain of a tile (16 + 16 + 64 MFMAs, two barriers, a softmax), not by its 100 MB of L2 reads.
+// (sample, head) pairs from which attention_sample_head_kernel runs (tools/kbench_enc, both kernels alternating on one box, us per
+// forward: B = 8 -- 64 pairs -- 751 with the tile-wise kernel / 784 with this one; B = 16: 1 106 / 1 111; B = 24: 1 606 / 1 596; B = 32: 1 919 / 1 895)
 #ifndef AHV_ATTN_PAIR_MIN_WGS
-#define AHV_ATTN_PAIR_MIN_WGS 256
+#define AHV_ATTN_PAIR_MIN_WGS 192
 #endif
 template <int QT>
 __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs a, int M)
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const AttnOutArgs 
 }
 
 // -------------------------------------------------------------------------------------------------
-// The same launch for MANY samples (B >= 32, round 6): one workgroup per (sample, head), wave w owns the 16 queries of
+// The same launch for MANY samples (B >= 24, round 6): one workgroup per (sample, head), wave w owns the 16 queries of
 // tile w against ALL 64 keys.  The in-kernel timeline of the kernel above at B = 32 (tools/kbench_enc.bin 32 --stamps,
 // profiles/r06_attention_timeline_b32.txt) showed what its 17.9 us are: 1 024 workgroups of ~150 registers run three per CU,
 // so a quarter of them waits 11 us for a slot; every workgroup spends its first 4.2 us fetching 100 KB of operands with
@@ -1289,7 +1291,7 @@ static int run_block_pair(const ahv_block_weights* const w[2], const float* cons
 #ifdef AHV_ENC_PROBE
         ao.stamps = AHV_ENC_STAMP_PTR;
 #endif
-        // from 256 (sample, head) pairs on: one workgroup per pair (attention_sample_head_kernel)
+        // from 192 (sample, head) pairs on (B >= 24): one workgroup per pair (attention_sample_head_kernel)
         if (2 * B * 4 >= AHV_ATTN_PAIR_MIN_WGS) AHV_ENC_LAUNCH(attention_sample_head_kernel, dim3(2 * B, 4), dim3(256), 0, s, ao, M);
         else if (B >= 32 && AHV_ATTN_QT == 4) AHV_ENC_LAUNCH(attention_heads_kernel<4>, dim3(2 * B, 1, 4), dim3(256), 0, s, ao, M);
         else if (B >= 32 && AHV_ATTN_QT == 2) AHV_ENC_LAUNCH(attention_heads_kernel<2>, dim3(2 * B, 2, 4), dim3(256), 0, s, ao, M);
