@@ -305,6 +305,8 @@ class DeferredHypotheses(torch.Tensor):
                     # the per-sample form (infoNCE_loss builds `sim` as a list over the batch, modules/model_co3d.py:54): the
                     # scores stay deferred until the first of them is used, and ALL samples' scores are then one launch
                     d = DeferredHypotheses(shape[:1], replace(self._ahv, kind="scores"))
+                    if len(_pending) >= 256:   # (references to tensors that were dropped unused)
+                        _pending[:] = [r for r in _pending if r() is not None]
                     _pending.append(weakref.ref(d))
                     return d
                 return self._scores()
