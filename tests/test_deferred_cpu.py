@@ -227,3 +227,62 @@ def test_pending_scores_are_grouped_by_batch_and_survive_odd_orders(be, data):
     del d_                                                           # never used: nothing is launched for it
     e = sample(1, head)
     assert torch.allclose(e.exp(), eager(1, head).exp(), atol=1e-6) and be["fused"] == 3
+
+
+def test_random_programs_agree_with_the_eager_sequence(be, data):
+    """300 random operator sequences on deferred tensors against the same sequences on the eager tensors: whatever mixture
+    of chain links and other operators a script applies, shapes agree after every step and values at the end."""
+    import random
+    vols, tgt, R, head = data
+    f_tgt = tr.forward_3d2d(tgt, *head)
+    rng = random.Random(7)
+
+    def start(bv):
+        d = [D.defer_rotate_volume(vols[i][None].expand(N, -1, -1, -1, -1), R) for i in range(bv)]
+        e = [tr.rotate_volume(vols[i][None].expand(N, -1, -1, -1, -1), R) for i in range(bv)]
+        return (torch.stack(d), torch.stack(e)) if (bv > 1 or rng.random() < 0.5) else (d[0], e[0])
+    head_fn = lambda x: x.with_head(*head) if isinstance(x, D.DeferredHypotheses) and x.deferred_kind == "rotated" and x.dim() == 5 \
+        else tr.forward_3d2d(x.reshape(-1, 16, 8, 8, 8) if x.shape[-4:] == (16, 8, 8, 8) else x, *head)
+    menu = [
+        ("flat5", lambda x, bv: x.reshape(-1, 16, 8, 8, 8)),
+        ("lead5", lambda x, bv: x.reshape(bv, N, 16, 8, 8, 8)),
+        ("view5", lambda x, bv: x.view(bv * N, 16, 8, 8, 8)),
+        ("head", lambda x, bv: head_fn(x)),
+        ("feat4", lambda x, bv: x.reshape(bv, N, -1, 64)),
+        ("feat3", lambda x, bv: x.reshape(bv * N, 32, 64)),
+        ("mul_tgt", lambda x, bv: x * f_tgt[:bv, None]),
+        ("rmul_tgt", lambda x, bv: f_tgt[:bv, None] * x),
+        ("mul_one", lambda x, bv: x * f_tgt[:1]),
+        ("sum2", lambda x, bv: x.sum(dim=2)),
+        ("sum1", lambda x, bv: x.sum(dim=1)),
+        ("sum_neg2", lambda x, bv: x.sum(-2)),
+        ("mean_last", lambda x, bv: x.mean(dim=-1)),
+        ("mean_keep", lambda x, bv: x.mean(dim=-1, keepdim=True)),
+        ("add", lambda x, bv: x + 0.5),
+        ("neg", lambda x, bv: -x),
+        ("index", lambda x, bv: x[..., 1:]),
+        ("transpose", lambda x, bv: x.transpose(-1, -2)),
+        ("contig", lambda x, bv: x.contiguous()),
+        ("double", lambda x, bv: x.double().float()),
+    ]
+    ran = 0
+    for _ in range(300):
+        bv = rng.choice([1, 1, 2])
+        d, e = start(bv)
+        trace = []
+        chain = ["flat5", "head", "feat4", rng.choice(["mul_tgt", "rmul_tgt"]), rng.choice(["sum2", "sum_neg2"]), "mean_last"]
+        prefix = chain[:rng.randint(0, 6)] if rng.random() < 0.5 else []        # half of the programs start along the chain
+        steps = [next(m for m in menu if m[0] == n) for n in prefix] + [rng.choice(menu) for _ in range(rng.randint(1, 4))]
+        for name, op in steps:
+            try:
+                e2 = op(e, bv)
+            except Exception:
+                continue                      # not applicable to the eager tensor at this point: skip the step for both
+            d = op(d, bv)
+            e = e2
+            trace.append(name)
+            assert tuple(d.shape) == tuple(e.shape), (trace, tuple(d.shape), tuple(e.shape))
+        got = d + 0.0 if isinstance(d, D.DeferredHypotheses) else d
+        assert torch.allclose(got, e, rtol=1e-5, atol=1e-6, equal_nan=True), (trace, (got - e).abs().max().item())   # (means of empty slices: NaN in both)
+        ran += 1
+    assert ran == 300 and be["fused"] > 0 and be["rotate"] > 0        # both the fused launch and the fallbacks were exercised
