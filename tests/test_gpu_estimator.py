@@ -1,6 +1,8 @@
 """Estimator / harness call surface on the GPU: the verify step inside them is the fused HIP launch;
 checked against the reference's op sequence issued with stock torch operators (oracle/torch_ref.py)
 on the same device and against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -357,6 +359,64 @@ def test_patched_linemod_and_validation_lines_with_a_batch(ahv, dev, g128):
         assert torch.allclose(got[0], ref[0], rtol=1e-4, atol=1e-6) and torch.allclose(got[1], ref[1], rtol=1e-4, atol=1e-6)
         assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
     assert torch.allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6)
+
+
+def test_unchanged_script_through_the_runner(ahv, dev, g128, tmp_path):
+    """`python ahv_run.py script.py`: a stand-in checkout whose `utils.rotate_volume` and `Feature_Aligner.forward_3d2d` RAISE
+    unless rebound, and a script with the reference's own lines (test_co3d.py:135-146) and not one line of ours -- run in its
+    own process on the GPU, it prints fixture G1's arg-max and best score."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "modules").mkdir()
+    (tmp_path / "modules" / "__init__.py").write_text("")
+    (tmp_path / "utils.py").write_text("def rotate_volume(volume, rotation_matrix, padding_mode='zeros'):\n"
+                                       "    raise AssertionError('utils.rotate_volume was not rebound')\n")
+    (tmp_path / "modules" / "modules.py").write_text(
+        "import torch\n"
+        "class Feature_Aligner(torch.nn.Module):\n"
+        "    def __init__(self):\n"
+        "        super().__init__()\n"
+        "        self.feature_embedding_2d = torch.nn.Sequential(torch.nn.Conv2d(384, 32, 1, bias=False), torch.nn.ReLU(), torch.nn.Conv2d(32, 32, 1))\n"
+        "    def forward_3d2d(self, img_feat):\n"
+        "        raise AssertionError('Feature_Aligner.forward_3d2d was not rebound')\n")
+    (tmp_path / "test_script.py").write_text(
+        "import sys\n"
+        "import numpy as np\n"
+        "import torch\n"
+        "from utils import rotate_volume\n"
+        "from modules.modules import Feature_Aligner\n"
+        "g = np.load(sys.argv[1])\n"
+        "T = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).cuda()\n"
+        "class M(torch.nn.Module):\n"
+        "    def __init__(self):\n"
+        "        super().__init__()\n"
+        "        self.feature_aligner = Feature_Aligner()\n"
+        "model = M().cuda()\n"
+        "with torch.no_grad():\n"
+        "    fe = model.feature_aligner.feature_embedding_2d\n"
+        "    fe[0].weight.copy_(T('W1').reshape(32, 384, 1, 1)); fe[2].weight.copy_(T('W2').reshape(32, 32, 1, 1)); fe[2].bias.copy_(T('b2'))\n"
+        "model.eval()\n"
+        "proposals, img_feat_src, img_feat_tgt = T('R'), T('vol_src'), T('vol_tgt')\n"
+        "B, C, D, H, W = img_feat_src.shape\n"
+        "img_feat_src_2_tgt = [rotate_volume(img_feat[None].expand(proposals.shape[0], -1, -1, -1, -1), proposals) for img_feat in img_feat_src]\n"
+        "img_feat_src_2_tgt = torch.stack(img_feat_src_2_tgt).reshape(-1, C, D, H, W)\n"
+        "img_feat_src_2_tgt = model.feature_aligner.forward_3d2d(img_feat_src_2_tgt).reshape(B, proposals.shape[0], -1, H*W)\n"
+        "img_feat_tgt = model.feature_aligner.forward_3d2d(img_feat_tgt)\n"
+        "pred_sim = (img_feat_src_2_tgt * img_feat_tgt[:, None]).sum(dim=2).mean(dim=-1)\n"
+        "pred_sim, pred_index = torch.max(pred_sim, dim=1)\n"
+        "pred_src_2_tgt_R = proposals[pred_index]\n"
+        "print('RESULT', pred_index.item(), '%.8f' % pred_sim.item())\n")
+    env = {k: v for k, v in os.environ.items() if k != "AHV_PATCH_DEFER"}
+    out = subprocess.run([sys.executable, os.path.join(repo, "ahv_run.py"), "test_script.py", os.path.join(repo, "tests", "golden", "score_n128.npz")],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert int(line[1]) == int(g128["best_idx"][0]) and abs(float(line[2]) - float(g128["best"][0])) < 1e-5
+    # without the runner the same script dies on the reference's own stand-in
+    bare = subprocess.run([sys.executable, "test_script.py", os.path.join(repo, "tests", "golden", "score_n128.npz")],
+                          cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert bare.returncode != 0 and "was not rebound" in bare.stderr
 
 
 def test_deferred_hypotheses_fall_back_to_the_op_level_kernels(ahv, dev, g128):
