@@ -15,6 +15,7 @@ echo "== bench forced pg, one lane" && AHV_BENCH_FORCE_PG=1 AHV_BENCH_LANES=1 ti
 echo "== bench forced pg, two lanes (what a run of 4 ranks and more takes)" && AHV_BENCH_FORCE_PG=1 AHV_BENCH_TWO_LANES_PG=1 timeout -k 10 600 python3 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_forced_pg_two_lanes.json 2> $O/bench_forced_pg_two_lanes.err; echo rc=$?
 echo "== profile bench" && timeout -k 10 900 bash tools/profile_bench.sh ${1:-eor} > $O/profile.log 2>&1; echo rc=$?
 echo "== bench 2-rank gloo (rehearsal on one GPU; two lanes forced: at 2 ranks the default is one)" && AHV_BENCH_TWO_LANES_MAX_N=25000 timeout -k 10 600 python3 bench.py --gpus 2 --backend gloo --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo rc=$?
+echo "== bench 4-rank gloo (rehearsal on one GPU: the default lane choice of 4 ranks -- two lanes, two groups per rank)" && timeout -k 10 700 python3 bench.py --gpus 4 --backend gloo --steps 40 --warmup 8 --no-cpu-baseline > $O/bench_4rank_gloo.json 2> $O/bench_4rank_gloo.err; echo rc=$?
 fi
 if [[ $HALF == *b* ]]; then
 echo "== secondary" && timeout -k 10 600 python3 tools/bench_configs.py 3 4 5 shard > $O/secondary.jsonl 2> $O/secondary.err; echo rc=$?
