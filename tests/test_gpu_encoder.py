@@ -17,9 +17,10 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max()).item()
 
 
-@pytest.mark.parametrize("B", [1, 3, 16, 17, 24, 32])   # 16: the 128x128-tiled FF kernels (M >= 1024, M % 128 == 0); 17: back on
+@pytest.mark.parametrize("B", [1, 3, 16, 17, 24, 32, 33])   # 16: the 128x128-tiled FF kernels (M >= 1024, M % 128 == 0); 17: back on
                                                          # the skinny ones; 24: attention per (sample, head) (from 192 pairs);
-                                                         # 32: the 64x64-tiled q / k / v projections too (M >= 2048)
+                                                         # 32: the 64x64-tiled q / k / v projections too (M >= 2048); 33: attention
+                                                         # per (sample, head) beside the skinny linears (M % 128 != 0)
 def test_transformer_blocks_match_torch_ops(fa, B):
     g = torch.Generator().manual_seed(B)
     x = torch.randn(B, 256, 8, 8, generator=g).cuda()
