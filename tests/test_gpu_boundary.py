@@ -140,10 +140,12 @@ def test_unchanged_infonce_lines_in_training_mode(ahv, dev, defer):
     R[:, 0] = gt
     ahv.patch.install(um, mm, defer=defer)
     before, dbefore = dict(ahv.patch.calls), dict(ahv.deferred.counters)
+    torch.autograd.set_detect_anomaly(True)        # as the reference's training runs (modules/model_co3d.py:22)
     try:
         loss = ref_infonce_verbatim(um.rotate_volume, fa.forward_3d2d, v1, v2, R, gt, 30.0, N)
         loss.backward()
     finally:
+        torch.autograd.set_detect_anomaly(False)
         ahv.patch.uninstall()
     ran = {k: ahv.patch.calls[k] - before[k] for k in before}
     dran = {k: ahv.deferred.counters[k] - dbefore[k] for k in dbefore}
